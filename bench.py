@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the fused copter step kernel on MI355X.
+
+A "step" is ONE pass of the hot path (one kernel launch = _Task.step() for every env of
+the batch) over one batch of synthetic actions that is already resident in HBM.  Default
+workload = BASELINE.json configs[1]: Lander3D, 65 536 envs, uniform random actions in
+[-1,1)^4, auto-reset on (NEXT_STEP), float32 state words, one GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+Rank 0 prints ONE JSON line (see the task contract): value = whole-job env-steps/s =
+N_gpus * envs_per_gpu * K / max-over-ranks wall time of the K timed steps, plus
+  roofline     : algorithmic bytes (176 B/env-step) per launch over the
+                 launch duration measured with HIP events on the launch stream, vs 8 TB/s
+  cpu_baseline : the scalar NumPy port of the reference (oracle/refcpu.py), timed here on
+                 the host, 1 core, bounded sample (a reported baseline, not a target)
+Multi-GPU: the env batch is sharded by contiguous env-id range with no data-path
+collective in the timed region ("scaling": "weak"); the optional concatenated-observation
+all-gather over RCCL is timed separately and reported as value_with_allgather.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = {"lander3d": 176, "hover3d": 176}
+HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8 TB/s
+HOVER = 0.016560178185018043                        # motor value with thrust == weight
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2000)
+    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    p.add_argument("--task", default="lander3d", choices=["lander3d", "hover3d"])
+    p.add_argument("--actions", default="uniform", choices=["uniform", "near_hover", "const"])
+    p.add_argument("--state", default="float32")
+    p.add_argument("--substeps", type=int, default=1)
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--graph-chunk", type=int, default=100)
+    p.add_argument("--ring", type=int, default=64, help="resident action batches cycled through")
+    p.add_argument("--gather", action="store_true", help="also time with the RCCL obs all-gather")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    return p.parse_args()
+
+
+def make_actions(torch, law, ring, n, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if law == "uniform":
+        return torch.rand((ring, n, 4), generator=g, device=device, dtype=torch.float32) * 2 - 1
+    if law == "near_hover":
+        return HOVER * (1 + 0.01 * torch.randn((ring, n, 4), generator=g, device=device, dtype=torch.float32))
+    return torch.full((ring, n, 4), 1.625e-2, device=device, dtype=torch.float32)
+
+
+class Stepper:
+    """Runs `count` consecutive env steps, as hipGraph replays of `chunk` captured
+    launches plus eager launches for the remainder."""
+
+    def __init__(self, torch, env, actions, use_graph, chunk, post=None):
+        self.torch, self.env, self.actions, self.post = torch, env, actions, post
+        self.ring = actions.shape[0]
+        self.pos = 0
+        self.graph = None
+        self.chunk = chunk
+        if use_graph:
+            s = torch.cuda.Stream(device=env.device)
+            s.wait_stream(torch.cuda.current_stream(env.device))
+            with torch.cuda.stream(s):
+                for j in range(3):       # settle allocations outside capture
+                    self._one(j)
+            torch.cuda.current_stream(env.device).wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                for j in range(chunk):
+                    self._one(j)
+
+    def _one(self, j):
+        self.env.step(self.actions[j % self.ring])
+        if self.post is not None:
+            self.post()
+
+    def run(self, count):
+        done = 0
+        if self.graph is not None:
+            while count - done >= self.chunk:
+                self.graph.replay()
+                done += self.chunk
+        while done < count:
+            self._one(self.pos)
+            self.pos += 1
+            done += 1
+
+
+def cpu_baseline(task, law, seconds):
+    """Scalar NumPy port of the reference (one env per object, same NumPy call structure),
+    one core, bounded sample; plus the vectorised NumPy oracle as an extra row."""
+    import numpy as np
+    from oracle.refcpu import TaskOracle
+    from oracle.refvec import VecOracle
+    rng = np.random.default_rng(0)
+    o = TaskOracle(task)
+    o.reset(rng=rng)
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(500):
+            if law == "uniform":
+                a = rng.uniform(-1, 1, 4)
+            elif law == "near_hover":
+                a = HOVER * (1 + 0.01 * rng.standard_normal(4))
+            else:
+                a = 1.625e-2 * np.ones(4)
+            _, _, done, _, _ = o.step(a)
+            steps += 1
+            if done:
+                o.reset(rng=rng)
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    scalar = steps / dt
+    nv = 65536
+    v = VecOracle(task, nv, store_mode="float32", autoreset=1, seed=1)
+    v.reset()
+    acts = rng.uniform(-1, 1, (nv, 4))
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < max(2.0, seconds / 4):
+        v.step(acts)
+        k += 1
+    vec = nv * k / (time.perf_counter() - t0)
+    return {"value": scalar, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "oracle/refcpu.py TaskOracle (scalar NumPy, reference call structure), %s, "
+                      "'%s' actions, %d steps in %.1f s on 1 of %d host cores"
+                      % (task, law, steps, dt, os.cpu_count()),
+            "vectorised_numpy": {"value": vec, "unit": "env-steps/s", "cores": 1,
+                                 "sample": "oracle/refvec.py VecOracle, %d envs x %d steps" % (nv, k)}}
+
+
+def main():
+    a = parse()
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    import gym_copter_amd
+    n = a.envs
+    env = gym_copter_amd.CopterVecEnv(task=a.task, num_envs=n, device=local, seed=1234,
+                                      autoreset_mode="next_step", state_dtype=a.state,
+                                      substeps=a.substeps, env_id_base=rank * n)
+    actions = make_actions(torch, a.actions, a.ring, n, device, 1234 + rank)
+    env.reset()
+    use_graph = not a.no_graph
+    chunk = min(a.graph_chunk, max(1, a.steps))
+    stepper = Stepper(torch, env, actions, use_graph, chunk)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(st, k):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        st.run(k)
+        ev1.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        wall = t1 - t0
+        if dist is not None:
+            t = torch.tensor([wall], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, ev0.elapsed_time(ev1) * 1e-3
+
+    stepper.run(a.warmup)
+    wall, ev_s = timed(stepper, a.steps)
+    total_envs = n * world
+    value = total_envs * a.steps / wall
+    launch_s = ev_s / a.steps                       # HIP events on the launch stream
+    achieved = ALGO_BYTES[a.task] * n / launch_s / 1e9
+
+    extra = {}
+    if a.gather and dist is not None:
+        gathered = torch.empty((world * n, env.obs_dim), dtype=torch.float32, device=device)
+        post = lambda: dist.all_gather_into_tensor(gathered, env._obs)
+        st2 = Stepper(torch, env, actions, False, chunk, post=post)
+        st2.run(min(a.warmup, 50))
+        w2, _ = timed(st2, a.steps)
+        extra["value_with_allgather"] = total_envs * a.steps / w2
+        extra["ms_per_step_with_allgather"] = w2 / a.steps * 1e3
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("%s_%d" % (a.task, n))
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "env-steps/sec Lander3D at 65 536 envs" if (a.task, n) == ("lander3d", 65536)
+                  else "env-steps/sec %s at %d envs" % (a.task, n),
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s, %d envs/GPU, %s actions, auto-reset NEXT_STEP, %s state words, "
+                               "dt=%g x %d substeps, %s" % (a.task, n, a.actions, a.state,
+                                                          1.0 / (100 * a.substeps), a.substeps,
+                                                          "hipGraph replay of %d-step chunks" % chunk
+                                                          if use_graph else "eager launches"),
+                   "envs_per_gpu": n, "total_envs": total_envs, "task": a.task,
+                   "actions": a.actions, "state_words": a.state, "substeps": a.substeps,
+                   "parallelism": "env-shard x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": "step_kernel<%s,%s>" % (a.task, a.state),
+                     "launch_us": launch_s * 1e6,
+                     "algorithmic_bytes_per_launch": ALGO_BYTES[a.task] * n},
+    }
+    out.update(extra)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.task, a.actions, a.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

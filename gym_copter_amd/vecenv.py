@@ -1,0 +1,315 @@
+"""CopterVecEnv: Gymnasium-style vector environment whose step()/reset() are one HIP
+kernel launch each, through the C ABI of libcopterstep.so.
+
+It mirrors the interface the reference exposes through gym.make('gym_copter:Lander-v0')
+(reference gym_copter/envs/task.py:23-143, envs/lander.py:15-97, gym_copter/__init__.py:9-13),
+widened from one environment to a batch:
+
+    reference (single env)                        here (batch of N)
+    ---------------------------------------------------------------------------------
+    reset(seed, options) -> (obs[10], {})         reset(seed, options) -> (obs[N,10], {})
+    step(a[4]) -> (obs, r, done, False, {})       step(a[N,4]) -> (obs[N,10], r[N], term[N], trunc[N], {})
+    observation_space / action_space              single_*_space + batched *_space
+    set_altitude(a), close(), unwrapped, FRAMES_PER_SECOND, STATE_NAMES, metadata
+
+Device tensors go in and come out zero-copy (torch CUDA/HIP tensors); NumPy actions are
+accepted for drop-in use and then NumPy arrays are returned (paying PCIe both ways).
+PyTorch is used only for device memory and streams.  There is no CPU implementation in
+this package: construction fails if libcopterstep.so or a HIP device is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .spaces import Box, batch_space
+
+_TASKS = {"lander3d": _lib.TASK_LANDER3D, "lander": _lib.TASK_LANDER3D,
+          "hover3d": _lib.TASK_HOVER3D, "hover": _lib.TASK_HOVER3D}
+# float32 (default) = float32 state words + 8 guard bits; see DESIGN.md "state words"
+_STATE_MODES = {"float32": _lib.STATE_F32G, "float32_guard": _lib.STATE_F32G,
+                "float32_rn": _lib.STATE_F32_RN, "float32_sr": _lib.STATE_F32_SR,
+                "float64": _lib.STATE_F64}
+_AUTORESET = {"disabled": _lib.AUTORESET_DISABLED, "next_step": _lib.AUTORESET_NEXT_STEP,
+              "same_step": _lib.AUTORESET_SAME_STEP}
+_VEHICLE_KEYS = ("B", "D", "M", "L", "Ix", "Iy", "Iz", "Jr", "maxrpm")   # dji_phantom.py:9-26
+_TASK_KEYS = {"initial_random_force": "initial_random_force",             # task.py:32-38
+              "out_of_bounds_penalty": "out_of_bounds_penalty",
+              "max_angle": "max_angle_deg", "bounds": "bounds",
+              "initial_altitude": "initial_altitude"}
+
+STATE_NAMES_12 = ['X', 'dX', 'Y', 'dY', 'Z', 'dZ', 'Phi', 'dPhi', 'Theta', 'dTheta', 'Psi', 'dPsi']
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class CopterVecEnv:
+    FRAMES_PER_SECOND = 100                                    # task.py:25
+
+    def __init__(self, task="lander3d", num_envs=1, device=0, seed=0,
+                 autoreset_mode="next_step", substeps=1, state_dtype="float32",
+                 time_limit_truncates=False, episode_stats=False, env_id_base=0,
+                 max_steps=1000, vehicle_params=None, frames_per_second=None, **task_kwargs):
+        lib = _lib.load()
+        torch = _torch()
+        if task not in _TASKS:
+            raise ValueError("unknown task %r (have %s)" % (task, sorted(_TASKS)))
+        if state_dtype not in _STATE_MODES:
+            raise ValueError("unknown state_dtype %r (have %s)" % (state_dtype, sorted(_STATE_MODES)))
+        if autoreset_mode not in _AUTORESET:
+            raise ValueError("unknown autoreset_mode %r (have %s)" % (autoreset_mode, sorted(_AUTORESET)))
+        if isinstance(device, str):
+            device = torch.device(device).index or 0
+        elif isinstance(device, torch.device):
+            device = device.index or 0
+        self._lib = lib
+        self._ctx = C.c_void_p()
+        cfg = _lib.Config()
+        _lib.check(lib.cs_config_init(C.byref(cfg), _TASKS[task]))
+        cfg.state_mode = _STATE_MODES[state_dtype]
+        cfg.autoreset = _AUTORESET[autoreset_mode]
+        cfg.substeps = int(substeps)
+        cfg.time_limit_truncates = int(bool(time_limit_truncates))
+        cfg.episode_stats = int(bool(episode_stats))
+        cfg.device = int(device)
+        cfg.max_steps = int(max_steps)
+        cfg.num_envs = int(num_envs)
+        cfg.env_id_base = int(env_id_base)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if frames_per_second is not None:
+            cfg.frames_per_second = float(frames_per_second)
+            self.FRAMES_PER_SECOND = frames_per_second
+        for k, v in (vehicle_params or {}).items():
+            if k not in _VEHICLE_KEYS:
+                raise ValueError("unknown vehicle parameter %r" % k)
+            setattr(cfg, k, float(v))
+        for k, v in task_kwargs.items():
+            if k not in _TASK_KEYS:
+                raise TypeError("unexpected keyword argument %r" % k)
+            setattr(cfg, _TASK_KEYS[k], float(v))
+        self.config = cfg
+        self.task = "lander3d" if cfg.task == _lib.TASK_LANDER3D else "hover3d"
+        self.num_envs = int(num_envs)
+        self.autoreset_mode = autoreset_mode
+        self.episode_stats = bool(episode_stats)
+        self.device = torch.device("cuda", int(device))
+        self.obs_dim = 10 if cfg.task == _lib.TASK_LANDER3D else 12
+        self.STATE_NAMES = STATE_NAMES_12[:self.obs_dim]          # lander.py:30-31
+        self.metadata = {"render_modes": [], "render_fps": self.FRAMES_PER_SECOND,
+                         "autoreset_mode": autoreset_mode}
+        self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)  # task.py:46-49
+        self.single_action_space = Box(-1, +1, (4,), np.float32)                            # task.py:52-55
+        self.observation_space = batch_space(self.single_observation_space, self.num_envs)
+        self.action_space = batch_space(self.single_action_space, self.num_envs)
+        self.closed = False
+        # cs_create fails loudly when no HIP device is usable (no CPU fallback)
+        _lib.check(lib.cs_create(C.byref(cfg), C.byref(self._ctx)))
+        n = self.num_envs
+        with torch.cuda.device(self.device):
+            self._obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=self.device)
+            self._reward = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._term = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._trunc = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._actions = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+            self._final_obs = None
+            self._done = None
+
+    # -- plumbing ------------------------------------------------------------------
+    @property
+    def unwrapped(self):
+        return self
+
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _dev_f32(self, a, shape, name):
+        """Return (device float32 contiguous tensor view/copy, was_numpy)."""
+        torch = _torch()
+        was_numpy = not isinstance(a, torch.Tensor)
+        if was_numpy:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+        else:
+            t = a
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=torch.float32, non_blocking=True).contiguous()
+        return t, was_numpy
+
+    def _check_open(self):
+        if self.closed:
+            raise RuntimeError("environment is closed")
+
+    # -- Gymnasium surface ---------------------------------------------------------
+    def seed(self, seed=None):                                  # task.py:71-75
+        self._check_open()
+        _lib.check(self._lib.cs_seed(self._ctx, int(seed or 0) & 0xFFFFFFFFFFFFFFFF))
+        return [seed]
+
+    def set_altitude(self, altitude):                           # task.py:67-69
+        self._check_open()
+        _lib.check(self._lib.cs_set_altitude(self._ctx, float(altitude)))
+
+    def reset(self, seed=None, options=None):
+        """Reset every env (or options['mask']); returns (obs[N,obs_dim], {}).
+
+        options: {'mask': bool[N], 'forces': float[3,N] newtons (else Philox U[-F,F))}.
+        seed re-keys the perturbation stream (the reference draws from global np.random,
+        task.py:199-202; here the draw is counter-based on (seed, env id, call count))."""
+        self._check_open()
+        torch = _torch()
+        options = options or {}
+        if seed is not None:
+            self.seed(seed)
+        mask = options.get("mask")
+        forces = options.get("forces")
+        mask_t = force_t = None
+        mask_p = force_p = None
+        if mask is not None:
+            mask_t = torch.as_tensor(np.asarray(mask) if not isinstance(mask, torch.Tensor) else mask)
+            mask_t = (mask_t != 0).to(device=self.device, dtype=torch.uint8).contiguous()
+            if tuple(mask_t.shape) != (self.num_envs,):
+                raise ValueError("mask must have shape (%d,)" % self.num_envs)
+            mask_p = C.c_void_p(mask_t.data_ptr())
+        if forces is not None:
+            force_t, _ = self._dev_f32(forces, (3, self.num_envs), "forces")
+            force_p = C.c_void_p(force_t.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_reset(self._ctx, mask_p, force_p,
+                                          C.c_void_p(self._obs.data_ptr()), self._stream()))
+        self._keep = (mask_t, force_t)      # alive until the stream has consumed them
+        return self._obs, {}
+
+    def step(self, actions):
+        """One env step for the whole batch: exactly one kernel launch, asynchronous on
+        the current torch stream.  Returned tensors are this env's persistent output
+        buffers (overwritten by the next step())."""
+        self._check_open()
+        torch = _torch()
+        a, was_numpy = self._dev_f32(actions, (self.num_envs, 4), "actions")
+        with torch.cuda.device(self.device):
+            if self._final_obs is None and self._done is None:
+                _lib.check(self._lib.cs_step(
+                    self._ctx, C.c_void_p(a.data_ptr()), C.c_void_p(self._obs.data_ptr()),
+                    C.c_void_p(self._reward.data_ptr()), C.c_void_p(self._term.data_ptr()),
+                    C.c_void_p(self._trunc.data_ptr()), self._stream()))
+            else:
+                io = _lib.StepIO()
+                io.actions_dev = a.data_ptr()
+                io.obs_dev = self._obs.data_ptr()
+                io.reward_dev = self._reward.data_ptr()
+                io.terminated_dev = self._term.data_ptr()
+                io.truncated_dev = self._trunc.data_ptr()
+                if self._final_obs is not None:
+                    io.final_obs_dev = self._final_obs.data_ptr()
+                if self._done is not None:
+                    io.done_count_dev = self._done["count"].data_ptr()
+                    io.done_ids_dev = self._done["ids"].data_ptr()
+                    io.done_length_dev = self._done["length"].data_ptr()
+                    if self.episode_stats:
+                        io.done_return_dev = self._done["return"].data_ptr()
+                _lib.check(self._lib.cs_step_ex(self._ctx, C.byref(io), self._stream()))
+        self._keep = a
+        infos = {}
+        if self._final_obs is not None:
+            infos["final_obs"] = self._final_obs
+        if self._done is not None:
+            infos["episode"] = self._done
+        term, trunc = self._term.view(torch.bool), self._trunc.view(torch.bool)
+        if was_numpy:
+            return (self._obs.cpu().numpy(), self._reward.cpu().numpy(), term.cpu().numpy(),
+                    trunc.cpu().numpy(), {k: _to_numpy(v) for k, v in infos.items()})
+        return self._obs, self._reward, term, trunc, infos
+
+    def close(self):                                            # task.py:139-143
+        if not self.closed and self._ctx:
+            self._lib.cs_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+        self.closed = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- optional outputs ------------------------------------------------------------
+    def enable_final_obs(self):
+        """SAME_STEP autoreset: also return the pre-reset observation in infos['final_obs']."""
+        torch = _torch()
+        self._final_obs = torch.zeros((self.num_envs, self.obs_dim), dtype=torch.float32,
+                                      device=self.device)
+
+    def enable_done_list(self):
+        """Compacted list of finished envs per step (wave-ballot compaction on device):
+        infos['episode'] = {'count': i32[1], 'ids': i32[N], 'length': i32[N], 'return': f32[N]}."""
+        torch = _torch()
+        n, dev = self.num_envs, self.device
+        self._done = {"count": torch.zeros(1, dtype=torch.int32, device=dev),
+                      "ids": torch.zeros(n, dtype=torch.int32, device=dev),
+                      "length": torch.zeros(n, dtype=torch.int32, device=dev)}
+        if self.episode_stats:
+            self._done["return"] = torch.zeros(n, dtype=torch.float32, device=dev)
+
+    # -- Dynamics-level access (reference dynamics/__init__.py public methods) ---------
+    def set_motors(self, motors):
+        """`substeps` x Dynamics.setMotors(motors[i]) on every env, no task logic."""
+        self._check_open()
+        torch = _torch()
+        m, _ = self._dev_f32(motors, (self.num_envs, 4), "motors")
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_set_motors(self._ctx, C.c_void_p(m.data_ptr()), self._stream()))
+        self._keep = m
+
+    def get_state(self):
+        """Whole-batch state as NumPy (synchronises): dict with x[12,N] f64, status, steps,
+        prev_shaping (NaN = None), force[3,N] newtons, flags, (episode_return)."""
+        self._check_open()
+        n = self.num_envs
+        out = {"x": np.empty((12, n)), "status": np.empty(n, np.uint8), "steps": np.empty(n, np.int32),
+               "prev_shaping": np.empty(n), "force": np.empty((3, n)), "flags": np.empty(n, np.uint8)}
+        er = np.empty(n) if self.episode_stats else None
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.cs_get_state(self._ctx, p(out["x"]), p(out["status"]), p(out["steps"]),
+                                          p(out["prev_shaping"]), p(out["force"]), p(out["flags"]),
+                                          p(er), self._stream()))
+        if er is not None:
+            out["episode_return"] = er
+        return out
+
+    def set_state(self, x=None, status=None, steps=None, prev_shaping=None, force=None, flags=None,
+                  episode_return=None):
+        self._check_open()
+        n = self.num_envs
+
+        def prep(a, shape, dtype):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(np.asarray(a, dtype=dtype))
+            if a.shape != shape:
+                raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+            return a
+        arrs = [prep(x, (12, n), np.float64), prep(status, (n,), np.uint8), prep(steps, (n,), np.int32),
+                prep(prev_shaping, (n,), np.float64), prep(force, (3, n), np.float64),
+                prep(flags, (n,), np.uint8), prep(episode_return, (n,), np.float64)]
+        ptrs = [None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs]
+        _lib.check(self._lib.cs_set_state(self._ctx, *ptrs, self._stream()))
+
+    @property
+    def epoch(self):
+        v = C.c_uint64()
+        _lib.check(self._lib.cs_get_epoch(self._ctx, C.byref(v), self._stream()))
+        return v.value
+
+    @epoch.setter
+    def epoch(self, value):
+        _lib.check(self._lib.cs_set_epoch(self._ctx, int(value), self._stream()))
+
+
+def _to_numpy(v):
+    if isinstance(v, dict):
+        return {k: _to_numpy(x) for k, x in v.items()}
+    return v.cpu().numpy()

@@ -1,0 +1,174 @@
+/*
+ * copterstep.h -- C ABI of libcopterstep.so: a batch ("vector env") stepper for the
+ * gym-copter rigid-body hot path on AMD MI355X (gfx950).
+ *
+ * The upstream project (simondlevy/gym-copter) is pure Python and has no FFI layer;
+ * the interface this ABI stands behind is its Gymnasium Env surface plus the public
+ * methods of its Dynamics class.  Each entry point names the upstream code it
+ * replaces (paths relative to the upstream checkout):
+ *
+ *   cs_create / cs_destroy   Lander.__init__ / _Task.__init__   envs/lander.py:25-33, envs/task.py:32-65
+ *                            Dynamics.__init__                  dynamics/__init__.py:78-112
+ *                            _Task.close                        envs/task.py:139-143
+ *   cs_config_init           constructor defaults + constants   envs/task.py:25,32-38, envs/lander.py:17-23,
+ *                                                               dynamics/__init__.py:71-76, vehicles/dji_phantom.py:9-26
+ *   cs_seed                  _Task.seed                         envs/task.py:71-75
+ *   cs_reset                 Lander.reset -> _Task._reset       envs/lander.py:35-37, envs/task.py:145-202
+ *   cs_step / cs_step_ex     _Task.step + Lander._get_reward    envs/task.py:77-137, envs/lander.py:39-74
+ *                            (+ attic hover.py:18-21, hover3d.py:32-37 for CS_TASK_HOVER3D)
+ *                            which calls Dynamics.setMotors     dynamics/__init__.py:114-197,249-302
+ *   cs_set_motors            Dynamics.setMotors (used directly) dynamics/__init__.py:114-197
+ *   cs_get_state             Dynamics.getState / getStatus      dynamics/__init__.py:199-207,223-225
+ *   cs_set_state             Dynamics.setState / perturb        dynamics/__init__.py:210-217,227-229
+ *   cs_set_altitude          _Task.set_altitude                 envs/task.py:67-69
+ *
+ * Conventions
+ *   - Every function returns CS_OK (0) or a negative cs_status; cs_last_error() then
+ *     holds a thread-local message.  Nothing throws across this boundary.
+ *   - A context owns all of its device allocations (freed by cs_destroy) and belongs to
+ *     ONE HIP device.  Pointers named *_dev are device pointers owned by the caller;
+ *     pointers named *_host are host pointers.
+ *   - cs_reset / cs_step / cs_step_ex / cs_set_motors only ENQUEUE work on `stream`
+ *     (a hipStream_t, NULL = the null stream) and return; the caller synchronises.
+ *     They may be captured into a hipGraph: they allocate nothing and never
+ *     synchronise.  cs_get_state / cs_set_state synchronise `stream`.
+ *   - A context is not thread-safe; distinct contexts may be driven from distinct threads.
+ *   - There is no CPU fallback: without a HIP device cs_create fails with CS_ERR_DEVICE.
+ */
+#ifndef COPTERSTEP_H
+#define COPTERSTEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_ABI_VERSION 1
+
+typedef enum cs_status {
+  CS_OK = 0,
+  CS_ERR_ARG = -1,      /* bad argument (null pointer, bad enum, bad size) */
+  CS_ERR_DEVICE = -2,   /* no usable HIP device / device ordinal out of range */
+  CS_ERR_MEMORY = -3,   /* device or host allocation failed */
+  CS_ERR_HIP = -4,      /* a HIP runtime call failed */
+  CS_ERR_ABI = -5       /* cs_config.struct_size / abi_version mismatch */
+} cs_status;
+
+enum { CS_TASK_LANDER3D = 0, CS_TASK_HOVER3D = 1 };
+
+/* How the 12 state words are kept in HBM.  Arithmetic is float64 in registers in
+ * every mode; the mode only selects the stored word and its rounding. */
+enum {
+  CS_STATE_F32G = 0,    /* float32 words + 8 guard bits per component, packed four
+                           to a dword (default; +24 B per env-step of traffic)    */
+  CS_STATE_F32_RN = 1,  /* float32 words only, round-to-nearest-even              */
+  CS_STATE_F64 = 2,     /* float64 words                                          */
+  CS_STATE_F32_SR = 3   /* float32 words only, stochastic rounding                */
+};
+
+/* Gymnasium vector-env autoreset conventions (upstream has a single env and none). */
+enum {
+  CS_AUTORESET_DISABLED = 0,  /* upstream behaviour: a finished env just keeps stepping */
+  CS_AUTORESET_NEXT_STEP = 1, /* the step after a done resets (action ignored, reward 0) */
+  CS_AUTORESET_SAME_STEP = 2  /* reset inside the finishing step; obs = reset obs        */
+};
+
+/* Flight status codes, dynamics/__init__.py:65-68 */
+enum { CS_STATUS_CRASHED = 0, CS_STATUS_LANDED = 1, CS_STATUS_LEVELING = 2, CS_STATUS_AIRBORNE = 3 };
+
+typedef struct cs_config {
+  uint32_t struct_size;     /* = sizeof(cs_config), set by cs_config_init */
+  uint32_t abi_version;     /* = CS_ABI_VERSION */
+  int32_t task;             /* CS_TASK_* */
+  int32_t state_mode;       /* CS_STATE_* */
+  int32_t autoreset;        /* CS_AUTORESET_* */
+  int32_t substeps;         /* Dynamics.setMotors calls per env step (upstream: 1) */
+  int32_t time_limit_truncates; /* 0 = upstream (step limit folded into `terminated`) */
+  int32_t episode_stats;    /* 1 = keep per-env episode return on device */
+  int32_t device;           /* HIP device ordinal */
+  int32_t max_steps;        /* task.py:35 */
+  int64_t num_envs;         /* environments held by this context (this shard) */
+  int64_t env_id_base;      /* global id of local env 0: keys the RNG so that a batch
+                               sharded over several contexts/GPUs is shard-invariant */
+  uint64_t seed;
+  double frames_per_second; /* task.py:25; dt = 1 / (frames_per_second * substeps) */
+  /* vehicle, dji_phantom.py:9-26 */
+  double B, D, M, L, Ix, Iy, Iz, Jr, maxrpm;
+  /* dynamics constants, dynamics/__init__.py:71-76 */
+  double G, landing_vel_x, landing_vel_y, landing_angle;
+  /* task, task.py:32-38 */
+  double initial_random_force, out_of_bounds_penalty, max_angle_deg, bounds, initial_altitude;
+  /* lander, lander.py:17-23 */
+  double target_radius, yaw_penalty_factor, xyz_penalty_factor, dz_max, dz_penalty,
+      inside_radius_bonus;
+} cs_config;
+
+typedef struct cs_ctx cs_ctx;
+
+/* Optional outputs of one step.  Any pointer may be NULL. */
+typedef struct cs_step_io {
+  const float* actions_dev;  /* [N,4] row-major, required */
+  float* obs_dev;            /* [N,obs_dim] row-major (10 Lander3D / 12 Hover3D) */
+  float* reward_dev;         /* [N] */
+  uint8_t* terminated_dev;   /* [N] */
+  uint8_t* truncated_dev;    /* [N] */
+  float* final_obs_dev;      /* [N,obs_dim]; SAME_STEP only: pre-reset observation of
+                                envs that finished this step (other rows untouched) */
+  /* done-mask compaction (wave ballot): ids of the envs that finished this step,
+     their episode return and length, in unspecified order; *done_count_dev is
+     zeroed by the library on `stream` before the kernel runs. */
+  int32_t* done_count_dev;   /* [1] */
+  int32_t* done_ids_dev;     /* [N] local env index */
+  float* done_return_dev;    /* [N] (needs cfg.episode_stats) */
+  int32_t* done_length_dev;  /* [N] */
+} cs_step_io;
+
+int cs_version(void);
+const char* cs_last_error(void);
+
+int cs_config_init(cs_config* cfg, int task);
+int cs_create(const cs_config* cfg, cs_ctx** out);
+int cs_destroy(cs_ctx* ctx);
+
+int cs_num_envs(const cs_ctx* ctx, int64_t* out);
+int cs_obs_dim(const cs_ctx* ctx, int32_t* out);
+int cs_seed(cs_ctx* ctx, uint64_t seed);
+int cs_set_altitude(cs_ctx* ctx, double altitude);
+/* Call counter that keys the per-call random streams.  It lives in device memory and is
+ * advanced by every reset/step/set_motors KERNEL (so a captured hipGraph replays with
+ * fresh keys); both calls synchronise `stream`. */
+int cs_get_epoch(cs_ctx* ctx, uint64_t* out, void* stream);
+int cs_set_epoch(cs_ctx* ctx, uint64_t epoch, void* stream);
+
+/* Reset envs with mask_dev[i] != 0 (NULL = all).  force_xyz_dev: [3,N] perturbation
+ * forces in newtons to install (NULL = draw U[-F,F) with Philox4x32-10 keyed by
+ * (seed, global env id, epoch)).  obs_dev (nullable) receives ALL envs' observations. */
+int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, float* obs_dev,
+             void* stream);
+
+int cs_step(cs_ctx* ctx, const float* actions_dev, float* obs_dev, float* reward_dev,
+            uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
+int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream);
+
+/* Physics only: `substeps` x Dynamics.setMotors(motors[i]) on every env, raw motor
+ * values (no clipping, no task logic). */
+int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream);
+
+/* Whole-batch state exchange with HOST buffers (parity tests, checkpoint/restore).
+ * Any pointer may be NULL.  x_host is [12,N] float64 struct-of-arrays in upstream slot
+ * order (x,dx,y,dy,z,dz,phi,dphi,theta,dtheta,psi,dpsi); force_xyz_host is [3,N] newtons;
+ * flags_host bit0 = perturbation pending, bit1 = reset pending (NEXT_STEP);
+ * prev_shaping NaN = upstream's None. */
+int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
+                 double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
+                 double* episode_return_host, void* stream);
+int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
+                 const int32_t* steps_host, const double* prev_shaping_host,
+                 const double* force_xyz_host, const uint8_t* flags_host,
+                 const double* episode_return_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COPTERSTEP_H */

@@ -1,0 +1,397 @@
+"""
+oracle/refvec.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+NumPy-vectorised batch restatement of the gym-copter hot path.  It follows the
+same float64 operation order as oracle/refcpu.py (which is pinned bit-for-bit
+against golden traces of the real reference) and tests/test_oracle_vec.py
+proves the two agree bit-for-bit, so this file inherits that pin.  On top of
+the reference semantics it models the *batch* features the device library adds
+(none of which exist upstream): struct-of-arrays state, storage dtype
+(float32 state words with float64 arithmetic), inner substeps, masked
+auto-reset with a counter-based Philox4x32-10 perturbation draw, and the
+time-limit-as-truncation option.  It is the checker the GPU parity tests and
+__graft_entry__.smoke() compare the HIP kernels against, and the
+"vectorised" row of bench.py's cpu_baseline.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.
+
+Reference lines followed (paths relative to the upstream checkout):
+  gym_copter/dynamics/__init__.py:114-197, :249-302   (physics, via refcpu.RigidBody)
+  gym_copter/envs/task.py:77-137, :145-202            (step / reset)
+  gym_copter/envs/lander.py:46-74                     (Lander reward)
+  attic/gym_copter/envs/hover.py:18-21, hover3d.py:32-37
+"""
+
+import numpy as np
+
+from .refcpu import (AIRBORNE, CRASHED, DJI_PHANTOM, G, LANDED, LANDING_ANGLE,
+                     LANDING_VEL_X, LANDING_VEL_Y, LEVELING, TaskParams)
+
+AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
+
+# ---------------------------------------------------------------------------
+# Philox4x32-10 (Salmon et al., SC'11).  counter = 4 x u32, key = 2 x u32.
+# ---------------------------------------------------------------------------
+_PH_M0, _PH_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PH_W0, _PH_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+_U32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """All arguments uint32 arrays (broadcastable).  Returns 4 uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
+    k0 = np.asarray(k0, dtype=np.uint32)
+    k1 = np.asarray(k1, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        for r in range(10):
+            p0 = _PH_M0 * c0.astype(np.uint64)
+            p1 = _PH_M1 * c2.astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & _U32).astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & _U32).astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            if r < 9:
+                k0 = (k0 + _PH_W0).astype(np.uint32)
+                k1 = (k1 + _PH_W1).astype(np.uint32)
+    return c0, c1, c2, c3
+
+
+def draw_forces(seed, env_ids, epoch, magnitude):
+    """Perturbation force draw shared (by specification) with the device kernel.
+
+    counter = (env_id lo, env_id hi, epoch lo, epoch hi), key = (seed lo, seed hi);
+    u = (word >> 8) * 2^-24 in [0,1);  F = u * (2*magnitude) - magnitude, float64,
+    un-fused multiply then add.  Returns [3, n] float64.
+    """
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    epoch = np.uint64(epoch)
+    seed = np.uint64(seed)
+    sh = np.uint64(32)
+    r = philox4x32_10((env_ids & _U32).astype(np.uint32), (env_ids >> sh).astype(np.uint32),
+                      np.uint32(epoch & _U32), np.uint32(epoch >> sh),
+                      np.uint32(seed & _U32), np.uint32(seed >> sh))
+    out = np.empty((3, env_ids.shape[0]))
+    for i in range(3):
+        u = (r[i] >> np.uint32(8)).astype(np.float64) * (2.0 ** -24)
+        out[i] = u * (2.0 * float(magnitude)) - float(magnitude)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Stored-word rounding shared (by specification) with the device kernels.
+# ---------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def _lowbias32(x):
+    x = x.astype(np.uint32)
+    with np.errstate(over="ignore"):
+        x = x ^ (x >> np.uint32(16))
+        x = (x * np.uint32(0x7feb352d)).astype(np.uint32)
+        x = x ^ (x >> np.uint32(15))
+        x = (x * np.uint32(0x846ca68b)).astype(np.uint32)
+        x = x ^ (x >> np.uint32(16))
+    return x
+
+
+def sr_keys(seed, epoch):
+    a = _splitmix64((seed ^ ((epoch * 0x9E3779B97F4A7C15) & _M64)) & _M64)
+    b = _splitmix64(a)
+    return a & 0xFFFFFFFF, a >> 32, b & 0xFFFFFFFF
+
+
+def stochastic_round_f32(x64, env_ids, seed, epoch):
+    """float64 [12,n] -> float32 [12,n]: add 8 hashed random bits below the float32 ulp
+    (bits 28..21 of the float64 mantissa), truncate the 29 dropped bits, convert (exact)."""
+    k0, k1, k2 = sr_keys(int(seed), int(epoch))
+    gid = (np.asarray(env_ids, dtype=np.uint64) & _U32).astype(np.uint32)
+    h0 = _lowbias32(gid ^ np.uint32(k0))
+    h1 = _lowbias32(h0 ^ np.uint32(k1))
+    h2 = _lowbias32(h1 ^ np.uint32(k2))
+    hs = (h0, h1, h2)
+    out = np.empty(x64.shape, dtype=np.float32)
+    for k in range(12):
+        rnd = ((hs[k >> 2] >> np.uint32(8 * (k & 3))) & np.uint32(0xFF)).astype(np.uint64)
+        b = np.ascontiguousarray(x64[k], dtype=np.float64).view(np.uint64)
+        with np.errstate(over="ignore"):
+            b = (b + (rnd << np.uint64(21))) & np.uint64(~0x1FFFFFFF & _M64)
+        with np.errstate(over="ignore", invalid="ignore"):
+            out[k] = b.view(np.float64).astype(np.float32)
+    return out
+
+
+def guard_round(x64):
+    """float64 -> the nearest value with 32 significant bits (a float32 word plus 8 guard
+    bits), as float64: add half of mantissa bit 21, clear bits 20..0."""
+    b = np.ascontiguousarray(x64, dtype=np.float64).view(np.uint64)
+    with np.errstate(over="ignore"):
+        b = (b + np.uint64(1 << 20)) & np.uint64(~0x1FFFFF & _M64)
+    return b.view(np.float64)
+
+
+def guard_observe(x64):
+    """float32 observation of guard-mode state: the truncated float32 word, bumped one ulp
+    when the guard byte is >= 128 (integer add on the float32 bit pattern)."""
+    b = np.ascontiguousarray(x64, dtype=np.float64).view(np.uint64)
+    guard = ((b >> np.uint64(21)) & np.uint64(0xFF)).astype(np.uint32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        w = (b & np.uint64(~0x1FFFFFFF & _M64)).view(np.float64).astype(np.float32)
+    return (w.view(np.uint32) + (guard >> np.uint32(7))).view(np.float32)
+
+
+# mode -> (dtype of the float words: prev_shaping / force / x words, container dtype of x, rounding)
+STORE_MODES = {"float32": (np.float32, np.float64, "guard"),
+               "float32_guard": (np.float32, np.float64, "guard"),
+               "float32_rn": (np.float32, np.float32, "rn"),
+               "float32_sr": (np.float32, np.float32, "sr"),
+               "float64": (np.float64, np.float64, "rn")}
+
+
+# ---------------------------------------------------------------------------
+class VecOracle:
+    """Batch of independent Lander3D / Hover3D environments on the CPU."""
+
+    def __init__(self, task="lander3d", num_envs=1, tp=TaskParams(), vp=DJI_PHANTOM,
+                 substeps=1, store_mode="float64", autoreset=AUTORESET_DISABLED,
+                 seed=0, env_id_base=0, time_limit_truncates=False):
+        assert task in ("lander3d", "hover3d")
+        self.task, self.n, self.tp, self.vp = task, int(num_envs), tp, vp
+        self.substeps = int(substeps)
+        word, xdtype, self.rounding = STORE_MODES[store_mode]
+        self.T = np.dtype(word)
+        self.autoreset = autoreset
+        self.seed = int(seed)
+        self.env_ids = np.arange(env_id_base, env_id_base + self.n, dtype=np.uint64)
+        self.time_limit_truncates = bool(time_limit_truncates)
+        self.obs_dim = 10 if task == "lander3d" else 12
+        self.dt = 1. / (tp.frames_per_second * self.substeps)
+        self.max_angle = np.radians(tp.max_angle)
+        self.epoch = 0                       # +1 per reset()/step() call (Philox counter)
+        n = self.n
+        self.x = np.zeros((12, n), dtype=xdtype)          # struct-of-arrays state
+        self.status = np.full(n, LANDED, dtype=np.uint8)
+        self.steps = np.zeros(n, dtype=np.int32)
+        self.prev_shaping = np.full(n, np.nan, dtype=self.T)   # NaN == "None"
+        self.force = np.zeros((3, n), dtype=self.T)       # pending perturbation force [N]
+        self.pending = np.zeros(n, dtype=bool)            # perturbation not yet consumed
+        self.done_pending = np.zeros(n, dtype=bool)       # NEXT_STEP: reset on next step
+        self.ep_return = np.zeros(n)
+        self.ep_length = np.zeros(n, dtype=np.int32)
+
+    # ------------------------------------------------------------------ physics
+    def _physics(self, x, status, pend, k, motors, active):
+        """One Dynamics.setMotors() for every lane with active[i]; float64 in, in place.
+
+        x [12,n] f64, status [n] u8, pend [n] bool, k [3,n] f64 (= force / M),
+        motors [n,4] f64 (already clipped by the task, or raw in dynamics-only use).
+        """
+        p = self.vp
+        w = motors * p.maxrpm * np.pi / 30
+        w2 = w ** 2
+        w0, w1, w2_, w3 = w2[:, 0], w2[:, 1], w2[:, 2], w2[:, 3]
+        U1 = p.B * (((w0 + w1) + w2_) + w3)
+        U2 = p.L * p.B * ((w1 + w2_) - (w0 + w3))
+        U3 = p.L * p.B * ((w1 + w3) - (w0 + w2_))
+        U4 = p.D * ((w0 + w1) - (w2_ + w3))
+        Omega = 0
+
+        phi, the, psi = x[6], x[8], x[10]
+        cph, cth, cps = np.cos(phi), np.cos(the), np.cos(psi)
+        sph, sth, sps = np.sin(phi), np.sin(the), np.sin(psi)
+        bz = -U1 / p.M
+        ax = bz * (sph * sps + cph * cps * sth)
+        ay = bz * (cph * sps * sth - cps * sph)
+        az = bz * (cph * cth)
+        netz = az + G
+
+        st = status.copy()
+        st[active & (st == LANDED) & (netz < 0)] = AIRBORNE
+
+        leveling = active & (st == LEVELING)
+        air = active & (st == AIRBORNE)
+        contact = air & (x[4] > 0) & (x[5] > 0)
+        hard = (x[5] > LANDING_VEL_Y) | (np.abs(x[3]) > LANDING_VEL_X) | (np.abs(x[6]) > LANDING_ANGLE)
+        integ = air & ~contact
+
+        kx = np.where(pend, k[0], 0.0)
+        ky = np.where(pend, k[1], 0.0)
+        kz = np.where(pend, k[2], 0.0)
+        dphi, dthe, dpsi = x[7], x[9], x[11]
+        d = np.empty_like(x)
+        d[0] = x[1]
+        d[1] = ax + kx
+        d[2] = x[3]
+        d[3] = ay + ky
+        d[4] = x[5]
+        d[5] = netz + kz
+        d[6] = dphi
+        d[7] = dpsi * dthe * (p.Iy - p.Iz) / p.Ix - p.Jr / p.Ix * dthe * Omega + U2 / p.Ix + 0.0
+        d[8] = dthe
+        d[9] = -(dpsi * dphi * (p.Iz - p.Ix) / p.Iy + p.Jr / p.Iy * dphi * Omega + U3 / p.Iy) + 0.0
+        d[10] = dpsi
+        d[11] = dthe * dphi * (p.Ix - p.Iy) / p.Iz + U4 / p.Iz + 0.0
+        d[1] += kx
+        d[3] += ky
+        d[5] += kz
+        d[7] += 0.0
+        d[9] += 0.0
+        d[11] += 0.0
+        xn = x + self.dt * d
+        x[:, integ] = xn[:, integ]
+
+        x[6, leveling] = 0
+        x[8, leveling] = 0
+        st[leveling] = LANDED
+        st[contact] = np.where(hard[contact], CRASHED, LEVELING)
+        status[:] = st
+        # perturbation is consumed by every call that does not freeze on contact
+        pend[active & ~contact] = False
+
+    # ------------------------------------------------------------------ reset
+    def _reset_lanes(self, m, forces=None):
+        """Masked reset (task.py:145-197): state, status, perturbation, the
+        'initializing' step's shaping, steps = 1."""
+        tp = self.tp
+        if not np.any(m):
+            return
+        self.x[:, m] = 0
+        self.x[4, m] = self.T.type(-tp.initial_altitude)
+        self.status[m] = AIRBORNE if -tp.initial_altitude < 0 else LANDED
+        if forces is None:
+            f = draw_forces(self.seed, self.env_ids[m], self.epoch, tp.initial_random_force)
+        else:
+            f = np.asarray(forces, dtype=np.float64)[:, m]
+        self.force[:, m] = f.astype(self.T)
+        self.pending[m] = True
+        self.done_pending[m] = False
+        xs = self.x[:, m].astype(np.float64)
+        if self.task == "lander3d":
+            self.prev_shaping[m] = self._shaping(xs).astype(self.T)
+        else:
+            self.prev_shaping[m] = np.nan
+        self.steps[m] = 1
+        self.ep_return[m] = 0
+        self.ep_length[m] = 0
+
+    def reset(self, mask=None, forces=None, seed=None):
+        """Reset all lanes (mask None) or lanes with mask[i] != 0.  Returns obs [n, obs_dim] f32."""
+        if seed is not None:
+            self.seed = int(seed)
+        m = np.ones(self.n, dtype=bool) if mask is None else np.asarray(mask).astype(bool)
+        self._reset_lanes(m, forces)
+        self.epoch += 1
+        return self.observe()
+
+    def observe(self):
+        if self.rounding == "guard":
+            return np.ascontiguousarray(guard_observe(self.x[:self.obs_dim]).T)
+        return np.ascontiguousarray(self.x[:self.obs_dim].T.astype(np.float32))
+
+    # ------------------------------------------------------------------ reward
+    def _shaping(self, x):
+        tp = self.tp
+        s6 = ((((x[0] ** 2 + x[1] ** 2) + x[2] ** 2) + x[3] ** 2) + x[4] ** 2) + x[5] ** 2
+        s2 = x[10] ** 2 + x[11] ** 2
+        sh = -(tp.xyz_penalty_factor * np.sqrt(s6) + tp.yaw_penalty_factor * np.sqrt(s2))
+        return np.where(np.abs(x[5]) > tp.dz_max, sh - tp.dz_penalty, sh)
+
+    # ------------------------------------------------------------------ dynamics-only stepping
+    def set_motors(self, motors):
+        """Dynamics.setMotors() on every lane with raw (unclipped) motor values: the
+        reference's L2 interface, used to replay the D-series traces."""
+        x = self.x.astype(np.float64)
+        k = self.force.astype(np.float64) / self.vp.M
+        motors = np.asarray(motors, dtype=np.float64)
+        active = np.ones(self.n, dtype=bool)
+        for _ in range(self.substeps):
+            self._physics(x, self.status, self.pending, k, motors, active)
+        self.x[:] = self._round(x)
+        self.epoch += 1
+
+    def _round(self, x64):
+        """float64 registers -> stored state words."""
+        if self.rounding == "sr":
+            return stochastic_round_f32(x64, self.env_ids, self.seed, self.epoch)
+        if self.rounding == "guard":
+            return guard_round(x64)
+        with np.errstate(over="ignore"):
+            return x64.astype(self.T)
+
+    # ------------------------------------------------------------------ step
+    def step(self, actions):
+        tp, n = self.tp, self.n
+        actions = np.asarray(actions, dtype=np.float64).reshape(n, 4)
+        obs = np.empty((n, self.obs_dim), dtype=np.float32)
+        reward = np.zeros(n)
+        term = np.zeros(n, dtype=bool)
+        trunc = np.zeros(n, dtype=bool)
+
+        resetting = self.done_pending.copy() if self.autoreset == AUTORESET_NEXT_STEP else np.zeros(n, bool)
+        live = ~resetting
+
+        status0 = self.status.copy()
+        x = self.x.astype(np.float64)
+        k = self.force.astype(np.float64) / self.vp.M
+        motors = np.clip(actions, 0, 1)
+        active = live & (status0 != LANDED)
+        for _ in range(self.substeps):
+            self._physics(x, self.status, self.pending, k, motors, active)
+        self.x[:, live] = self._round(x)[:, live]
+
+        # task logic on the *stored* (rounded) state, float64 arithmetic
+        x = self.x.astype(np.float64)
+        done = np.zeros(n, dtype=bool)
+        if self.task == "lander3d":
+            sh = self._shaping(x)
+            prev = self.prev_shaping.astype(np.float64)
+            r = np.where(np.isnan(prev), 0.0, sh - prev)
+            self.prev_shaping[live] = sh.astype(self.T)[live]
+            landed0 = status0 == LANDED
+            done |= landed0
+            inside = np.sqrt(x[0] ** 2 + x[2] ** 2) < tp.target_radius
+            r = np.where(landed0 & inside, r + tp.inside_radius_bonus, r)
+        else:
+            r = np.ones(n)
+        oob = (np.abs(x[0]) >= tp.bounds) | (np.abs(x[2]) >= tp.bounds)
+        tilt = ~oob & ((np.abs(x[6]) >= self.max_angle) | (np.abs(x[8]) >= self.max_angle))
+        crash = ~oob & ~tilt & (status0 == CRASHED)
+        r = np.where(oob, r - tp.out_of_bounds_penalty, r)
+        r = np.where(tilt, -float(tp.out_of_bounds_penalty), r)
+        done |= oob | tilt | crash
+        limit = self.steps == tp.max_steps
+        if self.time_limit_truncates:
+            tr = limit & ~done
+        else:
+            tr = np.zeros(n, dtype=bool)
+            done |= limit
+        self.steps[live] += 1
+
+        reward[live] = r[live]
+        term[live] = done[live]
+        trunc[live] = tr[live]
+        obs[:] = self.observe()
+
+        fin = live & (term | trunc)
+        self.ep_return[live] += r[live]
+        self.ep_length[live] += 1
+        self.last_done = np.flatnonzero(fin)
+        self.last_return = self.ep_return[fin].copy()
+        self.last_length = self.ep_length[fin].copy()
+        self.final_obs = obs.copy()
+
+        if self.autoreset == AUTORESET_NEXT_STEP:
+            self._reset_lanes(resetting)
+            obs[resetting] = self.observe()[resetting]
+            self.done_pending = fin
+        elif self.autoreset == AUTORESET_SAME_STEP:
+            self._reset_lanes(fin)
+            obs[fin] = self.observe()[fin]
+        self.epoch += 1
+        return obs, reward, term, trunc

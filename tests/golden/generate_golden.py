@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""
+DEV-ONLY fixture generator.  Runs ONLY in the build container, where the
+upstream reference checkout is mounted read-only at /root/reference.  It
+imports the reference's own NumPy implementation, drives it with recorded
+inputs and writes small golden .npz files next to this script.  Nothing in
+here travels as code to the GPU box except this script itself (as provenance);
+the GPU box only ever reads the .npz data.
+
+What is imported from the reference (never copied):
+  * gym_copter/dynamics/__init__.py            -> class Dynamics   (D-series)
+  * gym_copter/dynamics/vehicles/dji_phantom.py -> vehicle_params
+  * gym_copter/envs/task.py, envs/lander.py    -> _Task, Lander    (E-series)
+`gymnasium` is not installed in the container, and the reference only uses a
+handful of names from it (Env, spaces.Box, utils.EzPickle, utils.seeding,
+envs.registration.register), so a tiny in-memory stand-in for those names is
+registered in sys.modules before the import.  The stand-in holds no reference
+code.
+
+Hover3D (attic/gym_copter/envs/hover3d.py + hover.py) cannot be imported (it
+needs modules that no longer exist upstream), so its fixture is produced by a
+subclass of the *imported live* _Task whose two overrides restate
+hover.py:18-21 (reward == 1) and hover3d.py:32-37 (12-component observation).
+
+Inputs are made float32-representable (actions, perturbation forces) so that
+the fp32 device path can be fed bit-identical inputs; the reference still
+computes everything in float64.
+
+Usage:  python tests/golden/generate_golden.py   (rewrites tests/golden/*.npz)
+"""
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("COPTER_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------
+# in-memory gymnasium stand-in (only the names the reference touches)
+# --------------------------------------------------------------------------
+def _install_gymnasium_standin():
+    if "gymnasium" in sys.modules:
+        return
+    gym = types.ModuleType("gymnasium")
+
+    class Env:
+        @property
+        def unwrapped(self):
+            return self
+
+        def close(self):
+            pass
+
+    class Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    class EzPickle:
+        def __init__(self, *a, **k):
+            pass
+
+    spaces = types.ModuleType("gymnasium.spaces")
+    spaces.Box = Box
+    utils = types.ModuleType("gymnasium.utils")
+    utils.EzPickle = EzPickle
+    seeding = types.ModuleType("gymnasium.utils.seeding")
+    seeding.np_random = lambda seed=None: (np.random.default_rng(seed), seed)
+    utils.seeding = seeding
+    envs = types.ModuleType("gymnasium.envs")
+    registration = types.ModuleType("gymnasium.envs.registration")
+    registration.register = lambda **kw: None
+    envs.registration = registration
+    gym.Env, gym.spaces, gym.utils, gym.envs = Env, spaces, utils, envs
+    sys.modules.update({
+        "gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.utils": utils,
+        "gymnasium.utils.seeding": seeding, "gymnasium.envs": envs,
+        "gymnasium.envs.registration": registration})
+
+
+def load_reference():
+    _install_gymnasium_standin()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    dyn = importlib.import_module("gym_copter.dynamics")
+    veh = importlib.import_module("gym_copter.dynamics.vehicles.dji_phantom")
+    task = importlib.import_module("gym_copter.envs.task")
+    lander = importlib.import_module("gym_copter.envs.lander")
+    return dyn.Dynamics, veh.vehicle_params, task._Task, lander.Lander
+
+
+def f32r(a):
+    """Round to float32 and return as float64 (exactly representable both ways)."""
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+# hover motor value: B*4*w^2 = M*G  ->  m = sqrt(M*G/(4B)) / (maxrpm*pi/30)
+def hover_motor(vp, G=9.80665):
+    return float(np.sqrt(vp["M"] * G / (4 * vp["B"])) / (vp["maxrpm"] * np.pi / 30))
+
+
+# --------------------------------------------------------------------------
+# D-series: Dynamics.setMotors() traces
+# --------------------------------------------------------------------------
+def run_dynamics(Dynamics, vp, fps, x0, force, motors):
+    """motors: [T,4] float64.  Returns per-call x[T,12], status[T], ticks[T]."""
+    d = Dynamics(vp, fps)
+    d.setState(np.array(x0, dtype=np.float64))
+    status0 = d.getStatus()
+    if force is not None:
+        d.perturb(np.array(force, dtype=np.float64))
+    T = motors.shape[0]
+    xs = np.zeros((T, 12))
+    st = np.zeros(T, dtype=np.int8)
+    tk = np.zeros(T, dtype=np.int64)
+    for t in range(T):
+        d.setMotors(motors[t])
+        xs[t] = d._x
+        st[t] = d.getStatus()
+        tk[t] = d._ticks
+    return dict(fps=np.int64(fps), x0=np.array(x0, dtype=np.float64),
+                status0=np.int8(status0),
+                force=np.zeros(6) if force is None else np.array(force, dtype=np.float64),
+                motors=motors, x=xs, status=st, ticks=tk)
+
+
+def d_series(Dynamics, vp):
+    rng = np.random.default_rng(20240117)
+    hov = hover_motor(vp)
+    cases = {}
+
+    def airborne(alt=10.0, **kw):
+        x = np.zeros(12)
+        x[4] = -alt
+        for k, v in kw.items():
+            x[int(k[1:])] = v
+        return x
+
+    T = 1000
+    ones = np.ones((T, 4))
+    # D01 constant sub-hover thrust (lander.py's MOTORVAL), xyz perturbation
+    cases["D01_const_motorval"] = run_dynamics(
+        Dynamics, vp, 100, airborne(), f32r([12.5, -7.25, 3.0, 0, 0, 0]),
+        f32r(1.625e-2) * ones)
+    # D02 near hover for 1000 calls (netz = catastrophic cancellation case)
+    cases["D02_near_hover"] = run_dynamics(
+        Dynamics, vp, 100, airborne(), f32r([-3.5, 21.0, -29.75, 0, 0, 0]),
+        f32r(hov) * ones)
+    # D03 slightly asymmetric motors: roll/pitch/yaw torques all non-zero
+    m = f32r(hov * np.array([1.0, 1.002, 0.999, 1.001]))
+    cases["D03_asymmetric"] = run_dynamics(
+        Dynamics, vp, 100, airborne(50.0), f32r([5, 5, 5, 0, 0, 0]), m * ones)
+    # D04 random motor sequence around hover with non-zero initial rates
+    mseq = f32r(hov * (1.0 + 0.02 * rng.standard_normal((T, 4))))
+    cases["D04_random_motors"] = run_dynamics(
+        Dynamics, vp, 100,
+        airborne(200.0, i1=0.5, i3=-0.25, i6=0.05, i7=0.01, i8=-0.03, i9=0.02, i10=0.3, i11=-0.1),
+        f32r([29.5, -29.5, 10.0, 0, 0, 0]), mseq)
+    # D05 take-off from LANDED (z = 0): motors ramp from 0 to above hover
+    ramp = f32r(np.linspace(0.0, 1.5 * hov, 300))[:, None] * np.ones((300, 4))
+    cases["D05_takeoff"] = run_dynamics(Dynamics, vp, 100, np.zeros(12), None, ramp)
+    # D06 ground contact -> CRASHED (free fall from 3 m, motors off)
+    cases["D06_crash"] = run_dynamics(
+        Dynamics, vp, 100, airborne(3.0), None, np.zeros((200, 4)))
+    # D07 ground contact -> LEVELING -> LANDED (0.05 m, slightly below hover)
+    cases["D07_soft_landing"] = run_dynamics(
+        Dynamics, vp, 100, airborne(0.05, i6=0.01), None, f32r(1.6e-2) * np.ones((300, 4)))
+    # D08 crash by lateral speed / by roll angle at contact
+    cases["D08_crash_lateral"] = run_dynamics(
+        Dynamics, vp, 100, airborne(0.05, i3=2.5), None, f32r(1.6e-2) * np.ones((200, 4)))
+    cases["D09_crash_roll"] = run_dynamics(
+        Dynamics, vp, 100, airborne(0.05, i6=0.9), None, f32r(1.6e-2) * np.ones((200, 4)))
+    # D10 fps = 1000 (oracle for the 10-substep configuration), 10 000 calls
+    cases["D10_fps1000"] = run_dynamics(
+        Dynamics, vp, 1000, airborne(), f32r([12.5, -7.25, 3.0, 0, 0, 0]),
+        f32r(hov * 0.999) * np.ones((10000, 4)))
+    # D11 large angles (wrap well past pi) -- exercises sin/cos range reduction
+    cases["D11_spin"] = run_dynamics(
+        Dynamics, vp, 100,
+        airborne(5000.0, i6=2.5, i8=-1.0, i10=40.0, i11=25.0),
+        None, f32r(hov) * ones)
+    # D12 full-range motors (0..1): huge thrust, values ~1e5
+    cases["D12_full_range"] = run_dynamics(
+        Dynamics, vp, 100, airborne(), f32r([1, 2, 3, 0, 0, 0]),
+        f32r(rng.uniform(0, 1, (200, 4))))
+    return cases
+
+
+# --------------------------------------------------------------------------
+# E-series: env-level traces
+# --------------------------------------------------------------------------
+def run_env(env, actions, seed, altitude=None, extra_after_done=25, action_dtype=np.float64):
+    """Drive env.reset() + env.step() with the recorded actions.
+
+    The drawn perturbation force is rounded to float32 and re-installed before
+    the first step so that an fp32 device path can be given identical inputs.
+    Stepping continues `extra_after_done` steps past the first done (the
+    reference allows that; it is what autoreset=DISABLED must reproduce)."""
+    if altitude is not None:
+        env.set_altitude(altitude)
+    np.random.seed(seed)
+    obs0, _ = env.reset()
+    d = env.dynamics
+    force = f32r(d._perturb * d.M)
+    d.perturb(force.copy())
+    rec = dict(obs=[], reward=[], done=[], status=[], steps=[], prev_shaping=[], x=[])
+    T = actions.shape[0]
+    first_done = -1
+    t = 0
+    while t < T:
+        a = actions[t].astype(action_dtype)
+        obs, reward, done, trunc, info = env.step(a)
+        assert trunc is False and info == {}
+        rec["obs"].append(obs)
+        rec["reward"].append(float(reward))
+        rec["done"].append(bool(done))
+        rec["status"].append(int(d.getStatus()))
+        rec["steps"].append(int(env.steps))
+        ps = getattr(env, "prev_shaping", None)
+        rec["prev_shaping"].append(np.nan if ps is None else float(ps))
+        rec["x"].append(d._x.copy())
+        if done and first_done < 0:
+            first_done = t
+        t += 1
+        if first_done >= 0 and t > first_done + extra_after_done:
+            break
+    n = len(rec["reward"])
+    return dict(
+        task=np.array("hover3d" if len(obs0) == 12 else "lander3d"),
+        seed=np.int64(seed), altitude=np.float64(env.initial_altitude),
+        force=force[:3], actions=actions[:n].astype(np.float64),
+        action_is_f32=np.bool_(action_dtype == np.float32),
+        obs0=np.asarray(obs0, dtype=np.float32), first_done=np.int64(first_done),
+        obs=np.asarray(rec["obs"], dtype=np.float32), reward=np.asarray(rec["reward"]),
+        done=np.asarray(rec["done"]), status=np.asarray(rec["status"], dtype=np.int8),
+        steps=np.asarray(rec["steps"], dtype=np.int64),
+        prev_shaping=np.asarray(rec["prev_shaping"]), x=np.asarray(rec["x"]))
+
+
+def e_series(_Task, Lander, vp):
+    rng = np.random.default_rng(777)
+    hov = hover_motor(vp)
+    MOTORVAL = 1.625e-2  # reference lander.py:21
+
+    class HoverRef(_Task):
+        # restates attic hover.py:18-21 and hover3d.py:32-37 on the live _Task
+        def __init__(self):
+            _Task.__init__(self, 12, 4)
+
+        def reset(self, seed=None, options=None):
+            return _Task._reset(self, seed, options)
+
+        def _get_reward(self, status, state, d, x, y):
+            return 1
+
+        def _get_state(self, state):
+            return [state[k] for k in ('x', 'dx', 'y', 'dy', 'z', 'dz',
+                                       'phi', 'dphi', 'theta', 'dtheta', 'psi', 'dpsi')]
+
+        def _get_motors(self, motors):
+            return motors
+
+    T = 1100
+    ones = np.ones((T, 4))
+    cases = {}
+    # E01 BASELINE config 1: lander.py constant thrust, exact float64 MOTORVAL
+    cases["E01_lander_const_f64"] = run_env(Lander(), MOTORVAL * ones, seed=0)
+    # E02 same with float32-representable MOTORVAL (device-comparable)
+    cases["E02_lander_const"] = run_env(Lander(), f32r(MOTORVAL) * ones, seed=0)
+    # E03 lander.py --random:  MOTORVAL * randn(4)  (negatives clip to 0)
+    cases["E03_lander_randn"] = run_env(Lander(), f32r(MOTORVAL * rng.standard_normal((T, 4))), seed=1)
+    # E04 uniform [-1,1)^4 actions: tilt limit within a few steps
+    for k in range(4):
+        cases["E04_lander_uniform_%d" % k] = run_env(
+            Lander(), f32r(rng.uniform(-1, 1, (T, 4))), seed=10 + k)
+    # E05 roll torque: tilt limit in 3 steps
+    cases["E05_lander_roll"] = run_env(Lander(), np.array([0., 1., 1., 0.]) * ones, seed=2)
+    # E06 hover thrust with small noise for > 1000 steps: step limit fires
+    cases["E06_lander_hover_limit"] = run_env(Lander(), f32r(hov) * ones, seed=3)
+    # E07 soft landing from 5 cm: LEVELING -> LANDED -> done + bonus
+    cases["E07_lander_soft_landing"] = run_env(Lander(), f32r(1.6e-2) * ones, seed=4, altitude=0.05)
+    # E08 out of bounds: sustained lateral tilt then hover
+    a = f32r(hov * np.array([0.99, 1.01, 1.01, 0.99])) * ones
+    a[40:] = f32r(hov)
+    cases["E08_lander_oob"] = run_env(Lander(), a, seed=5)
+    # E09 near-hover noisy actions (low-churn benchmark law)
+    cases["E09_lander_noisy_hover"] = run_env(
+        Lander(), f32r(hov * (1 + 0.01 * rng.standard_normal((T, 4)))), seed=6)
+    # E10 float32 action arrays: under NumPy >= 2 promotion the reference then
+    #     evaluates the motor model in float32 (documented quirk)
+    cases["E10_lander_f32_actions"] = run_env(
+        Lander(), f32r(hov * (1 + 0.01 * rng.standard_normal((T, 4)))), seed=7,
+        action_dtype=np.float32)
+    # Hover3D
+    cases["E20_hover_const"] = run_env(HoverRef(), f32r(hov) * ones, seed=8)
+    cases["E21_hover_uniform"] = run_env(HoverRef(), f32r(rng.uniform(-1, 1, (T, 4))), seed=9)
+    cases["E22_hover_soft_landing"] = run_env(HoverRef(), f32r(1.6e-2) * ones, seed=11, altitude=0.05)
+    cases["E23_hover_noisy"] = run_env(
+        HoverRef(), f32r(hov * (1 + 0.01 * rng.standard_normal((T, 4)))), seed=12)
+    return cases
+
+
+def save(name, cases):
+    flat = {}
+    for cname, c in cases.items():
+        for k, v in c.items():
+            flat["%s/%s" % (cname, k)] = v
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **flat)
+    print("wrote %s  (%d cases, %.1f kB)" % (path, len(cases), os.path.getsize(path) / 1e3))
+
+
+def main():
+    Dynamics, vp, _Task, Lander = load_reference()
+    print("numpy", np.__version__, "reference", REF)
+    save("dynamics_traces.npz", d_series(Dynamics, vp))
+    save("env_traces.npz", e_series(_Task, Lander, vp))
+    # known-answer constants observed from the reference (used as spot checks)
+    meta = dict(numpy_version=np.array(np.__version__), hover_motor=np.float64(hover_motor(vp)))
+    np.savez(os.path.join(OUT, "meta.npz"), **meta)
+
+
+if __name__ == "__main__":
+    main()

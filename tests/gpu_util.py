@@ -1,0 +1,88 @@
+"""Helpers shared by the -m gpu parity tests: build a device env and the CPU checker
+(oracle.refvec.VecOracle) with the same configuration, and compare them."""
+import numpy as np
+
+from oracle import refvec
+from oracle.refcpu import TaskParams
+from oracle.refvec import VecOracle
+
+AUTORESET = {"disabled": refvec.AUTORESET_DISABLED, "next_step": refvec.AUTORESET_NEXT_STEP,
+             "same_step": refvec.AUTORESET_SAME_STEP}
+
+# per-component scale of the parity metric |got - ref| <= tol * max(|ref|, scale):
+# 1 m, 1 m/s, 1 rad, 1 rad/s (a pure relative test is ill-posed at zero crossings)
+SCALE = 1.0
+
+
+def have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def make_pair(task="lander3d", n=1, mode="float32", autoreset="disabled", substeps=1, seed=0,
+              env_id_base=0, time_limit_truncates=False, episode_stats=False, **task_kwargs):
+    import gym_copter_amd
+    env = gym_copter_amd.CopterVecEnv(task=task, num_envs=n, state_dtype=mode,
+                                      autoreset_mode=autoreset, substeps=substeps, seed=seed,
+                                      env_id_base=env_id_base,
+                                      time_limit_truncates=time_limit_truncates,
+                                      episode_stats=episode_stats, **task_kwargs)
+    tp = TaskParams(**task_kwargs)
+    orc = VecOracle(task, n, tp, substeps=substeps, store_mode=mode, autoreset=AUTORESET[autoreset],
+                    seed=seed, env_id_base=env_id_base, time_limit_truncates=time_limit_truncates)
+    return env, orc
+
+
+def scaled_err(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        e = np.abs(got - ref) / np.maximum(np.abs(ref), SCALE)
+    both_nan = np.isnan(got) & np.isnan(ref)
+    same_inf = np.isinf(got) & np.isinf(ref) & (np.sign(got) == np.sign(ref))
+    e = np.where(both_nan | same_inf, 0.0, e)
+    return float(np.nanmax(e)) if e.size else 0.0
+
+
+def to_np(t):
+    return t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+
+
+def step_both(env, orc, actions):
+    """actions: numpy float32 [n,4].  Returns ((obs,r,term,trunc) device-as-numpy, oracle tuple)."""
+    import torch
+    a = torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)).to(env.device)
+    obs, r, term, trunc, infos = env.step(a)
+    got = tuple(to_np(v).copy() for v in (obs, r, term, trunc))
+    want = orc.step(actions.astype(np.float64))
+    return got, want, infos
+
+
+def assert_step_close(got, want, x_tol, r_abs=5e-5, r_rel=1e-5, ctx=""):
+    obs, r, term, trunc = got
+    wobs, wr, wterm, wtrunc = want
+    assert np.array_equal(term.astype(bool), wterm), "terminated mismatch %s" % ctx
+    assert np.array_equal(trunc.astype(bool), wtrunc), "truncated mismatch %s" % ctx
+    e = scaled_err(obs, wobs)
+    assert e <= x_tol, "obs err %.3e > %.1e %s" % (e, x_tol, ctx)
+    dr = np.abs(r.astype(np.float64) - wr)
+    lim = r_abs + r_rel * np.abs(wr)
+    assert np.all(dr <= lim), "reward err %.3e %s" % (float(dr.max()), ctx)
+
+
+def assert_state_close(env, orc, x_tol, ctx=""):
+    s = env.get_state()
+    assert np.array_equal(s["status"], orc.status), "status mismatch %s" % ctx
+    assert np.array_equal(s["steps"], orc.steps), "steps mismatch %s" % ctx
+    assert np.array_equal((s["flags"] & 1).astype(bool), orc.pending), "pending flag %s" % ctx
+    e = scaled_err(s["x"], orc.x)
+    assert e <= x_tol, "state err %.3e > %.1e %s" % (e, x_tol, ctx)
+    return e
+
+
+# tolerance of "device vs the oracle run in the SAME storage mode" (only float64 rounding
+# differences: fma contraction, reciprocal-multiply, sin/cos ulps) per mode
+MODE_TOL = {"float64": 1e-11, "float32": 2e-8, "float32_rn": 2e-6, "float32_sr": 2e-6}

@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: libcopterstep.so loads without a GPU, exports
+every symbol include/copterstep.h declares, the ctypes mirror of cs_config matches the
+header's defaults, and the product path fails loudly (no CPU fallback) without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gym_copter_amd
+from gym_copter_amd import _lib
+from gym_copter_amd.spaces import Box
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "copterstep.h")).read()
+
+
+def _declared_functions():
+    body = HEADER.split("int cs_version(void);")[0]
+    rest = "int cs_version(void);" + HEADER.split("int cs_version(void);")[1]
+    return sorted(set(re.findall(r"\b(cs_[a-z_]+)\s*\(", rest)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 17
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SYMBOLS) == declared            # the binding covers the whole header
+    assert lib.cs_version() == _lib.ABI_VERSION == int(re.search(r"#define CS_ABI_VERSION (\d+)", HEADER).group(1))
+
+
+def test_config_defaults_are_the_reference_constants():
+    lib = _lib.load()
+    cfg = _lib.Config()
+    assert lib.cs_config_init(C.byref(cfg), _lib.TASK_LANDER3D) == 0
+    assert cfg.struct_size == C.sizeof(_lib.Config)      # ctypes mirror == C layout
+    ref = dict(B=5e-3, D=2e-6, M=1.380, L=0.350, Ix=2, Iy=2, Iz=3, Jr=38e-4, maxrpm=15000,   # dji_phantom.py
+               G=9.80665, landing_vel_x=2.0, landing_vel_y=1.0, landing_angle=np.pi / 4,   # dynamics :71-76
+               initial_random_force=30, out_of_bounds_penalty=100, max_angle_deg=45, bounds=10,
+               initial_altitude=10, max_steps=1000, frames_per_second=100,                    # task.py
+               target_radius=2, yaw_penalty_factor=50, xyz_penalty_factor=25, dz_max=10,
+               dz_penalty=100, inside_radius_bonus=100)                                       # lander.py
+    for k, v in ref.items():
+        assert getattr(cfg, k) == v, k
+    assert cfg.substeps == 1 and cfg.autoreset == _lib.AUTORESET_DISABLED and cfg.state_mode == _lib.STATE_F32G
+    assert lib.cs_config_init(C.byref(cfg), 7) == -1 and b"unknown task" in lib.cs_last_error()
+    assert lib.cs_config_init(None, 0) == -1
+
+
+def test_argument_errors_without_touching_a_device():
+    lib = _lib.load()
+    cfg = _lib.Config()
+    lib.cs_config_init(C.byref(cfg), _lib.TASK_HOVER3D)
+    ctx = C.c_void_p()
+    cfg.struct_size += 8
+    assert lib.cs_create(C.byref(cfg), C.byref(ctx)) == -5          # CS_ERR_ABI
+    cfg.struct_size -= 8
+    cfg.num_envs = 0
+    assert lib.cs_create(C.byref(cfg), C.byref(ctx)) == -1 and not ctx.value
+    cfg.num_envs = 4
+    cfg.substeps = 0
+    assert lib.cs_create(C.byref(cfg), C.byref(ctx)) == -1
+    assert lib.cs_step(None, None, None, None, None, None, None) == -1
+    assert lib.cs_destroy(None) == 0
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product refuses to run instead of computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    with pytest.raises(gym_copter_amd.CopterStepError) as e:
+        gym_copter_amd.make("Lander-v0", num_envs=4)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gym_copter_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "refcpu" not in src and "refvec" not in src, f
+
+
+def test_spaces_and_registry():
+    b = Box(-1, 1, (4,), np.float32)
+    assert b.shape == (4,) and b.dtype == np.float32 and b.contains(b.sample())
+    assert b.high[0] == 1 and not b.contains(np.full(4, 2, np.float32))
+    assert set(gym_copter_amd._REGISTRY) == {"Lander-v0", "Lander3D-v0", "Hover3D-v0"}

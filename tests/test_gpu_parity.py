@@ -1,0 +1,407 @@
+"""-m gpu parity tests: the HIP kernels (through the C ABI) against the CPU oracle and the
+committed golden traces of the real reference.  Tolerances are written where used:
+
+  * device vs golden float64 reference traces ........ 1e-5 * max(|ref|, 1)   (the north-star bar)
+  * device vs the oracle run in the same storage mode . gpu_util.MODE_TOL      (float64 rounding only)
+"""
+import numpy as np
+import pytest
+
+from conftest import load_cases
+from gpu_util import (MODE_TOL, assert_state_close, assert_step_close, have_gpu, make_pair,
+                      scaled_err, step_both, to_np)
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
+
+ENV = load_cases("env_traces.npz")
+DYN = load_cases("dynamics_traces.npz")
+import os
+HOVER = float(np.load(os.path.join(os.path.dirname(__file__), "golden", "meta.npz"))["hover_motor"])
+BAR = 1e-5   # BASELINE.json: <= 1e-5 relative fp32 per state component over 1000 steps
+MODES = ["float32", "float32_rn", "float32_sr", "float64"]
+
+
+def _env_groups():
+    groups = {}
+    for c in ENV.names():
+        g = ENV[c]
+        if bool(g["action_is_f32"]) or c == "E01_lander_const_f64":
+            continue   # inputs not float32-representable -> oracle-only cases
+        groups.setdefault((str(g["task"]), float(g["altitude"])), []).append(c)
+    return groups
+
+
+# ---------------------------------------------------------------------------------------
+# golden env traces of the real reference, all episodes of a task as one batch
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["float32", "float64"])
+@pytest.mark.parametrize("key", sorted(_env_groups()))
+def test_golden_env_traces(key, mode):
+    task, alt = key
+    cs = _env_groups()[key]
+    n = len(cs)
+    T = max(len(ENV[c]["reward"]) for c in cs)
+    acts = np.zeros((T, n, 4), dtype=np.float32)
+    forces = np.zeros((3, n), dtype=np.float32)
+    for i, c in enumerate(cs):
+        a = ENV[c]["actions"]
+        acts[:len(a), i] = a
+        forces[:, i] = ENV[c]["force"]
+    env, _ = make_pair(task, n, mode, initial_altitude=alt)
+    obs0, _ = env.reset(options={"forces": forces})
+    obs0 = to_np(obs0)
+    for i, c in enumerate(cs):
+        assert np.array_equal(obs0[i], ENV[c]["obs0"])
+    tol = 1e-9 if mode == "float64" else BAR
+    worst = 0.0
+    import torch
+    for t in range(T):
+        obs, r, term, trunc, _ = env.step(torch.from_numpy(acts[t]).to(env.device))
+        obs, r, term = to_np(obs), to_np(r), to_np(term)
+        assert not to_np(trunc).any()
+        if t % 50 == 0 or t == T - 1:
+            st = env.get_state()
+        for i, c in enumerate(cs):
+            g = ENV[c]
+            if t >= len(g["reward"]):
+                continue
+            # beyond the end of an episode the free-running state of a crashed /
+            # diverged copter is not a parity target; compare through first_done + 5
+            if t > int(g["first_done"]) + 5 >= 5:
+                continue
+            e = scaled_err(obs[i], g["obs"][t])
+            worst = max(worst, e)
+            assert e <= tol, (c, t, e)
+            assert bool(term[i]) == bool(g["done"][t]), (c, t)
+            assert abs(float(r[i]) - g["reward"][t]) <= 5e-5 + 1e-5 * abs(g["reward"][t]), (c, t)
+            if t % 50 == 0 or t == T - 1:
+                assert st["status"][i] == g["status"][t] and st["steps"][i] == g["steps"][t], (c, t)
+    print("worst scaled error vs float64 reference [%s %s]: %.3e" % (task, mode, worst))
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# golden Dynamics.setMotors traces through cs_set_motors
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["float32", "float64"])
+@pytest.mark.parametrize("fps", [100, 1000])
+def test_golden_dynamics_traces(fps, mode):
+    cs = [c for c in DYN.names() if int(DYN[c]["fps"]) == fps]
+    if mode != "float64":
+        # D12 (full-range random motors, angles of hundreds of radians and 1e5 m/s^2
+        # accelerations) is chaotic at float32 word precision: float64 mode only
+        cs = [c for c in cs if c != "D12_full_range"]
+    n = len(cs)
+    T = max(len(DYN[c]["status"]) for c in cs)
+    import torch
+    env, _ = make_pair("lander3d", n, mode, frames_per_second=fps)
+    x0 = np.zeros((12, n))
+    status0 = np.zeros(n, np.uint8)
+    force = np.zeros((3, n))
+    flags = np.zeros(n, np.uint8)
+    motors = np.zeros((T, n, 4), dtype=np.float32)
+    for i, c in enumerate(cs):
+        g = DYN[c]
+        x0[:, i] = g["x0"]
+        status0[i] = g["status0"]
+        force[:, i] = g["force"][:3]
+        flags[i] = 1 if np.any(g["force"]) else 0
+        motors[:len(g["motors"]), i] = g["motors"]
+    env.set_state(x=x0, status=status0, force=force, flags=flags, steps=np.ones(n, np.int32))
+    tol = 1e-9 if mode == "float64" else BAR
+    check_every = 1 if T <= 1000 else 10
+    for t in range(T):
+        env.set_motors(torch.from_numpy(motors[t]).to(env.device))
+        if t % check_every and t != T - 1:
+            continue
+        st = env.get_state()
+        for i, c in enumerate(cs):
+            g = DYN[c]
+            if t < len(g["status"]):
+                e = scaled_err(st["x"][:, i], g["x"][t])
+                assert e <= tol, (c, t, e)
+                assert st["status"][i] == g["status"][t], (c, t)
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# one step from random states: every output against the oracle in the same storage mode
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task", ["lander3d", "hover3d"])
+@pytest.mark.parametrize("mode", MODES)
+def test_single_step_random_states(task, mode):
+    rng = np.random.default_rng(11)
+    n = 4096 + 37   # ragged last wavefront
+    env, orc = make_pair(task, n, mode, seed=5)
+    env.reset(options={"forces": np.zeros((3, n), np.float32)})
+    orc.reset(forces=np.zeros((3, n)))
+    x = rng.standard_normal((12, n)) * np.array([4, 2, 4, 2, 6, 2, .4, .5, .4, .5, 2, 1])[:, None]
+    x[4] -= 6
+    x[0, :64] = 9.99 + 0.02 * rng.random(64)          # bounds edge
+    x[6, 64:128] = np.pi / 4 - 1e-3 + 2e-3 * rng.random(64)   # tilt edge
+    x[4, 128:512] = np.abs(x[4, 128:512]) * 0.01       # below ground, some descending
+    status = rng.integers(0, 4, n).astype(np.uint8)
+    steps = rng.integers(1, 1002, n).astype(np.int32)
+    steps[:16] = 1000
+    prev = -rng.random(n) * 300
+    prev[::97] = np.nan
+    force = rng.uniform(-30, 30, (3, n))
+    flags = (rng.random(n) < 0.3).astype(np.uint8)
+    # make every input exactly representable in the storage mode under test
+    orc.x[:] = orc._round(x)
+    orc.status[:] = status
+    orc.steps[:] = steps
+    orc.prev_shaping[:] = prev.astype(orc.T)
+    orc.force[:] = force.astype(orc.T)
+    orc.pending[:] = flags.astype(bool)
+    env.set_state(x=orc.x.astype(np.float64), status=status, steps=steps,
+                  prev_shaping=orc.prev_shaping.astype(np.float64),
+                  force=orc.force.astype(np.float64), flags=flags)
+    st = env.get_state()
+    assert np.array_equal(st["x"], orc.x.astype(np.float64))      # set/get round trip is exact
+    assert np.array_equal(np.isnan(st["prev_shaping"]), np.isnan(prev))
+    env.epoch = orc.epoch                                         # same rounding stream
+    actions = rng.uniform(-0.5, 1.5, (n, 4)).astype(np.float32)
+    actions[::5] = (HOVER * (1 + 0.01 * rng.standard_normal((len(actions[::5]), 4)))).astype(np.float32)
+    got, want, _ = step_both(env, orc, actions)
+    # single step: states agree to float64 rounding (a handful of ulps of the stored word)
+    tol = {"float64": 1e-13, "float32": 1e-9, "float32_rn": 2.5e-7, "float32_sr": 2.5e-7}[mode]
+    assert_step_close(got, want, max(tol, 1.3e-7), ctx="%s %s" % (task, mode))
+    assert_state_close(env, orc, tol, ctx="%s %s" % (task, mode))
+    st = env.get_state()
+    if task == "lander3d":
+        ps, wps = st["prev_shaping"], orc.prev_shaping.astype(np.float64)
+        assert np.all(np.abs(ps - wps) <= 3.1e-5 + 1e-12 * np.abs(wps))
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# 1000 steps on identical motor inputs (the north-star parity statement)
+# ---------------------------------------------------------------------------------------
+def _rollout_vs_oracle(task, n, mode, T, law, substeps=1, check_every=100):
+    rng = np.random.default_rng(2024)
+    env, orc = make_pair(task, n, mode, substeps=substeps, seed=9)
+    env.reset(seed=9)
+    orc.reset(seed=9)
+    assert_state_close(env, orc, 0.0, ctx="after reset")    # Philox forces identical
+    st = env.get_state()
+    assert np.array_equal(st["force"], orc.force.astype(np.float64))
+    worst = 0.0
+    for t in range(T):
+        if law == "near_hover":
+            a = (HOVER * (1 + 0.01 * rng.standard_normal((n, 4)))).astype(np.float32)
+        elif law == "const":
+            a = np.full((n, 4), 1.625e-2, dtype=np.float32)
+        else:
+            a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        got, want, _ = step_both(env, orc, a)
+        if t % check_every == 0 or t == T - 1:
+            assert_step_close(got, want, MODE_TOL[mode], ctx="t=%d" % t)
+            worst = max(worst, assert_state_close(env, orc, MODE_TOL[mode], ctx="t=%d" % t))
+    env.close()
+    return worst
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_1000_steps_near_hover_vs_oracle(mode):
+    worst = _rollout_vs_oracle("lander3d", 2048, mode, 1000, "near_hover")
+    print("1000-step near-hover, %s: worst scaled state error vs same-mode oracle %.3e" % (mode, worst))
+
+
+def test_1000_steps_vs_float64_reference_semantics():
+    """Default device format (float32 words + guard bits) against the oracle run in pure
+    float64 (= the reference's arithmetic, pinned to its golden traces): <= 1e-5 * max(|ref|,1)
+    on every state component at every 50th step of 1000, constant and near-hover thrust."""
+    rng = np.random.default_rng(7)
+    n = 1024
+    for law in ("const", "near_hover"):
+        env, _ = make_pair("lander3d", n, "float32", seed=3)
+        _, ref = make_pair("lander3d", n, "float64", seed=3)
+        _.close()
+        env.reset(seed=3)
+        ref.reset(seed=3)
+        # the float64 oracle must start from the float32-rounded forces the device holds
+        ref.force[:] = ref.force.astype(np.float32).astype(np.float64)
+        worst = 0.0
+        for t in range(1000):
+            a = (np.full((n, 4), 1.625e-2) if law == "const"
+                 else HOVER * (1 + 0.01 * rng.standard_normal((n, 4)))).astype(np.float32)
+            got, want, _i = step_both(env, ref, a)
+            if t % 50 == 0 or t == 999:
+                st = env.get_state()
+                airborne = ref.status == 3    # grounded copters are frozen; compare the flying ones
+                e = scaled_err(st["x"][:, airborne], ref.x[:, airborne])
+                worst = max(worst, e)
+                assert e <= BAR, (law, t, e)
+        print("1000 steps vs float64 semantics [%s]: worst %.3e (bar %.0e)" % (law, worst, BAR))
+        env.close()
+
+
+@pytest.mark.parametrize("task,n", [("lander3d", 65536), ("hover3d", 262144)])
+def test_full_size_short_rollout_vs_oracle(task, n):
+    """BASELINE configs 2 and 3 at full batch size, random U[-1,1) actions with NEXT_STEP
+    auto-reset (reset churn ~15 % of lanes per step): 40 steps against the oracle, every
+    output of every step."""
+    rng = np.random.default_rng(99)
+    env, orc = make_pair(task, n, "float32", autoreset="next_step", seed=1234)
+    env.reset()
+    orc.reset()
+    resets = 0
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        got, want, _ = step_both(env, orc, a)
+        # diverging (full-throttle) trajectories: compare at the float32-observation level
+        assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6, ctx="%s t=%d" % (task, t))
+        resets += int(want[2].sum())
+    assert_state_close(env, orc, 2e-6, ctx=task)
+    assert resets > n        # every env finished more than once on average
+    env.close()
+
+
+def test_substeps_config5():
+    """BASELINE config 5: dt = 1e-3 with 10 inner substeps per step()."""
+    g = DYN["D10_fps1000"]
+    env, orc = make_pair("lander3d", 256, "float64", substeps=10)
+    f = np.tile(g["force"][:3, None], (1, 256)).astype(np.float32)
+    env.reset(options={"forces": f})
+    orc.reset(forces=f.astype(np.float64))
+    import torch
+    a = torch.from_numpy(np.tile(g["motors"][0].astype(np.float32), (256, 1))).to(env.device)
+    for s in range(1000):
+        env.step(a)
+        if s % 100 == 99:
+            st = env.get_state()
+            assert scaled_err(st["x"][:, 7], g["x"][10 * s + 9]) <= 1e-10, s
+    env.close()
+    worst = _rollout_vs_oracle("lander3d", 1024, "float32", 300, "near_hover", substeps=10)
+    assert worst <= MODE_TOL["float32"]
+
+
+# ---------------------------------------------------------------------------------------
+# auto-reset, done-list compaction, episode statistics
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task", ["lander3d", "hover3d"])
+@pytest.mark.parametrize("autoreset", ["next_step", "same_step"])
+def test_autoreset_and_done_list(task, autoreset):
+    rng = np.random.default_rng(4)
+    n = 3000
+    env, orc = make_pair(task, n, "float32", autoreset=autoreset, seed=77, env_id_base=10 ** 6,
+                         episode_stats=True)
+    env.enable_done_list()
+    if autoreset == "same_step":
+        env.enable_final_obs()
+    env.reset()
+    orc.reset()
+    total = 0
+    for t in range(60):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        got, want, infos = step_both(env, orc, a)
+        assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6, ctx="t=%d" % t)
+        ep = infos["episode"]
+        cnt = int(to_np(ep["count"])[0])
+        ids = to_np(ep["ids"])[:cnt]
+        order = np.argsort(ids)
+        assert np.array_equal(ids[order], orc.last_done), t
+        assert np.array_equal(to_np(ep["length"])[:cnt][order], orc.last_length), t
+        assert np.allclose(to_np(ep["return"])[:cnt][order], orc.last_return, rtol=1e-5, atol=1e-2), t
+        if autoreset == "same_step" and cnt:
+            fo = to_np(infos["final_obs"])[orc.last_done]
+            assert scaled_err(fo, orc.final_obs[orc.last_done]) <= 2e-6
+        total += cnt
+    assert total > n
+    assert_state_close(env, orc, 2e-6)
+    st = env.get_state()
+    assert np.array_equal(st["force"], orc.force.astype(np.float64))   # Philox draws identical
+    env.close()
+
+
+def test_time_limit_as_truncation():
+    env, orc = make_pair("hover3d", 130, "float32", time_limit_truncates=True, max_steps=25)
+    z = np.zeros((3, 130), np.float32)
+    env.reset(options={"forces": z})
+    orc.reset(forces=z)
+    a = np.full((130, 4), HOVER, dtype=np.float32)
+    for t in range(25):
+        got, want, _ = step_both(env, orc, a)
+        assert_step_close(got, want, 1e-7)
+        assert got[3].all() == (t == 24) and not got[2].any()
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# size-independent properties at full size; edge cases
+# ---------------------------------------------------------------------------------------
+def test_batch_position_invariance_full_size():
+    """Env i's trajectory does not depend on batch size, position in the batch or shard:
+    the same global env ids stepped inside a 65 536 batch and as a 1000-env shard."""
+    import gym_copter_amd
+    import torch
+    rng = np.random.default_rng(1)
+    N, lo, m = 65536, 31337, 1000
+    big = gym_copter_amd.CopterVecEnv("lander3d", N, seed=42, autoreset_mode="next_step")
+    small = gym_copter_amd.CopterVecEnv("lander3d", m, seed=42, autoreset_mode="next_step",
+                                        env_id_base=lo)
+    big.reset()
+    small.reset()
+    for t in range(100):
+        a = (HOVER * (1 + 0.3 * rng.standard_normal((N, 4)))).astype(np.float32)
+        ob, rb, tb, _, _ = big.step(torch.from_numpy(a).to(big.device))
+        os_, rs, ts, _, _ = small.step(torch.from_numpy(a[lo:lo + m]).to(small.device))
+        assert torch.equal(ob[lo:lo + m], os_) and torch.equal(rb[lo:lo + m], rs)
+        assert torch.equal(tb[lo:lo + m], ts)
+    sb, ss = big.get_state(), small.get_state()
+    assert np.array_equal(sb["x"][:, lo:lo + m], ss["x"]) and np.array_equal(sb["steps"][lo:lo + m], ss["steps"])
+    big.close()
+    small.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 257])
+def test_ragged_batch_sizes(n):
+    rng = np.random.default_rng(n)
+    for task in ("lander3d", "hover3d"):
+        env, orc = make_pair(task, n, "float32", autoreset="next_step", seed=n)
+        env.reset()
+        orc.reset()
+        for t in range(30):
+            got, want, _ = step_both(env, orc, rng.uniform(-1, 1, (n, 4)).astype(np.float32))
+            assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6)
+        env.close()
+
+
+def test_numpy_actions_and_argument_errors():
+    import gym_copter_amd
+    env = gym_copter_amd.make("Lander-v0", num_envs=8, autoreset_mode="disabled")
+    obs, info = env.reset(seed=1)
+    assert tuple(obs.shape) == (8, 10) and info == {}
+    out = env.step(np.full((8, 4), HOVER, dtype=np.float64))     # NumPy in -> NumPy out
+    assert isinstance(out[0], np.ndarray) and out[0].dtype == np.float32 and out[0].shape == (8, 10)
+    assert out[1].dtype == np.float32 and out[2].dtype == bool and out[3].dtype == bool
+    with pytest.raises(ValueError):
+        env.step(np.zeros((7, 4), np.float32))
+    with pytest.raises(TypeError):
+        gym_copter_amd.make("Lander-v0", num_envs=2, not_a_kwarg=1)
+    with pytest.raises(KeyError):
+        gym_copter_amd.make("Nope-v0")
+    env.close()
+    with pytest.raises(RuntimeError):
+        env.step(np.zeros((8, 4), np.float32))
+
+
+def test_nonfinite_and_out_of_range_inputs_propagate_like_the_reference():
+    """The reference raises nothing on the path: NaN/inf propagate silently, actions are
+    clipped to [0,1] (task.py:91)."""
+    env, orc = make_pair("lander3d", 64, "float64")
+    z = np.zeros((3, 64), np.float32)
+    env.reset(options={"forces": z})
+    orc.reset(forces=z)
+    a = np.full((64, 4), HOVER, dtype=np.float32)
+    a[0] = [5.0, -3.0, 1e30, -1e30]
+    a[1, 2] = np.nan
+    a[2] = np.inf
+    for t in range(3):
+        got, want, _ = step_both(env, orc, a)
+    st = env.get_state()
+    assert scaled_err(st["x"][:, 0], orc.x[:, 0]) < 1e-12
+    assert np.isnan(st["x"][:, 1]).any() == np.isnan(orc.x[:, 1]).any()
+    assert scaled_err(st["x"][:, 3:], orc.x[:, 3:]) < 1e-12
+    env.close()

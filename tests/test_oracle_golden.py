@@ -1,0 +1,72 @@
+"""Pins oracle/refcpu.py (scalar float64 restatement) bit-for-bit against golden
+traces captured from the real reference by tests/golden/generate_golden.py."""
+import numpy as np
+import pytest
+
+from conftest import load_cases
+from oracle.refcpu import (AIRBORNE, CRASHED, DJI_PHANTOM, LANDED, RigidBody, TaskOracle,
+                           TaskParams)
+
+DYN = load_cases("dynamics_traces.npz")
+ENV = load_cases("env_traces.npz")
+
+
+@pytest.mark.parametrize("name", DYN.names())
+def test_dynamics_trace_bit_exact(name):
+    g = DYN[name]
+    b = RigidBody(DJI_PHANTOM, int(g["fps"]))
+    b.set_state(g["x0"])
+    assert b.status == g["status0"]
+    if np.any(g["force"]):
+        b.perturb(g["force"])
+    for t, m in enumerate(g["motors"]):
+        b.set_motors(m)
+        assert np.array_equal(b.x, g["x"][t]), (name, t)
+        assert b.status == g["status"][t] and b.ticks == g["ticks"][t], (name, t)
+
+
+@pytest.mark.parametrize("name", ENV.names())
+def test_env_trace_bit_exact(name):
+    g = ENV[name]
+    f32_actions = bool(g["action_is_f32"])
+    o = TaskOracle(str(g["task"]), TaskParams(initial_altitude=float(g["altitude"])),
+                   action_dtype_passthrough=f32_actions)
+    obs0 = o.reset(force_xyz=g["force"])
+    assert obs0.dtype == np.float32 and np.array_equal(obs0, g["obs0"])
+    assert o.steps == 1
+    for t, a in enumerate(g["actions"]):
+        if f32_actions:
+            a = a.astype(np.float32)
+        obs, r, done, trunc, info = o.step(a)
+        assert trunc is False and info == {}
+        assert np.array_equal(obs, g["obs"][t]), (name, t)
+        assert r == g["reward"][t] and done == g["done"][t], (name, t)
+        assert o.body.status == g["status"][t] and o.steps == g["steps"][t], (name, t)
+        assert np.array_equal(o.body.x, g["x"][t]), (name, t)
+        ps = g["prev_shaping"][t]
+        assert (o.prev_shaping is None and np.isnan(ps)) or o.prev_shaping == ps
+
+
+def test_known_answers():
+    """Spot values observed on the real reference."""
+    o = TaskOracle("lander3d")
+    obs = o.reset(force_xyz=[0.0, 0.0, 0.0])
+    assert np.array_equal(obs, np.array([0, 0, 0, 0, -10, 0, 0, 0, 0, 0], dtype=np.float32))
+    assert o.prev_shaping == -250.0 and o.steps == 1 and o.body.status == AIRBORNE
+    # forward Euler: first step from rest changes dz but not z
+    o.step(1.625e-2 * np.ones(4))
+    assert o.body.x[4] == -10.0 and abs(o.body.x[5] - 0.363923869e-2) < 1e-9
+    # the reset perturbation is applied twice on the first integrated step
+    o = TaskOracle("lander3d")
+    o.reset(force_xyz=[2.0, 0.0, 0.0])
+    o.step(np.zeros(4))
+    assert o.body.x[1] == 2 * (2.0 / 1.380) * 0.01
+    # free fall onto the ground crashes; status lags one step in `done`
+    g = ENV["E02_lander_const"]
+    fd = int(g["first_done"])
+    assert g["status"][fd] == CRASHED and g["status"][fd - 1] == CRASHED and not g["done"][fd - 1]
+    # a landed lander stays LANDED and keeps reporting done
+    g = ENV["E07_lander_soft_landing"]
+    assert g["status"][-1] == LANDED and g["done"][-1]
+    # step limit fires on the 1000th user step
+    assert ENV["E06_lander_hover_limit"]["first_done"] == 999
