@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libcopterstep.so")
 
 ABI_VERSION = 1
 TASK_LANDER3D, TASK_HOVER3D = 0, 1
-STATE_F32G, STATE_F32_RN, STATE_F64, STATE_F32_SR = 0, 1, 2, 3
+STATE_F32G, STATE_F32_RN, STATE_F64 = 0, 1, 2
 AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
 STATUS_CRASHED, STATUS_LANDED, STATUS_LEVELING, STATUS_AIRBORNE = 0, 1, 2, 3
 
@@ -67,14 +67,12 @@ SYMBOLS = {
     "cs_obs_dim": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "cs_seed": (C.c_int, [_P, C.c_uint64]),
     "cs_set_altitude": (C.c_int, [_P, C.c_double]),
-    "cs_get_epoch": (C.c_int, [_P, C.POINTER(C.c_uint64), _P]),
-    "cs_set_epoch": (C.c_int, [_P, C.c_uint64, _P]),
     "cs_reset": (C.c_int, [_P, _P, _P, _P, _P]),
     "cs_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "cs_step_ex": (C.c_int, [_P, C.POINTER(StepIO), _P]),
     "cs_set_motors": (C.c_int, [_P, _P, _P]),
-    "cs_get_state": (C.c_int, [_P] + [_P] * 7 + [_P]),
-    "cs_set_state": (C.c_int, [_P] + [_P] * 7 + [_P]),
+    "cs_get_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
+    "cs_set_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
 }
 
 _lib = None
@@ -89,6 +87,11 @@ def load():
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C gym_copter_amd/csrc` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+    # PyTorch (used for device memory and streams) bundles its own libamdhip64.so.7.  Import
+    # it FIRST so that libcopterstep.so binds to that same, already-loaded HIP runtime by
+    # SONAME; loading ours first would put a second HIP/HSA runtime (/opt/rocm) in the
+    # process, and the two do not share devices, streams or allocations.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported

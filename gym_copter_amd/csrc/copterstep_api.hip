@@ -40,27 +40,25 @@ double stored_word(const cs_config& cfg, double v) {
   return cfg.state_mode == CS_STATE_F64 ? v : (double)(float)v;
 }
 
-// Per-launch constants.  Reciprocals are formed once here in float64; the kernels
-// multiply where upstream divides (<= 1 ulp(f64) apart).
+// Per-launch constants.  Uniform factors and reciprocals are folded once here in float64;
+// the kernels multiply where upstream divides (a few ulp(f64) apart).
 cs::DevConst make_const(const cs_ctx* ctx) {
   const cs_config& g = ctx->cfg;
   cs::DevConst c;
   std::memset(&c, 0, sizeof c);
   const double pi = 3.141592653589793238462643383279502884;
-  c.w_scale = g.maxrpm * pi / 30.0;
-  c.B = g.B;
-  c.LB = g.L * g.B;
-  c.D = g.D;
-  c.inv_M = 1.0 / g.M;
-  c.neg_inv_M = -1.0 / g.M;
+  const double ws = g.maxrpm * pi / 30.0;  // motor value -> rad/s
+  const double ws2 = ws * ws;
+  c.k_thrust = -(g.B * ws2) / g.M;
+  c.k_roll = (g.L * g.B * ws2) / g.Ix;
+  c.k_pitch = (g.L * g.B * ws2) / g.Iy;
+  c.k_yaw = (g.D * ws2) / g.Iz;
   c.G = g.G;
-  c.inv_Ix = 1.0 / g.Ix;
-  c.inv_Iy = 1.0 / g.Iy;
-  c.inv_Iz = 1.0 / g.Iz;
   c.c_dphi = (g.Iy - g.Iz) / g.Ix;
   c.c_dthe = (g.Iz - g.Ix) / g.Iy;
   c.c_dpsi = (g.Ix - g.Iy) / g.Iz;
   c.dt = 1.0 / (g.frames_per_second * (double)g.substeps);
+  c.kick = 2.0 * c.dt / g.M;
   c.land_vx = g.landing_vel_x;
   c.land_vy = g.landing_vel_y;
   c.land_ang = g.landing_angle;
@@ -109,7 +107,7 @@ void free_state(cs_ctx* ctx) {
   if (s.prev_shaping) (void)hipFree(s.prev_shaping);
   if (s.force) (void)hipFree(s.force);
   if (s.ep_return) (void)hipFree(s.ep_return);
-  if (s.epoch) (void)hipFree(s.epoch);
+  if (s.episode) (void)hipFree(s.episode);
   std::memset(&s, 0, sizeof s);
 }
 
@@ -178,12 +176,12 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
     return fail(CS_ERR_ABI, "cs_create: cs_config size/version mismatch (use cs_config_init)");
   if (cfg->task != CS_TASK_LANDER3D && cfg->task != CS_TASK_HOVER3D)
     return fail(CS_ERR_ARG, "cs_create: unknown task");
-  if (cfg->state_mode < CS_STATE_F32G || cfg->state_mode > CS_STATE_F32_SR)
+  if (cfg->state_mode < CS_STATE_F32G || cfg->state_mode > CS_STATE_F64)
     return fail(CS_ERR_ARG, "cs_create: unknown state_mode");
   if (cfg->autoreset < CS_AUTORESET_DISABLED || cfg->autoreset > CS_AUTORESET_SAME_STEP)
     return fail(CS_ERR_ARG, "cs_create: unknown autoreset mode");
-  if (cfg->num_envs < 1 || cfg->num_envs > (int64_t)1 << 31)
-    return fail(CS_ERR_ARG, "cs_create: num_envs must be in [1, 2^31]");
+  if (cfg->num_envs < 1 || cfg->num_envs > (int64_t)1 << 28)
+    return fail(CS_ERR_ARG, "cs_create: num_envs must be in [1, 2^28]");
   if (cfg->env_id_base < 0) return fail(CS_ERR_ARG, "cs_create: env_id_base must be >= 0");
   if (cfg->substeps < 1 || cfg->substeps > 1000)
     return fail(CS_ERR_ARG, "cs_create: substeps must be in [1, 1000]");
@@ -215,8 +213,8 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
             hipMalloc(&s.prev_shaping, n * ctx->word) == hipSuccess &&
             hipMalloc(&s.force, 3 * stride * ctx->word) == hipSuccess;
   if (ok)
-    ok = hipMalloc((void**)&s.epoch, 2 * sizeof(uint64_t)) == hipSuccess &&
-         hipMemset(s.epoch, 0, 2 * sizeof(uint64_t)) == hipSuccess;
+    ok = hipMalloc((void**)&s.episode, n * sizeof(uint32_t)) == hipSuccess &&
+         hipMemset(s.episode, 0, n * sizeof(uint32_t)) == hipSuccess;
   if (ok && cfg->episode_stats)
     ok = hipMalloc((void**)&s.ep_return, n * sizeof(float)) == hipSuccess;
   if (ok && cfg->state_mode == CS_STATE_F32G)
@@ -268,22 +266,6 @@ int cs_seed(cs_ctx* ctx, uint64_t seed) {
 int cs_set_altitude(cs_ctx* ctx, double altitude) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   ctx->cfg.initial_altitude = altitude;
-  return CS_OK;
-}
-
-int cs_get_epoch(cs_ctx* ctx, uint64_t* out, void* stream) {
-  if (check_ctx(ctx) || out == nullptr) return fail(CS_ERR_ARG, "cs_get_epoch: null argument");
-  CS_HIP(hipSetDevice(ctx->cfg.device));
-  CS_HIP(hipStreamSynchronize((hipStream_t)stream));
-  CS_HIP(hipMemcpy(out, ctx->st.epoch, sizeof(uint64_t), hipMemcpyDeviceToHost));
-  return CS_OK;
-}
-
-int cs_set_epoch(cs_ctx* ctx, uint64_t epoch, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
-  CS_HIP(hipSetDevice(ctx->cfg.device));
-  CS_HIP(hipStreamSynchronize((hipStream_t)stream));
-  CS_HIP(hipMemcpy(ctx->st.epoch, &epoch, sizeof(uint64_t), hipMemcpyHostToDevice));
   return CS_OK;
 }
 
@@ -433,7 +415,7 @@ static int words_to_dev(const cs_ctx* ctx, void* dev, size_t rows, size_t stride
 
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
-                 double* episode_return_host, void* stream) {
+                 double* episode_return_host, uint32_t* episode_host, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   CS_HIP(hipSetDevice(ctx->cfg.device));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -457,6 +439,8 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
   }
   if (steps_host)
     CS_HIP(hipMemcpy(steps_host, s.steps, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (episode_host)
+    CS_HIP(hipMemcpy(episode_host, s.episode, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   if (episode_return_host) {
     if (!s.ep_return) return fail(CS_ERR_ARG, "cs_get_state: episode_stats is disabled");
     std::vector<float> tmp(n);
@@ -469,7 +453,7 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
 int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
                  const int32_t* steps_host, const double* prev_shaping_host,
                  const double* force_xyz_host, const uint8_t* flags_host,
-                 const double* episode_return_host, void* stream) {
+                 const double* episode_return_host, const uint32_t* episode_host, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   CS_HIP(hipSetDevice(ctx->cfg.device));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -499,6 +483,8 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
   }
   if (steps_host)
     CS_HIP(hipMemcpy(s.steps, steps_host, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (episode_host)
+    CS_HIP(hipMemcpy(s.episode, episode_host, n * sizeof(uint32_t), hipMemcpyHostToDevice));
   if (episode_return_host) {
     if (!s.ep_return) return fail(CS_ERR_ARG, "cs_set_state: episode_stats is disabled");
     std::vector<float> tmp(n);

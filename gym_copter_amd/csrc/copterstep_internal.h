@@ -17,19 +17,22 @@ constexpr uint8_t kFlagResetPending = 0x80;    // NEXT_STEP: env finished, reset
 
 // Uniform (per-launch) constants, all float64, derived once on the host from cs_config.
 struct DevConst {
-  double w_scale;  // maxrpm * pi / 30                     dynamics/__init__.py:120
-  double B, LB, D; // thrust coeff, L*B, yaw-torque coeff  :127-132
-  double neg_inv_M, inv_M, G;
-  double inv_Ix, inv_Iy, inv_Iz;
+  // motor model with every uniform factor folded in (dynamics/__init__.py:120-132):
+  double k_thrust;  // -B * (maxrpm*pi/30)^2 / M      bz   = k_thrust * sum(m^2)
+  double k_roll;    //  L*B * (maxrpm*pi/30)^2 / Ix
+  double k_pitch;   //  L*B * (maxrpm*pi/30)^2 / Iy
+  double k_yaw;     //  D * (maxrpm*pi/30)^2 / Iz
+  double G;
   double c_dphi, c_dthe, c_dpsi;  // (Iy-Iz)/Ix, (Iz-Ix)/Iy, (Ix-Iy)/Iz   :275-289
   double dt;
+  double kick;      // 2 * dt / M: velocity kick per newton of reset perturbation
   double land_vx, land_vy, land_ang;  // :71-73
   double bounds, max_angle, oob_penalty, z0, force_mag;
   double xyz_pen, yaw_pen, dz_max, dz_pen, target_r2, bonus;
   double reset_shaping;  // shaping potential of the reset state (NaN for Hover3D)
   int32_t max_steps, nsub, autoreset, tl_trunc, stats, status0;
-  uint32_t seed_lo, seed_hi;                      // Philox key (the counter holds env id + epoch)
-  uint32_t id_lo, id_hi;                          // global id of local env 0
+  uint32_t seed_lo, seed_hi;  // Philox key (the counter holds env id + episode number)
+  uint32_t id_lo, id_hi;      // global id of local env 0
 };
 
 // Struct-of-arrays state of one context.  `stride` (elements) separates components.
@@ -41,7 +44,7 @@ struct DevState {
   void* prev_shaping;  // [N]  float or double (NaN = None)
   void* force;         // [3][stride] float or double, newtons
   float* ep_return;    // [N] or null
-  uint64_t* epoch;     // [2]: call counter (keys the random streams), workgroup ticket
+  uint32_t* episode;   // [N] episodes started so far (Philox counter word)
   int64_t stride;
   int64_t n;
 };

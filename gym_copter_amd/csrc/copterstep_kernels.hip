@@ -14,10 +14,10 @@
 //   :292-302 (_bodyZToInertial), envs/task.py:77-137 (step), :145-202 (reset),
 //   envs/lander.py:46-74 (reward), attic hover.py:18-21 / hover3d.py:32-37.
 //
-// Numerics: all arithmetic is float64 in registers (the path is HBM-bound, and the
-// thrust-minus-gravity term is a catastrophic cancellation in float32); only the
-// stored state words are float32 (CS_STATE_F32*) or float64 (CS_STATE_F64).  The
-// default CS_STATE_F32G keeps, next to each float32 word, 8 guard bits (the next 8
+// Numerics: all arithmetic is float64 in registers (the thrust-minus-gravity term and
+// the motor-difference torques are catastrophic cancellations in float32); only the
+// stored state words are float32 (CS_STATE_F32G / _F32_RN) or float64 (CS_STATE_F64).
+// The default CS_STATE_F32G keeps, next to each float32 word, 8 guard bits (the next 8
 // mantissa bits, four components packed per dword), so that 1000 forward-Euler
 // accumulations x += dt*dxdt do not stagnate when dt*dxdt << ulp(x).
 // This is an elementwise ODE: no MFMA.
@@ -39,51 +39,8 @@ struct WordOf<CS_STATE_F64> {
 };
 
 // ---------------------------------------------------------------------------------
-// integer hashing / counter-based RNG
+// counter-based RNG for the reset perturbation
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
-  x ^= x >> 16;
-  x *= 0x7feb352dU;
-  x ^= x >> 15;
-  x *= 0x846ca68bU;
-  x ^= x >> 16;
-  return x;
-}
-
-__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ULL;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
-}
-
-// The call counter ("epoch") that keys the Philox draw and the stochastic-rounding
-// stream lives in DEVICE memory so that a captured hipGraph replays with fresh keys:
-// every kernel reads it on entry, and the last workgroup to finish (ticket counter)
-// advances it for the next launch on the stream.
-__device__ __forceinline__ void epoch_tick(const DevState& s, uint64_t epoch) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int* ticket = reinterpret_cast<unsigned int*>(s.epoch + 1);
-    const unsigned int t = atomicAdd(ticket, 1u);
-    if (t == gridDim.x - 1) {
-      *ticket = 0u;
-      s.epoch[0] = epoch + 1;
-    }
-  }
-}
-
-// hashed bytes for CS_STATE_F32_SR, keyed by (seed, epoch, global env id)
-__device__ __forceinline__ void sr_hash(const DevConst& c, uint64_t epoch, uint32_t gid_lo,
-                                        uint32_t (&h)[3]) {
-  const uint64_t seed = ((uint64_t)c.seed_hi << 32) | c.seed_lo;
-  const uint64_t a = splitmix64(seed ^ (epoch * 0x9E3779B97F4A7C15ULL));
-  const uint64_t b = splitmix64(a);
-  h[0] = lowbias32(gid_lo ^ (uint32_t)a);
-  h[1] = lowbias32(h[0] ^ (uint32_t)(a >> 32));
-  h[2] = lowbias32(h[1] ^ (uint32_t)b);
-}
-
 // Philox4x32-10 (Salmon et al. 2011); returns words 0..2 of the output block.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[3]) {
@@ -104,12 +61,14 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // Reset perturbation force (task.py:177-188, :199-202): three U[-F, F) draws keyed by
-// (seed, global env id, epoch).  u*2F and the subtraction are kept un-fused so the
-// CPU oracle reproduces the value bit-for-bit.
-__device__ __forceinline__ void draw_force(const DevConst& c, uint64_t epoch, uint32_t id_lo,
-                                           uint32_t id_hi, double (&f)[3]) {
+// (seed, global env id, this env's episode number) -- a pure function of those three,
+// so it is invariant to batch size, sharding, launch history and hipGraph replay.
+// u*2F and the subtraction are kept un-fused so the CPU oracle reproduces the value
+// bit-for-bit.
+__device__ __forceinline__ void draw_force(const DevConst& c, uint32_t id_lo, uint32_t id_hi,
+                                           uint32_t episode, double (&f)[3]) {
   uint32_t r[3];
-  philox4x32_10(id_lo, id_hi, (uint32_t)epoch, (uint32_t)(epoch >> 32), c.seed_lo, c.seed_hi, r);
+  philox4x32_10(id_lo, id_hi, episode, 0u, c.seed_lo, c.seed_hi, r);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const double u = (double)(r[i] >> 8) * 0x1.0p-24;
@@ -147,7 +106,7 @@ __device__ __forceinline__ double decode_word(typename WordOf<MODE>::type w, uin
 }
 
 template <int MODE>
-__device__ __forceinline__ Stored<MODE> encode_word(double v, uint32_t rnd8) {
+__device__ __forceinline__ Stored<MODE> encode_word(double v) {
   Stored<MODE> o;
   o.guard = 0;
   if constexpr (MODE == CS_STATE_F64) {
@@ -156,22 +115,14 @@ __device__ __forceinline__ Stored<MODE> encode_word(double v, uint32_t rnd8) {
   } else if constexpr (MODE == CS_STATE_F32_RN) {
     o.word = (float)v;
     o.value = (double)o.word;
-  } else if constexpr (MODE == CS_STATE_F32G) {
-    // round to 32 significant bits (add half of bit 21, carry propagates through the
-    // exponent), then split: top 24 bits -> float32 word (exact conversion), next 8 ->
-    // guard byte.
+  } else {
+    // CS_STATE_F32G: round to 32 significant bits (add half of bit 21, the carry
+    // propagates through the exponent), then split: top 24 bits -> float32 word (exact
+    // conversion), next 8 -> guard byte.
     unsigned long long b = (unsigned long long)__double_as_longlong(v) + (1ULL << 20);
     o.guard = (uint32_t)(b >> 21) & 0xFFu;
     o.word = (float)__longlong_as_double((long long)(b & ~0x1FFFFFFFULL));
     o.value = __longlong_as_double((long long)(b & ~0x1FFFFFULL));
-  } else {
-    // CS_STATE_F32_SR: stochastic rounding to float32: add 8 hashed random bits just
-    // below the float32 ulp, truncate the 29 dropped bits, convert (exact).
-    unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    b += (unsigned long long)rnd8 << 21;
-    b &= ~0x1FFFFFFFULL;
-    o.word = (float)__longlong_as_double((long long)b);
-    o.value = (double)o.word;
   }
   return o;
 }
@@ -194,14 +145,19 @@ __device__ __forceinline__ uint32_t byte_of(const uint32_t (&w)[3], int k) {
 }
 
 // ---------------------------------------------------------------------------------
-// sin/cos in float64: Cody-Waite reduction by pi/2 in three 33-bit pieces + the
-// fdlibm minimax kernels (<= ~1 ulp for |x| < 2^19 * pi/2).  Anything larger (never
-// reached by a physical trajectory) takes the library slow path.
+// float64 sin/cos and sqrt, sized for this kernel (no library slow paths, no scratch)
 // ---------------------------------------------------------------------------------
+// Cody-Waite reduction by pi/2 in three pieces (33+33+53 bits) + the fdlibm minimax
+// kernels: <= ~1 ulp for |x| < 2^19*pi/2.  Larger angles (not reached by a physical
+// trajectory: 8e5 rad) are first folded by multiples of 2^17 * 2pi, which keeps full
+// accuracy up to ~8e11 rad and degrades gracefully beyond.
 __device__ __forceinline__ void sincos_f64(double x, double& s, double& c) {
-  if (__builtin_expect(!(fabs(x) < 8.0e5), 0)) {
-    sincos(x, &s, &c);
-    return;
+  if (__builtin_expect(fabs(x) >= 8.0e5, 0)) {
+    const double n1 = rint(x * (1.0 / (6.283185307179586476925 * 131072.0)));
+    // 2pi * 2^17 in the same three pieces as pi/2 below (power-of-two scalings are exact)
+    x = fma(-n1, 1.57079632673412561417e+00 * 524288.0, x);
+    x = fma(-n1, 6.07710050630396597660e-11 * 524288.0, x);
+    x = fma(-n1, 2.02226624879595063154e-21 * 524288.0, x);
   }
   const double fn = rint(x * 6.36619772367581382433e-01);
   double y = fma(-fn, 1.57079632673412561417e+00, x);
@@ -227,6 +183,17 @@ __device__ __forceinline__ void sincos_f64(double x, double& s, double& c) {
   c = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// sqrt for a >= 0: hardware v_rsq_f64 seed + two Heron corrections (<= 1 ulp);
+// 0, +inf and NaN pass through.
+__device__ __forceinline__ double sqrt_f64(double a) {
+  const double r = __builtin_amdgcn_rsq(a);
+  double y = a * r;
+  const double h = 0.5 * r;
+  y = fma(fma(-y, y, a), h, y);
+  y = fma(fma(-y, y, a), h, y);
+  return (a == 0.0 || a == __builtin_huge_val()) ? a : y;
+}
+
 // ---------------------------------------------------------------------------------
 // physics
 // ---------------------------------------------------------------------------------
@@ -237,58 +204,57 @@ struct Wrench {  // per-env, constant across substeps
   double apsi;   // U4 / Iz
 };
 
-// dynamics/__init__.py:120-132 + _u2/_u3/_u4 (:231-247); m* are the motor values.
-__device__ __forceinline__ Wrench motor_model(const DevConst& c, double m0, double m1, double m2,
-                                              double m3) {
-  const double w0 = m0 * c.w_scale, w1 = m1 * c.w_scale, w2 = m2 * c.w_scale, w3 = m3 * c.w_scale;
-  const double q0 = w0 * w0, q1 = w1 * w1, q2 = w2 * w2, q3 = w3 * w3;
-  const double U1 = c.B * (((q0 + q1) + q2) + q3);
-  const double U2 = c.LB * ((q1 + q2) - (q0 + q3));  // roll right
-  const double U3 = c.LB * ((q1 + q3) - (q0 + q2));  // pitch forward
-  const double U4 = c.D * ((q0 + q1) - (q2 + q3));   // yaw cw
+// dynamics/__init__.py:120-132 + _u2/_u3/_u4 (:231-247).  The squares of the motor
+// values are exact in float64 (24-bit inputs); the uniform factors (maxrpm*pi/30)^2,
+// B, L*B, D and the 1/M, 1/I divisions are folded into one host-side constant each.
+__device__ __forceinline__ Wrench motor_model(const DevConst& c, float a0, float a1, float a2,
+                                              float a3) {
+  const double m0 = (double)a0, m1 = (double)a1, m2 = (double)a2, m3 = (double)a3;
+  const double q0 = m0 * m0, q1 = m1 * m1, q2 = m2 * m2, q3 = m3 * m3;
   Wrench w;
-  w.bz = U1 * c.neg_inv_M;
-  w.aphi = U2 * c.inv_Ix;
-  w.athe = U3 * c.inv_Iy;
-  w.apsi = U4 * c.inv_Iz;
+  w.bz = c.k_thrust * (((q0 + q1) + q2) + q3);
+  w.aphi = c.k_roll * ((q1 + q2) - (q0 + q3));   // roll right
+  w.athe = c.k_pitch * ((q1 + q3) - (q0 + q2));  // pitch forward
+  w.apsi = c.k_yaw * ((q0 + q1) - (q2 + q3));    // yaw cw
   return w;
 }
 
 // One Dynamics.setMotors() (dynamics/__init__.py:134-197) on the register-resident
-// state.  fs = flight status, pend = perturbation not yet consumed, k* = force/M.
-__device__ __forceinline__ void physics_call(const DevConst& c, const Wrench& w, double (&x)[12],
-                                             int& fs, bool& pend, double kx, double ky, double kz) {
+// state.  fs = flight status.  Returns what the call did, because the pending reset
+// perturbation (which upstream adds to the odd derivative slots twice) is applied by the
+// caller: it only ever enters the first call that integrates, survives a ground-contact
+// freeze, and is dropped by any other call.
+enum { kCallOther = 0, kCallIntegrated = 1, kCallFroze = 2 };
+
+__device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, double (&x)[12],
+                                            int& fs) {
   double sph, cph, sth, cth, sps, cps;
   sincos_f64(x[6], sph, cph);
   sincos_f64(x[8], sth, cth);
   sincos_f64(x[10], sps, cps);
   const double ax = w.bz * (sph * sps + cph * cps * sth);
   const double ay = w.bz * (cph * sps * sth - cps * sph);
-  const double netz = w.bz * (cph * cth) + c.G;
+  const double netz = fma(w.bz, cph * cth, c.G);
 
   if (fs == CS_STATUS_LANDED && netz < 0.0) fs = CS_STATUS_AIRBORNE;
 
+  int what = kCallOther;
   if (fs == CS_STATUS_LEVELING) {
     x[6] = 0.0;
     x[8] = 0.0;
     fs = CS_STATUS_LANDED;
-    pend = false;
   } else if (fs == CS_STATUS_AIRBORNE) {
     if (x[4] > 0.0 && x[5] > 0.0) {
       // ground contact: freeze (no integrate, perturbation kept).  Upstream tests
       // dz against LANDING_VEL_Y and |dy| against LANDING_VEL_X (:166-171).
       const bool hard = x[5] > c.land_vy || fabs(x[3]) > c.land_vx || fabs(x[6]) > c.land_ang;
       fs = hard ? CS_STATUS_CRASHED : CS_STATUS_LEVELING;
+      what = kCallFroze;
     } else {
-      const double px = pend ? kx : 0.0, py = pend ? ky : 0.0, pz = pend ? kz : 0.0;
       const double dphi = x[7], dthe = x[9], dpsi = x[11];
-      // perturbation enters twice (inside the derivative and again at :183)
-      const double d1 = (ax + px) + px;
-      const double d3 = (ay + py) + py;
-      const double d5 = (netz + pz) + pz;
-      const double d7 = dpsi * dthe * c.c_dphi + w.aphi;
-      const double d9 = -(dpsi * dphi * c.c_dthe + w.athe);
-      const double d11 = dthe * dphi * c.c_dpsi + w.apsi;
+      const double d7 = fma(dpsi * dthe, c.c_dphi, w.aphi);
+      const double d9 = -fma(dpsi * dphi, c.c_dthe, w.athe);
+      const double d11 = fma(dthe * dphi, c.c_dpsi, w.apsi);
       const double dt = c.dt;
       x[0] = fma(dt, x[1], x[0]);
       x[2] = fma(dt, x[3], x[2]);
@@ -296,16 +262,33 @@ __device__ __forceinline__ void physics_call(const DevConst& c, const Wrench& w,
       x[6] = fma(dt, dphi, x[6]);
       x[8] = fma(dt, dthe, x[8]);
       x[10] = fma(dt, dpsi, x[10]);
-      x[1] = fma(dt, d1, x[1]);
-      x[3] = fma(dt, d3, x[3]);
-      x[5] = fma(dt, d5, x[5]);
+      x[1] = fma(dt, ax, x[1]);
+      x[3] = fma(dt, ay, x[3]);
+      x[5] = fma(dt, netz, x[5]);
       x[7] = fma(dt, d7, x[7]);
       x[9] = fma(dt, d9, x[9]);
       x[11] = fma(dt, d11, x[11]);
-      pend = false;
+      what = kCallIntegrated;
     }
-  } else {
-    pend = false;  // CRASHED (or LANDED with netz >= 0): only the perturbation is cleared
+  }
+  return what;
+}
+
+// `nsub` x Dynamics.setMotors with one wrench.  pend = a reset perturbation is waiting;
+// k2[] = 2 * dt * force / M, i.e. the velocity kick of its double application (:263-271
+// inside the derivative plus :183).  It is consumed by the first call that does not
+// freeze on ground contact, and only an integrating call applies it.
+__device__ __forceinline__ void physics_substeps(const DevConst& c, const Wrench& w,
+                                                 double (&x)[12], int& fs, bool& pend,
+                                                 const double (&k2)[3]) {
+  for (int sub = 0; sub < c.nsub; ++sub) {
+    const int what = physics_call(c, w, x, fs);
+    if (pend && what == kCallIntegrated) {
+      x[1] += k2[0];
+      x[3] += k2[1];
+      x[5] += k2[2];
+    }
+    if (what != kCallFroze) pend = false;
   }
 }
 
@@ -314,7 +297,7 @@ __device__ __forceinline__ double lander_shaping(const DevConst& c, const double
   const double s6 =
       ((((x[0] * x[0] + x[1] * x[1]) + x[2] * x[2]) + x[3] * x[3]) + x[4] * x[4]) + x[5] * x[5];
   const double s2 = x[10] * x[10] + x[11] * x[11];
-  double sh = -(c.xyz_pen * sqrt(s6) + c.yaw_pen * sqrt(s2));
+  double sh = -(c.xyz_pen * sqrt_f64(s6) + c.yaw_pen * sqrt_f64(s2));
   if (fabs(x[5]) > c.dz_max) sh -= c.dz_pen;
   return sh;
 }
@@ -326,11 +309,10 @@ __device__ __forceinline__ double lander_shaping(const DevConst& c, const double
 // ---------------------------------------------------------------------------------
 template <int OBS>
 __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_wave, int lane,
-                                           int64_t env0, int64_t n, bool valid,
+                                           uint32_t env0, uint32_t n, bool valid,
                                            const float (&row)[OBS]) {
   if (out == nullptr) return;
-  const int64_t rows = n - env0;  // rows this wavefront owns (>= 1 for a live wave)
-  if (rows >= kWave) {
+  if (n - env0 >= (uint32_t)kWave) {
 #pragma unroll
     for (int j = 0; j < OBS; j += 2) {
       *reinterpret_cast<float2*>(lds_wave + lane * OBS + j) = make_float2(row[j], row[j + 1]);
@@ -338,7 +320,7 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float4* dst = reinterpret_cast<float4*>(out + env0 * OBS);
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)env0 * OBS);
     const float4* src = reinterpret_cast<const float4*>(lds_wave);
     constexpr int kVec = kWave * OBS / 4;  // 160 (Lander3D) or 192 (Hover3D) float4
 #pragma unroll
@@ -347,7 +329,7 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
       if (v < kVec) dst[v] = src[v];
     }
   } else if (valid) {  // ragged last wavefront: plain row stores
-    float* dst = out + (env0 + lane) * OBS;
+    float* dst = out + (size_t)(env0 + lane) * OBS;
 #pragma unroll
     for (int j = 0; j < OBS; ++j) dst[j] = row[j];
   }
@@ -363,50 +345,57 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t n = (uint32_t)s.n, stride = (uint32_t)s.stride;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
-  const int64_t env0 = i - lane;
-  const bool valid = i < s.n;
-  const int64_t ii = valid ? i : 0;  // out-of-range lanes shadow env 0, never store
+  const uint32_t env0 = i - lane;
+  const bool valid = i < n;
+  const uint32_t ii = valid ? i : 0u;  // out-of-range lanes shadow env 0, never store
 
   T* __restrict__ X = static_cast<T*>(s.x);
   T* __restrict__ F = static_cast<T*>(s.force);
   T* __restrict__ PS = static_cast<T*>(s.prev_shaping);
   uint32_t* __restrict__ GD = s.guard;
 
-  // ---- loads (all issued before first use) ----
-  const uint64_t epoch = s.epoch[0];
-  const float4 act = reinterpret_cast<const float4*>(io.actions_dev)[ii];
+  // ---- loads, in order of first use ----
   const uint8_t sb = s.status[ii];
-  int steps = s.steps[ii];
+  const float4 act = reinterpret_cast<const float4*>(io.actions_dev)[ii];
   T raw[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) raw[k] = X[k * s.stride + ii];
   uint32_t g[3] = {0, 0, 0};
+  raw[6] = X[6 * stride + ii];
+  raw[8] = X[8 * stride + ii];
+  raw[10] = X[10 * stride + ii];
   if constexpr (MODE == CS_STATE_F32G) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) g[j] = GD[j * s.stride + ii];
+    g[1] = GD[1 * stride + ii];
+    g[2] = GD[2 * stride + ii];
+    g[0] = GD[0 * stride + ii];
   }
-  double x[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], byte_of(g, k));
+  for (int k = 0; k < 12; ++k)
+    if (k != 6 && k != 8 && k != 10) raw[k] = X[k * stride + ii];
+  int steps = s.steps[ii];
   double prev_sh = 0.0;
   if constexpr (TASK == CS_TASK_LANDER3D) prev_sh = (double)PS[ii];
   float ep_ret = 0.f;
   if (c.stats) ep_ret = s.ep_return[ii];
 
+  // second-round loads, issued as soon as the status byte is back and consumed late:
+  // the pending reset perturbation and (for lanes that will reset) the episode number
   int fs = sb & kStatusMask;
   bool pend = (sb & kFlagPerturbPending) != 0;
-  double kx = 0.0, ky = 0.0, kz = 0.0;
-  if (pend) {
-    kx = (double)F[0 * s.stride + ii] * c.inv_M;
-    ky = (double)F[1 * s.stride + ii] * c.inv_M;
-    kz = (double)F[2 * s.stride + ii] * c.inv_M;
-  }
   const bool resetting = c.autoreset == CS_AUTORESET_NEXT_STEP && (sb & kFlagResetPending) != 0;
+  T fraw[3] = {(T)0, (T)0, (T)0};
+  if (pend) {
+    fraw[0] = F[0 * stride + ii];
+    fraw[1] = F[1 * stride + ii];
+    fraw[2] = F[2 * stride + ii];
+  }
+  uint32_t episode = 0;
+  if (c.autoreset != CS_AUTORESET_DISABLED) episode = s.episode[ii];
 
-  const uint32_t gid_lo = c.id_lo + (uint32_t)ii;
-  const uint32_t gid_hi = c.id_hi + (uint32_t)((uint64_t)ii >> 32) + (gid_lo < c.id_lo ? 1u : 0u);
+  double x[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], byte_of(g, k));
 
   double reward = 0.0;
   bool term = false, trunc = false;
@@ -417,18 +406,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   const int status0 = fs;
   if (!resetting && status0 != CS_STATUS_LANDED) {
     // np.clip(action, 0, 1), task.py:91 (comparisons, so a NaN action stays NaN as upstream)
-    const double m0 = (double)clip01(act.x), m1 = (double)clip01(act.y);
-    const double m2 = (double)clip01(act.z), m3 = (double)clip01(act.w);
-    const Wrench w = motor_model(c, m0, m1, m2, m3);
-    for (int sub = 0; sub < c.nsub; ++sub) physics_call(c, w, x, fs, pend, kx, ky, kz);
+    const Wrench w = motor_model(c, clip01(act.x), clip01(act.y), clip01(act.z), clip01(act.w));
+    const double k2[3] = {(double)fraw[0] * c.kick, (double)fraw[1] * c.kick,
+                          (double)fraw[2] * c.kick};
+    physics_substeps(c, w, x, fs, pend, k2);
   }
 
   // ---- round to the stored word; everything below sees exactly what is stored ----
-  uint32_t h[3] = {0, 0, 0};
-  if constexpr (MODE == CS_STATE_F32_SR) sr_hash(c, epoch, gid_lo, h);
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
-    const Stored<MODE> e = encode_word<MODE>(x[k], byte_of(h, k));
+    const Stored<MODE> e = encode_word<MODE>(x[k]);
     xs[k] = e.word;
     gs[k >> 2] |= e.guard << (8 * (k & 3));
     x[k] = e.value;
@@ -493,17 +480,17 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   float* lds_wave = lds + (threadIdx.x - lane) * OBS;
   const bool same_step = c.autoreset == CS_AUTORESET_SAME_STEP;
   if (same_step && io.final_obs_dev != nullptr && fin && valid) {
-    float* dst = io.final_obs_dev + i * OBS;
+    float* dst = io.final_obs_dev + (size_t)i * OBS;
 #pragma unroll
     for (int k = 0; k < OBS; ++k) dst[k] = row[k];
   }
 
   // ---- masked reset (task.py:145-197): fresh state, Philox force, shaping, steps = 1 ----
   const bool do_reset = resetting || (same_step && fin);
-  bool reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && fin;
+  const bool reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && fin;
   if (do_reset) {
     double f[3];
-    draw_force(c, epoch, gid_lo, gid_hi, f);
+    draw_force(c, c.id_lo + ii, c.id_hi + ((c.id_lo + ii) < c.id_lo ? 1u : 0u), episode, f);
 #pragma unroll
     for (int k = 0; k < 12; ++k) xs[k] = (T)0;
     xs[4] = (T)c.z0;
@@ -516,19 +503,20 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
     ep_ret = 0.f;
     prev_sh = c.reset_shaping;
     if (valid) {
-      F[0 * s.stride + i] = (T)f[0];
-      F[1 * s.stride + i] = (T)f[1];
-      F[2 * s.stride + i] = (T)f[2];
+      F[0 * stride + i] = (T)f[0];
+      F[1 * stride + i] = (T)f[1];
+      F[2 * stride + i] = (T)f[2];
+      s.episode[i] = episode + 1;
     }
   }
 
   // ---- stores ----
   if (valid) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) X[k * s.stride + i] = xs[k];
+    for (int k = 0; k < 12; ++k) X[k * stride + i] = xs[k];
     if constexpr (MODE == CS_STATE_F32G) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) GD[j * s.stride + i] = gs[j];
+      for (int j = 0; j < 3; ++j) GD[j * stride + i] = gs[j];
     }
     s.status[i] = (uint8_t)(fs | (pend ? kFlagPerturbPending : 0) | (reset_pending ? kFlagResetPending : 0));
     s.steps[i] = steps;
@@ -538,8 +526,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
     if (io.terminated_dev) io.terminated_dev[i] = term ? 1 : 0;
     if (io.truncated_dev) io.truncated_dev[i] = trunc ? 1 : 0;
   }
-  write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, s.n, valid, row);
-  epoch_tick(s, epoch);
+  write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, n, valid, row);
 }
 
 // ---------------------------------------------------------------------------------
@@ -549,48 +536,44 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, const DevState s,
                                                             const float* __restrict__ motors) {
   using T = typename WordOf<MODE>::type;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint64_t epoch = s.epoch[0];
-  if (i < s.n) {
-    T* __restrict__ X = static_cast<T*>(s.x);
-    const T* __restrict__ F = static_cast<const T*>(s.force);
-    uint32_t* __restrict__ GD = s.guard;
-    const float4 mv = reinterpret_cast<const float4*>(motors)[i];
-    const uint8_t sb = s.status[i];
-    uint32_t g[3] = {0, 0, 0};
-    if constexpr (MODE == CS_STATE_F32G) {
+  const uint32_t n = (uint32_t)s.n, stride = (uint32_t)s.stride;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  T* __restrict__ X = static_cast<T*>(s.x);
+  const T* __restrict__ F = static_cast<const T*>(s.force);
+  uint32_t* __restrict__ GD = s.guard;
+  const float4 mv = reinterpret_cast<const float4*>(motors)[i];
+  const uint8_t sb = s.status[i];
+  uint32_t g[3] = {0, 0, 0};
+  if constexpr (MODE == CS_STATE_F32G) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) g[j] = GD[j * s.stride + i];
-    }
-    double x[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(X[k * s.stride + i], byte_of(g, k));
-    int fs = sb & kStatusMask;
-    bool pend = (sb & kFlagPerturbPending) != 0;
-    double kx = 0.0, ky = 0.0, kz = 0.0;
-    if (pend) {
-      kx = (double)F[0 * s.stride + i] * c.inv_M;
-      ky = (double)F[1 * s.stride + i] * c.inv_M;
-      kz = (double)F[2 * s.stride + i] * c.inv_M;
-    }
-    const Wrench w = motor_model(c, (double)mv.x, (double)mv.y, (double)mv.z, (double)mv.w);
-    for (int sub = 0; sub < c.nsub; ++sub) physics_call(c, w, x, fs, pend, kx, ky, kz);
-    uint32_t h[3] = {0, 0, 0};
-    if constexpr (MODE == CS_STATE_F32_SR) sr_hash(c, epoch, c.id_lo + (uint32_t)i, h);
-    uint32_t gs[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const Stored<MODE> e = encode_word<MODE>(x[k], byte_of(h, k));
-      X[k * s.stride + i] = e.word;
-      gs[k >> 2] |= e.guard << (8 * (k & 3));
-    }
-    if constexpr (MODE == CS_STATE_F32G) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) GD[j * s.stride + i] = gs[j];
-    }
-    s.status[i] = (uint8_t)(fs | (pend ? kFlagPerturbPending : 0) | (sb & kFlagResetPending));
+    for (int j = 0; j < 3; ++j) g[j] = GD[j * stride + i];
   }
-  epoch_tick(s, epoch);
+  double x[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(X[k * stride + i], byte_of(g, k));
+  int fs = sb & kStatusMask;
+  bool pend = (sb & kFlagPerturbPending) != 0;
+  double k2[3] = {0.0, 0.0, 0.0};
+  if (pend) {
+    k2[0] = (double)F[0 * stride + i] * c.kick;
+    k2[1] = (double)F[1 * stride + i] * c.kick;
+    k2[2] = (double)F[2 * stride + i] * c.kick;
+  }
+  const Wrench w = motor_model(c, mv.x, mv.y, mv.z, mv.w);
+  physics_substeps(c, w, x, fs, pend, k2);
+  uint32_t gs[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const Stored<MODE> e = encode_word<MODE>(x[k]);
+    X[k * stride + i] = e.word;
+    gs[k >> 2] |= e.guard << (8 * (k & 3));
+  }
+  if constexpr (MODE == CS_STATE_F32G) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) GD[j * stride + i] = gs[j];
+  }
+  s.status[i] = (uint8_t)(fs | (pend ? kFlagPerturbPending : 0) | (sb & kFlagResetPending));
 }
 
 // ---------------------------------------------------------------------------------
@@ -603,48 +586,47 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
                                                        float* __restrict__ obs) {
   using T = typename WordOf<MODE>::type;
   constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint64_t epoch = s.epoch[0];
-  const bool valid = i < s.n;
+  const uint32_t n = (uint32_t)s.n, stride = (uint32_t)s.stride;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
   T* __restrict__ X = static_cast<T*>(s.x);
   T* __restrict__ F = static_cast<T*>(s.force);
   T* __restrict__ PS = static_cast<T*>(s.prev_shaping);
-  if (valid && (mask == nullptr || mask[i] != 0)) {
+  if (mask == nullptr || mask[i] != 0) {
     double f[3];
+    const uint32_t episode = s.episode[i];
     if (force_xyz != nullptr) {
-      f[0] = (double)force_xyz[0 * s.n + i];
-      f[1] = (double)force_xyz[1 * s.n + i];
-      f[2] = (double)force_xyz[2 * s.n + i];
+      f[0] = (double)force_xyz[0 * (size_t)n + i];
+      f[1] = (double)force_xyz[1 * (size_t)n + i];
+      f[2] = (double)force_xyz[2 * (size_t)n + i];
     } else {
-      const uint32_t gid_lo = c.id_lo + (uint32_t)i;
-      const uint32_t gid_hi = c.id_hi + (uint32_t)((uint64_t)i >> 32) + (gid_lo < c.id_lo ? 1u : 0u);
-      draw_force(c, epoch, gid_lo, gid_hi, f);
+      draw_force(c, c.id_lo + i, c.id_hi + ((c.id_lo + i) < c.id_lo ? 1u : 0u), episode, f);
     }
 #pragma unroll
-    for (int k = 0; k < 12; ++k) X[k * s.stride + i] = (k == 4) ? (T)c.z0 : (T)0;
+    for (int k = 0; k < 12; ++k) X[k * stride + i] = (k == 4) ? (T)c.z0 : (T)0;
     if constexpr (MODE == CS_STATE_F32G) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) s.guard[j * s.stride + i] = 0u;
+      for (int j = 0; j < 3; ++j) s.guard[j * stride + i] = 0u;
     }
-    F[0 * s.stride + i] = (T)f[0];
-    F[1 * s.stride + i] = (T)f[1];
-    F[2 * s.stride + i] = (T)f[2];
+    F[0 * stride + i] = (T)f[0];
+    F[1 * stride + i] = (T)f[1];
+    F[2 * stride + i] = (T)f[2];
+    s.episode[i] = episode + 1;
     s.status[i] = (uint8_t)(c.status0 | kFlagPerturbPending);
     s.steps[i] = 1;
     PS[i] = (T)c.reset_shaping;  // NaN (= None) for Hover3D
     if (c.stats) s.ep_return[i] = 0.f;
   }
-  if (valid && obs != nullptr) {
+  if (obs != nullptr) {
     uint32_t g[3] = {0, 0, 0};
     if constexpr (MODE == CS_STATE_F32G) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) g[j] = s.guard[j * s.stride + i];
+      for (int j = 0; j < 3; ++j) g[j] = s.guard[j * stride + i];
     }
 #pragma unroll
     for (int k = 0; k < OBS; ++k)
-      obs[i * OBS + k] = observe_word<MODE>(X[k * s.stride + i], byte_of(g, k));
+      obs[(size_t)i * OBS + k] = observe_word<MODE>(X[k * stride + i], byte_of(g, k));
   }
-  epoch_tick(s, epoch);
 }
 
 inline int grid_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
@@ -660,11 +642,9 @@ hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
     return hipGetLastError();                                                    \
   }
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_SR)
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F64)
   CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_SR)
   CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_RN)
   CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F64)
 #undef CS_LAUNCH
@@ -680,7 +660,6 @@ hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, con
     return hipGetLastError();                                                          \
   }
   CS_LAUNCH(CS_STATE_F32G)
-  CS_LAUNCH(CS_STATE_F32_SR)
   CS_LAUNCH(CS_STATE_F32_RN)
   CS_LAUNCH(CS_STATE_F64)
 #undef CS_LAUNCH
@@ -698,11 +677,9 @@ hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s
     return hipGetLastError();                                                          \
   }
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_SR)
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F64)
   CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_SR)
   CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_RN)
   CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F64)
 #undef CS_LAUNCH

@@ -28,8 +28,7 @@ _TASKS = {"lander3d": _lib.TASK_LANDER3D, "lander": _lib.TASK_LANDER3D,
           "hover3d": _lib.TASK_HOVER3D, "hover": _lib.TASK_HOVER3D}
 # float32 (default) = float32 state words + 8 guard bits; see DESIGN.md "state words"
 _STATE_MODES = {"float32": _lib.STATE_F32G, "float32_guard": _lib.STATE_F32G,
-                "float32_rn": _lib.STATE_F32_RN, "float32_sr": _lib.STATE_F32_SR,
-                "float64": _lib.STATE_F64}
+                "float32_rn": _lib.STATE_F32_RN, "float64": _lib.STATE_F64}
 _AUTORESET = {"disabled": _lib.AUTORESET_DISABLED, "next_step": _lib.AUTORESET_NEXT_STEP,
               "same_step": _lib.AUTORESET_SAME_STEP}
 _VEHICLE_KEYS = ("B", "D", "M", "L", "Ix", "Iy", "Iz", "Jr", "maxrpm")   # dji_phantom.py:9-26
@@ -158,7 +157,7 @@ class CopterVecEnv:
 
         options: {'mask': bool[N], 'forces': float[3,N] newtons (else Philox U[-F,F))}.
         seed re-keys the perturbation stream (the reference draws from global np.random,
-        task.py:199-202; here the draw is counter-based on (seed, env id, call count))."""
+        task.py:199-202; here the draw is counter-based on (seed, global env id, episode #))."""
         self._check_open()
         torch = _torch()
         options = options or {}
@@ -270,18 +269,19 @@ class CopterVecEnv:
         self._check_open()
         n = self.num_envs
         out = {"x": np.empty((12, n)), "status": np.empty(n, np.uint8), "steps": np.empty(n, np.int32),
-               "prev_shaping": np.empty(n), "force": np.empty((3, n)), "flags": np.empty(n, np.uint8)}
+               "prev_shaping": np.empty(n), "force": np.empty((3, n)), "flags": np.empty(n, np.uint8),
+               "episode": np.empty(n, np.uint32)}
         er = np.empty(n) if self.episode_stats else None
         p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         _lib.check(self._lib.cs_get_state(self._ctx, p(out["x"]), p(out["status"]), p(out["steps"]),
                                           p(out["prev_shaping"]), p(out["force"]), p(out["flags"]),
-                                          p(er), self._stream()))
+                                          p(er), p(out["episode"]), self._stream()))
         if er is not None:
             out["episode_return"] = er
         return out
 
     def set_state(self, x=None, status=None, steps=None, prev_shaping=None, force=None, flags=None,
-                  episode_return=None):
+                  episode_return=None, episode=None):
         self._check_open()
         n = self.num_envs
 
@@ -294,19 +294,10 @@ class CopterVecEnv:
             return a
         arrs = [prep(x, (12, n), np.float64), prep(status, (n,), np.uint8), prep(steps, (n,), np.int32),
                 prep(prev_shaping, (n,), np.float64), prep(force, (3, n), np.float64),
-                prep(flags, (n,), np.uint8), prep(episode_return, (n,), np.float64)]
+                prep(flags, (n,), np.uint8), prep(episode_return, (n,), np.float64),
+                prep(episode, (n,), np.uint32)]
         ptrs = [None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs]
         _lib.check(self._lib.cs_set_state(self._ctx, *ptrs, self._stream()))
-
-    @property
-    def epoch(self):
-        v = C.c_uint64()
-        _lib.check(self._lib.cs_get_epoch(self._ctx, C.byref(v), self._stream()))
-        return v.value
-
-    @epoch.setter
-    def epoch(self, value):
-        _lib.check(self._lib.cs_set_epoch(self._ctx, int(value), self._stream()))
 
 
 def _to_numpy(v):

@@ -63,8 +63,7 @@ enum {
   CS_STATE_F32G = 0,    /* float32 words + 8 guard bits per component, packed four
                            to a dword (default; +24 B per env-step of traffic)    */
   CS_STATE_F32_RN = 1,  /* float32 words only, round-to-nearest-even              */
-  CS_STATE_F64 = 2,     /* float64 words                                          */
-  CS_STATE_F32_SR = 3   /* float32 words only, stochastic rounding                */
+  CS_STATE_F64 = 2      /* float64 words                                          */
 };
 
 /* Gymnasium vector-env autoreset conventions (upstream has a single env and none). */
@@ -135,15 +134,9 @@ int cs_num_envs(const cs_ctx* ctx, int64_t* out);
 int cs_obs_dim(const cs_ctx* ctx, int32_t* out);
 int cs_seed(cs_ctx* ctx, uint64_t seed);
 int cs_set_altitude(cs_ctx* ctx, double altitude);
-/* Call counter that keys the per-call random streams.  It lives in device memory and is
- * advanced by every reset/step/set_motors KERNEL (so a captured hipGraph replays with
- * fresh keys); both calls synchronise `stream`. */
-int cs_get_epoch(cs_ctx* ctx, uint64_t* out, void* stream);
-int cs_set_epoch(cs_ctx* ctx, uint64_t epoch, void* stream);
-
 /* Reset envs with mask_dev[i] != 0 (NULL = all).  force_xyz_dev: [3,N] perturbation
  * forces in newtons to install (NULL = draw U[-F,F) with Philox4x32-10 keyed by
- * (seed, global env id, epoch)).  obs_dev (nullable) receives ALL envs' observations. */
+ * (seed, global env id, that env's episode number)).  obs_dev (nullable) receives ALL envs' observations. */
 int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, float* obs_dev,
              void* stream);
 
@@ -159,14 +152,15 @@ int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream);
  * Any pointer may be NULL.  x_host is [12,N] float64 struct-of-arrays in upstream slot
  * order (x,dx,y,dy,z,dz,phi,dphi,theta,dtheta,psi,dpsi); force_xyz_host is [3,N] newtons;
  * flags_host bit0 = perturbation pending, bit1 = reset pending (NEXT_STEP);
- * prev_shaping NaN = upstream's None. */
+ * prev_shaping NaN = upstream's None; episode_host [N] = episodes started so far per env
+ * (the Philox counter word of the next reset draw). */
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
-                 double* episode_return_host, void* stream);
+                 double* episode_return_host, uint32_t* episode_host, void* stream);
 int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
                  const int32_t* steps_host, const double* prev_shaping_host,
                  const double* force_xyz_host, const uint8_t* flags_host,
-                 const double* episode_return_host, void* stream);
+                 const double* episode_return_host, const uint32_t* episode_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,8 @@ proves the two agree bit-for-bit, so this file inherits that pin.  On top of
 the reference semantics it models the *batch* features the device library adds
 (none of which exist upstream): struct-of-arrays state, storage dtype
 (float32 state words with float64 arithmetic), inner substeps, masked
-auto-reset with a counter-based Philox4x32-10 perturbation draw, and the
+auto-reset with a counter-based Philox4x32-10 perturbation draw keyed by
+(seed, global env id, episode number), and the
 time-limit-as-truncation option.  It is the checker the GPU parity tests and
 __graft_entry__.smoke() compare the HIP kernels against, and the
 "vectorised" row of bench.py's cpu_baseline.
@@ -56,19 +57,19 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def draw_forces(seed, env_ids, epoch, magnitude):
+def draw_forces(seed, env_ids, episode, magnitude):
     """Perturbation force draw shared (by specification) with the device kernel.
 
-    counter = (env_id lo, env_id hi, epoch lo, epoch hi), key = (seed lo, seed hi);
+    counter = (env_id lo, env_id hi, episode number of that env, 0), key = (seed lo, seed hi);
     u = (word >> 8) * 2^-24 in [0,1);  F = u * (2*magnitude) - magnitude, float64,
     un-fused multiply then add.  Returns [3, n] float64.
     """
     env_ids = np.asarray(env_ids, dtype=np.uint64)
-    epoch = np.uint64(epoch)
+    episode = np.broadcast_to(np.asarray(episode, dtype=np.uint32), env_ids.shape)
     seed = np.uint64(seed)
     sh = np.uint64(32)
     r = philox4x32_10((env_ids & _U32).astype(np.uint32), (env_ids >> sh).astype(np.uint32),
-                      np.uint32(epoch & _U32), np.uint32(epoch >> sh),
+                      episode, np.uint32(0),
                       np.uint32(seed & _U32), np.uint32(seed >> sh))
     out = np.empty((3, env_ids.shape[0]))
     for i in range(3):
@@ -81,50 +82,6 @@ def draw_forces(seed, env_ids, epoch, magnitude):
 # Stored-word rounding shared (by specification) with the device kernels.
 # ---------------------------------------------------------------------------
 _M64 = (1 << 64) - 1
-
-
-def _splitmix64(z):
-    z = (z + 0x9E3779B97F4A7C15) & _M64
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
-    return z ^ (z >> 31)
-
-
-def _lowbias32(x):
-    x = x.astype(np.uint32)
-    with np.errstate(over="ignore"):
-        x = x ^ (x >> np.uint32(16))
-        x = (x * np.uint32(0x7feb352d)).astype(np.uint32)
-        x = x ^ (x >> np.uint32(15))
-        x = (x * np.uint32(0x846ca68b)).astype(np.uint32)
-        x = x ^ (x >> np.uint32(16))
-    return x
-
-
-def sr_keys(seed, epoch):
-    a = _splitmix64((seed ^ ((epoch * 0x9E3779B97F4A7C15) & _M64)) & _M64)
-    b = _splitmix64(a)
-    return a & 0xFFFFFFFF, a >> 32, b & 0xFFFFFFFF
-
-
-def stochastic_round_f32(x64, env_ids, seed, epoch):
-    """float64 [12,n] -> float32 [12,n]: add 8 hashed random bits below the float32 ulp
-    (bits 28..21 of the float64 mantissa), truncate the 29 dropped bits, convert (exact)."""
-    k0, k1, k2 = sr_keys(int(seed), int(epoch))
-    gid = (np.asarray(env_ids, dtype=np.uint64) & _U32).astype(np.uint32)
-    h0 = _lowbias32(gid ^ np.uint32(k0))
-    h1 = _lowbias32(h0 ^ np.uint32(k1))
-    h2 = _lowbias32(h1 ^ np.uint32(k2))
-    hs = (h0, h1, h2)
-    out = np.empty(x64.shape, dtype=np.float32)
-    for k in range(12):
-        rnd = ((hs[k >> 2] >> np.uint32(8 * (k & 3))) & np.uint32(0xFF)).astype(np.uint64)
-        b = np.ascontiguousarray(x64[k], dtype=np.float64).view(np.uint64)
-        with np.errstate(over="ignore"):
-            b = (b + (rnd << np.uint64(21))) & np.uint64(~0x1FFFFFFF & _M64)
-        with np.errstate(over="ignore", invalid="ignore"):
-            out[k] = b.view(np.float64).astype(np.float32)
-    return out
 
 
 def guard_round(x64):
@@ -150,7 +107,6 @@ def guard_observe(x64):
 STORE_MODES = {"float32": (np.float32, np.float64, "guard"),
                "float32_guard": (np.float32, np.float64, "guard"),
                "float32_rn": (np.float32, np.float32, "rn"),
-               "float32_sr": (np.float32, np.float32, "sr"),
                "float64": (np.float64, np.float64, "rn")}
 
 
@@ -173,7 +129,7 @@ class VecOracle:
         self.obs_dim = 10 if task == "lander3d" else 12
         self.dt = 1. / (tp.frames_per_second * self.substeps)
         self.max_angle = np.radians(tp.max_angle)
-        self.epoch = 0                       # +1 per reset()/step() call (Philox counter)
+        self.episode = np.zeros(self.n, dtype=np.uint32)   # episodes started (Philox counter word)
         n = self.n
         self.x = np.zeros((12, n), dtype=xdtype)          # struct-of-arrays state
         self.status = np.full(n, LANDED, dtype=np.uint8)
@@ -265,10 +221,11 @@ class VecOracle:
         self.x[4, m] = self.T.type(-tp.initial_altitude)
         self.status[m] = AIRBORNE if -tp.initial_altitude < 0 else LANDED
         if forces is None:
-            f = draw_forces(self.seed, self.env_ids[m], self.epoch, tp.initial_random_force)
+            f = draw_forces(self.seed, self.env_ids[m], self.episode[m], tp.initial_random_force)
         else:
             f = np.asarray(forces, dtype=np.float64)[:, m]
         self.force[:, m] = f.astype(self.T)
+        self.episode[m] += np.uint32(1)
         self.pending[m] = True
         self.done_pending[m] = False
         xs = self.x[:, m].astype(np.float64)
@@ -286,7 +243,6 @@ class VecOracle:
             self.seed = int(seed)
         m = np.ones(self.n, dtype=bool) if mask is None else np.asarray(mask).astype(bool)
         self._reset_lanes(m, forces)
-        self.epoch += 1
         return self.observe()
 
     def observe(self):
@@ -313,12 +269,9 @@ class VecOracle:
         for _ in range(self.substeps):
             self._physics(x, self.status, self.pending, k, motors, active)
         self.x[:] = self._round(x)
-        self.epoch += 1
 
     def _round(self, x64):
         """float64 registers -> stored state words."""
-        if self.rounding == "sr":
-            return stochastic_round_f32(x64, self.env_ids, self.seed, self.epoch)
         if self.rounding == "guard":
             return guard_round(x64)
         with np.errstate(over="ignore"):
@@ -393,5 +346,4 @@ class VecOracle:
         elif self.autoreset == AUTORESET_SAME_STEP:
             self._reset_lanes(fin)
             obs[fin] = self.observe()[fin]
-        self.epoch += 1
         return obs, reward, term, trunc
