@@ -312,7 +312,7 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
                                            uint32_t env0, uint32_t n, bool valid,
                                            const float (&row)[OBS]) {
   if (out == nullptr) return;
-  if (n - env0 >= (uint32_t)kWave) {
+  if (env0 + (uint32_t)kWave <= n) {  // full wavefront (a wavefront past the end has env0 >= n)
 #pragma unroll
     for (int j = 0; j < OBS; j += 2) {
       *reinterpret_cast<float2*>(lds_wave + lane * OBS + j) = make_float2(row[j], row[j + 1]);

@@ -70,7 +70,9 @@ def assert_step_close(got, want, x_tol, r_abs=5e-5, r_rel=1e-5, ctx=""):
     assert e <= x_tol, "obs err %.3e > %.1e %s" % (e, x_tol, ctx)
     dr = np.abs(r.astype(np.float64) - wr)
     lim = r_abs + r_rel * np.abs(wr)
-    assert np.all(dr <= lim), "reward err %.3e %s" % (float(dr.max()), ctx)
+    j = int(np.argmax(dr - lim))
+    assert np.all(dr <= lim), "reward err %.3e at env %d (got %r want %r term %r obs %r) %s" % (
+        float(dr[j]), j, r[j], wr[j], term[j], obs[j], ctx)
 
 
 def assert_state_close(env, orc, x_tol, ctx=""):

@@ -405,3 +405,41 @@ def test_nonfinite_and_out_of_range_inputs_propagate_like_the_reference():
     assert np.isnan(st["x"][:, 1]).any() == np.isnan(orc.x[:, 1]).any()
     assert scaled_err(st["x"][:, 3:], orc.x[:, 3:]) < 1e-12
     env.close()
+
+
+@pytest.mark.parametrize("n", [1, 37, 64, 100, 257, 4133])
+def test_no_out_of_bounds_writes(n):
+    """Outputs sit in the middle of canary-filled buffers; a ragged last wavefront (and the
+    wavefronts of the last block that lie wholly past the end) must not touch the canaries."""
+    import ctypes as C
+    import torch
+    import gym_copter_amd
+    from gym_copter_amd import _lib
+    pad = 8192
+    for task, od in (("lander3d", 10), ("hover3d", 12)):
+        env = gym_copter_amd.CopterVecEnv(task, n, autoreset_mode="same_step", seed=3)
+        env.reset()
+        dev = env.device
+        bufs = {"obs": torch.full((pad + n * od + pad,), -7.0, device=dev),
+                "rew": torch.full((pad + n + pad,), -7.0, device=dev),
+                "term": torch.full((pad + n + pad,), 99, dtype=torch.uint8, device=dev),
+                "trunc": torch.full((pad + n + pad,), 99, dtype=torch.uint8, device=dev),
+                "fin": torch.full((pad + n * od + pad,), -7.0, device=dev)}
+        a = (torch.rand((n, 4), device=dev) * 2 - 1).contiguous()
+        io = _lib.StepIO()
+        io.actions_dev = a.data_ptr()
+        io.obs_dev = bufs["obs"].data_ptr() + 4 * pad
+        io.reward_dev = bufs["rew"].data_ptr() + 4 * pad
+        io.terminated_dev = bufs["term"].data_ptr() + pad
+        io.truncated_dev = bufs["trunc"].data_ptr() + pad
+        io.final_obs_dev = bufs["fin"].data_ptr() + 4 * pad
+        for _ in range(12):
+            _lib.check(env._lib.cs_step_ex(env._ctx, C.byref(io), env._stream()))
+        torch.cuda.synchronize()
+        for k, b in bufs.items():
+            m = n * od if k in ("obs", "fin") else n
+            canary = -7.0 if b.dtype == torch.float32 else 99
+            assert bool((b[:pad] == canary).all()) and bool((b[pad + m:] == canary).all()), (task, k)
+        assert bool((bufs["obs"][pad:pad + n * od] != -7.0).all())
+        assert bool((bufs["term"][pad:pad + n] <= 1).all())
+        env.close()
