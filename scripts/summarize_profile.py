@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs written by scripts/profile_gpu.sh into a text summary and
+profiles-ready JSON (per-launch averages for the step kernel)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out = sys.argv[1]
+res = {}
+
+
+def find(sub, pat):
+    f = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return f[0] if f else None
+
+
+f = find("trace", "*kernel_stats.csv")
+if f:
+    print("== rocprofv3 --kernel-trace --stats (bench default command) ==")
+    for r in csv.DictReader(open(f)):
+        print("%-110s calls=%6s avg_ns=%10s min=%8s max=%8s pct=%s" % (
+            r["Name"][:110], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
+        if "step_kernel" in r["Name"]:
+            res["step_kernel_avg_ns"] = float(r["AverageNs"])
+            res["step_kernel_calls"] = int(r["Calls"])
+
+
+def counters(sub):
+    f = find(sub, "*counter_collection.csv")
+    acc = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f)):
+            if "step_kernel" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+print("\n== PMC, per launch of step_kernel (means) ==")
+for n in (65536, 4194304):
+    fs = counters("fetch_%d" % n).get("FETCH_SIZE")
+    ws = counters("write_%d" % n).get("WRITE_SIZE")
+    if fs is None or ws is None:
+        continue
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
+    # exactly half of the bytes of a coalesced streaming read -> double it; WRITE_SIZE is exact.
+    fetch_b, write_b = 2 * fs * 1024, ws * 1024
+    algo = 176 * n
+    print("N=%8d  FETCH_SIZE=%.1f KiB (x2 corrected: %.2f MB)  WRITE_SIZE=%.1f KiB (%.2f MB)  "
+          "traffic=%.2f MB  algorithmic=%.2f MB  ratio=%.3f" % (
+              n, fs, fetch_b / 1e6, ws, write_b / 1e6, (fetch_b + write_b) / 1e6, algo / 1e6,
+              (fetch_b + write_b) / algo))
+    res["lander3d_%d" % n] = fetch_b + write_b
+    res["lander3d_%d_detail" % n] = {"fetch_bytes_corrected": fetch_b, "write_bytes": write_b,
+                                      "algorithmic_bytes": algo}
+for sub in ("sq1", "sq2", "l2"):
+    c = counters(sub)
+    for k, v in sorted(c.items()):
+        print("%-24s %14.1f" % (k, v))
+    res.update({"pmc_" + k: v for k, v in c.items()})
+json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)

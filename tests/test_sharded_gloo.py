@@ -1,0 +1,103 @@
+"""N>1 path on CPU: world_size-2 gloo process group.  The product's sharding host code
+(shard arithmetic, global-id keyed seeding, all-gather ordering) runs unmodified; the local
+stepper is replaced -- in this test only -- by a stand-in backed by the CPU oracle, because
+the HIP stepper needs a GPU.  The sharded result must equal the unsharded oracle batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gym_copter_amd.sharded import ShardedCopterVecEnv, shard_bounds
+from gym_copter_amd.spaces import Box
+from oracle import refvec
+from oracle.refvec import VecOracle
+
+TOTAL, STEPS = 96, 40
+
+
+class OracleLocalEnv:
+    """Test double with CopterVecEnv's surface, computing on the CPU oracle."""
+
+    def __init__(self, task, num_envs, device, env_id_base, seed=0, autoreset_mode="next_step"):
+        self.o = VecOracle(task, num_envs, store_mode="float32", seed=seed, env_id_base=env_id_base,
+                           autoreset={"next_step": refvec.AUTORESET_NEXT_STEP,
+                                      "disabled": refvec.AUTORESET_DISABLED}[autoreset_mode])
+        self.obs_dim = self.o.obs_dim
+        self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)
+        self.single_action_space = Box(-1, 1, (4,), np.float32)
+
+    def reset(self, seed=None, options=None):
+        return torch.from_numpy(self.o.reset(seed=seed)), {}
+
+    def step(self, actions):
+        obs, r, term, trunc = self.o.step(actions.numpy().astype(np.float64))
+        return (torch.from_numpy(obs), torch.from_numpy(r.astype(np.float32)),
+                torch.from_numpy(term), torch.from_numpy(trunc), {})
+
+    def close(self):
+        pass
+
+
+def _actions():
+    rng = np.random.default_rng(31)
+    return rng.uniform(-1, 1, (STEPS, TOTAL, 4)).astype(np.float32)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        env = ShardedCopterVecEnv("lander3d", TOTAL, gather="all", seed=77,
+                                  local_env_factory=OracleLocalEnv)
+        assert (env.env_id_base, env.n_local) == (rank * TOTAL // world, TOTAL // world)
+        acts = torch.from_numpy(_actions())
+        obs, _ = env.reset()
+        rows = [obs.numpy().copy()]
+        for t in range(STEPS):
+            # even steps: pass the global action batch, odd steps: the local rows only
+            a = acts[t] if t % 2 == 0 else acts[t][env.local_slice()]
+            obs, r, term, trunc, _ = env.step(a)
+            assert obs.shape == (TOTAL, 10) and r.shape == (TOTAL,) and term.dtype == torch.bool
+            rows.append(np.concatenate([obs.numpy().ravel(), r.numpy(), term.numpy(), trunc.numpy()]))
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([x.ravel() for x in rows]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_sharding_matches_unsharded_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = VecOracle("lander3d", TOTAL, store_mode="float32", seed=77,
+                    autoreset=refvec.AUTORESET_NEXT_STEP)
+    rows = [ref.reset()]
+    acts = _actions()
+    ends = 0
+    for t in range(STEPS):
+        obs, r, term, trunc = ref.step(acts[t].astype(np.float64))
+        ends += int(term.sum())
+        rows.append(np.concatenate([obs.ravel(), r.astype(np.float32), term, trunc]))
+    want = np.concatenate([x.ravel() for x in rows])
+    assert ends > TOTAL     # auto-resets (Philox keyed by global env id) happened on both shards
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank))
+        assert np.array_equal(got, want), rank     # every rank holds the same, correct concatenation
+
+
+def test_shard_bounds():
+    assert shard_bounds(524288, 8, 3) == (3 * 65536, 65536)
+    assert shard_bounds(10, 1, 0) == (0, 10)
+    with pytest.raises(ValueError):
+        shard_bounds(10, 4, 0)
