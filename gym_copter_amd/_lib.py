@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcopterstep.so")
+# COPTERSTEP_LIB selects a diagnostic build of the same ABI (e.g. the stamp build); default = product
+LIB_PATH = os.environ.get("COPTERSTEP_LIB", os.path.join(_HERE, "libcopterstep.so"))
 
 ABI_VERSION = 1
 TASK_LANDER3D, TASK_HOVER3D = 0, 1

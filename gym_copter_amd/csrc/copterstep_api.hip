@@ -14,7 +14,7 @@
 struct cs_ctx {
   cs_config cfg;
   cs::DevState st;
-  size_t word;  // bytes per stored state word
+  cs::Layout layout;
 };
 
 namespace {
@@ -58,7 +58,7 @@ cs::DevConst make_const(const cs_ctx* ctx) {
   c.c_dthe = (g.Iz - g.Ix) / g.Iy;
   c.c_dpsi = (g.Ix - g.Iy) / g.Iz;
   c.dt = 1.0 / (g.frames_per_second * (double)g.substeps);
-  c.kick = 2.0 * c.dt / g.M;
+  c.two_inv_M = 2.0 / g.M;
   c.land_vx = g.landing_vel_x;
   c.land_vy = g.landing_vel_y;
   c.land_ang = g.landing_angle;
@@ -96,19 +96,6 @@ cs::DevConst make_const(const cs_ctx* ctx) {
 int check_ctx(const cs_ctx* ctx) {
   if (ctx == nullptr) return fail(CS_ERR_ARG, "null context");
   return CS_OK;
-}
-
-void free_state(cs_ctx* ctx) {
-  cs::DevState& s = ctx->st;
-  if (s.x) (void)hipFree(s.x);
-  if (s.guard) (void)hipFree(s.guard);
-  if (s.status) (void)hipFree(s.status);
-  if (s.steps) (void)hipFree(s.steps);
-  if (s.prev_shaping) (void)hipFree(s.prev_shaping);
-  if (s.force) (void)hipFree(s.force);
-  if (s.ep_return) (void)hipFree(s.ep_return);
-  if (s.episode) (void)hipFree(s.episode);
-  std::memset(&s, 0, sizeof s);
 }
 
 }  // namespace
@@ -180,11 +167,13 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
     return fail(CS_ERR_ARG, "cs_create: unknown state_mode");
   if (cfg->autoreset < CS_AUTORESET_DISABLED || cfg->autoreset > CS_AUTORESET_SAME_STEP)
     return fail(CS_ERR_ARG, "cs_create: unknown autoreset mode");
-  if (cfg->num_envs < 1 || cfg->num_envs > (int64_t)1 << 28)
-    return fail(CS_ERR_ARG, "cs_create: num_envs must be in [1, 2^28]");
+  if (cfg->num_envs < 1 || cfg->num_envs > (int64_t)1 << 25)
+    return fail(CS_ERR_ARG, "cs_create: num_envs must be in [1, 2^25] per context");
   if (cfg->env_id_base < 0) return fail(CS_ERR_ARG, "cs_create: env_id_base must be >= 0");
   if (cfg->substeps < 1 || cfg->substeps > 1000)
     return fail(CS_ERR_ARG, "cs_create: substeps must be in [1, 1000]");
+  if (cfg->max_steps < 1 || cfg->max_steps > (int32_t)cs::kMetaStepsMask - 2)
+    return fail(CS_ERR_ARG, "cs_create: max_steps must be in [1, 2^24 - 3]");
   if (!(cfg->frames_per_second > 0) || !(cfg->M > 0) || !(cfg->Ix > 0) || !(cfg->Iy > 0) ||
       !(cfg->Iz > 0))
     return fail(CS_ERR_ARG, "cs_create: frames_per_second, M, Ix, Iy, Iz must be positive");
@@ -202,45 +191,40 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   if (ctx == nullptr) return fail(CS_ERR_MEMORY, "cs_create: host allocation failed");
   std::memset(ctx, 0, sizeof *ctx);
   ctx->cfg = *cfg;
-  ctx->word = cfg->state_mode == CS_STATE_F64 ? sizeof(double) : sizeof(float);
+  ctx->layout = cs::make_layout(cfg->state_mode == CS_STATE_F64);
   cs::DevState& s = ctx->st;
-  s.n = cfg->num_envs;
-  s.stride = (cfg->num_envs + 63) / 64 * 64;  // component rows start 256-byte aligned
-  const size_t n = (size_t)s.n, stride = (size_t)s.stride;
-  bool ok = hipMalloc(&s.x, 12 * stride * ctx->word) == hipSuccess &&
-            hipMalloc((void**)&s.status, n) == hipSuccess &&
-            hipMalloc((void**)&s.steps, n * sizeof(int32_t)) == hipSuccess &&
-            hipMalloc(&s.prev_shaping, n * ctx->word) == hipSuccess &&
-            hipMalloc(&s.force, 3 * stride * ctx->word) == hipSuccess;
-  if (ok)
-    ok = hipMalloc((void**)&s.episode, n * sizeof(uint32_t)) == hipSuccess &&
-         hipMemset(s.episode, 0, n * sizeof(uint32_t)) == hipSuccess;
-  if (ok && cfg->episode_stats)
-    ok = hipMalloc((void**)&s.ep_return, n * sizeof(float)) == hipSuccess;
-  if (ok && cfg->state_mode == CS_STATE_F32G)
-    ok = hipMalloc((void**)&s.guard, 3 * stride * sizeof(uint32_t)) == hipSuccess &&
-         hipMemset(s.guard, 0, 3 * stride * sizeof(uint32_t)) == hipSuccess;
-  if (ok)
-    ok = hipMemset(s.x, 0, 12 * stride * ctx->word) == hipSuccess &&
-         hipMemset(s.status, CS_STATUS_LANDED, n) == hipSuccess &&
-         hipMemset(s.steps, 0, n * sizeof(int32_t)) == hipSuccess &&
-         hipMemset(s.prev_shaping, 0xFF, n * ctx->word) == hipSuccess &&  // all-ones = NaN
-         hipMemset(s.force, 0, 3 * stride * ctx->word) == hipSuccess &&
-         (!s.ep_return || hipMemset(s.ep_return, 0, n * sizeof(float)) == hipSuccess);
-  if (!ok) {
+  s.n = (uint32_t)cfg->num_envs;
+  s.ntiles = (s.n + 255u) / 256u * 4u;  // whole 256-thread workgroups: no lane is ever out of range
+  const size_t bytes = (size_t)s.ntiles * ctx->layout.tile_bytes;
+  // zero-filled tiles: steps 0, status CRASHED, nothing pending; cs_reset makes them live
+  if (hipMalloc((void**)&s.tiles, bytes) != hipSuccess ||
+      hipMemset(s.tiles, 0, bytes) != hipSuccess) {
     (void)hipGetLastError();
-    free_state(ctx);
+    if (s.tiles) (void)hipFree(s.tiles);
     delete ctx;
     return fail(CS_ERR_MEMORY, "cs_create: device allocation failed");
   }
+#ifdef CS_STAMPS
+  (void)hipMalloc((void**)&s.stamps, (size_t)s.ntiles * 8 * sizeof(unsigned long long));
+  (void)hipMemset(s.stamps, 0, (size_t)s.ntiles * 8 * sizeof(unsigned long long));
+#endif
   *out = ctx;
   return CS_OK;
 }
 
+#ifdef CS_STAMPS
+// diagnostic build only: copy the [ntiles][8] stamp buffer to the host
+extern "C" int cs_debug_read_stamps(cs_ctx* ctx, unsigned long long* host, void* stream) {
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  return hipMemcpy(host, ctx->st.stamps, (size_t)ctx->st.ntiles * 8 * sizeof(unsigned long long),
+                   hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
+}
+#endif
+
 int cs_destroy(cs_ctx* ctx) {
   if (ctx == nullptr) return CS_OK;
   (void)hipSetDevice(ctx->cfg.device);
-  free_state(ctx);
+  if (ctx->st.tiles) (void)hipFree(ctx->st.tiles);
   delete ctx;
   return CS_OK;
 }
@@ -318,7 +302,8 @@ int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
   return CS_OK;
 }
 
-// ---- host <-> device state exchange (not a hot path) ---------------------------------
+// ---- host <-> device state exchange (not a hot path): the whole tile slab is staged on
+// the host and (de)tiled there --------------------------------------------------------
 
 // CS_STATE_F32G host codec: same bit manipulation as the kernels (copterstep_kernels.hip).
 static double f32g_decode(float w, uint32_t guard) {
@@ -341,111 +326,85 @@ static void f32g_encode(double v, float* w, uint32_t* guard) {
   *w = (float)d;
 }
 
-static int x_to_host(const cs_ctx* ctx, double* host) {
-  const cs::DevState& s = ctx->st;
-  const size_t n = (size_t)s.n, stride = (size_t)s.stride;
-  std::vector<float> w(n);
-  std::vector<uint32_t> g(n);
-  for (size_t k = 0; k < 12; ++k) {
-    CS_HIP(hipMemcpy(w.data(), (const float*)s.x + k * stride, n * sizeof(float),
-                     hipMemcpyDeviceToHost));
-    CS_HIP(hipMemcpy(g.data(), s.guard + (k >> 2) * stride, n * sizeof(uint32_t),
-                     hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i)
-      host[k * n + i] = f32g_decode(w[i], (g[i] >> (8 * (k & 3))) & 0xFFu);
-  }
-  return CS_OK;
-}
+namespace {
 
-static int x_to_dev(const cs_ctx* ctx, const double* host) {
-  const cs::DevState& s = ctx->st;
-  const size_t n = (size_t)s.n, stride = (size_t)s.stride;
-  std::vector<float> w(n);
-  std::vector<uint32_t> g(3 * n, 0u);
-  for (size_t k = 0; k < 12; ++k) {
-    for (size_t i = 0; i < n; ++i) {
-      uint32_t gb;
-      f32g_encode(host[k * n + i], &w[i], &gb);
-      g[(k >> 2) * n + i] |= gb << (8 * (k & 3));
+struct HostTiles {
+  std::vector<char> buf;
+  const cs_ctx* ctx;
+  char* at(size_t i, uint32_t row, uint32_t word) {
+    return buf.data() + (i >> 6) * ctx->layout.tile_bytes + row + (i & 63) * word;
+  }
+  double get_word(size_t i, uint32_t row) {
+    if (ctx->layout.word == 8) {
+      double d;
+      std::memcpy(&d, at(i, row, 8), 8);
+      return d;
     }
-    CS_HIP(hipMemcpy((float*)s.x + k * stride, w.data(), n * sizeof(float),
-                     hipMemcpyHostToDevice));
+    float f;
+    std::memcpy(&f, at(i, row, 4), 4);
+    return (double)f;
   }
-  for (size_t j = 0; j < 3; ++j)
-    CS_HIP(hipMemcpy(s.guard + j * stride, g.data() + j * n, n * sizeof(uint32_t),
-                     hipMemcpyHostToDevice));
-  return CS_OK;
-}
-
-static int words_to_host(const cs_ctx* ctx, const void* dev, size_t rows, size_t stride,
-                         double* host) {
-  const size_t n = (size_t)ctx->st.n;
-  if (ctx->word == sizeof(double)) {
-    for (size_t r = 0; r < rows; ++r)
-      CS_HIP(hipMemcpy(host + r * n, (const double*)dev + r * stride, n * sizeof(double),
-                       hipMemcpyDeviceToHost));
-  } else {
-    std::vector<float> tmp(n);
-    for (size_t r = 0; r < rows; ++r) {
-      CS_HIP(hipMemcpy(tmp.data(), (const float*)dev + r * stride, n * sizeof(float),
-                       hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < n; ++i) host[r * n + i] = (double)tmp[i];
+  void set_word(size_t i, uint32_t row, double v) {
+    if (ctx->layout.word == 8) {
+      std::memcpy(at(i, row, 8), &v, 8);
+    } else {
+      const float f = (float)v;
+      std::memcpy(at(i, row, 4), &f, 4);
     }
   }
-  return CS_OK;
-}
-
-static int words_to_dev(const cs_ctx* ctx, void* dev, size_t rows, size_t stride,
-                        const double* host) {
-  const size_t n = (size_t)ctx->st.n;
-  if (ctx->word == sizeof(double)) {
-    for (size_t r = 0; r < rows; ++r)
-      CS_HIP(hipMemcpy((double*)dev + r * stride, host + r * n, n * sizeof(double),
-                       hipMemcpyHostToDevice));
-  } else {
-    std::vector<float> tmp(n);
-    for (size_t r = 0; r < rows; ++r) {
-      for (size_t i = 0; i < n; ++i) tmp[i] = (float)host[r * n + i];
-      CS_HIP(hipMemcpy((float*)dev + r * stride, tmp.data(), n * sizeof(float),
-                       hipMemcpyHostToDevice));
-    }
+  uint32_t get_u32(size_t i, uint32_t row) {
+    uint32_t u;
+    std::memcpy(&u, at(i, row, 4), 4);
+    return u;
   }
-  return CS_OK;
-}
+  void set_u32(size_t i, uint32_t row, uint32_t u) { std::memcpy(at(i, row, 4), &u, 4); }
+};
+
+}  // namespace
 
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
                  double* episode_return_host, uint32_t* episode_host, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (episode_return_host && !ctx->cfg.episode_stats)
+    return fail(CS_ERR_ARG, "cs_get_state: episode_stats is disabled");
   CS_HIP(hipSetDevice(ctx->cfg.device));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
-  const cs::DevState& s = ctx->st;
-  const size_t n = (size_t)s.n, stride = (size_t)s.stride;
-  int rc;
-  if (x_host && (rc = s.guard ? x_to_host(ctx, x_host) : words_to_host(ctx, s.x, 12, stride, x_host)))
-    return rc;
-  if (prev_shaping_host && (rc = words_to_host(ctx, s.prev_shaping, 1, n, prev_shaping_host)))
-    return rc;
-  if (force_xyz_host && (rc = words_to_host(ctx, s.force, 3, stride, force_xyz_host))) return rc;
-  if (status_host || flags_host) {
-    std::vector<uint8_t> sb(n);
-    CS_HIP(hipMemcpy(sb.data(), s.status, n, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) {
-      if (status_host) status_host[i] = sb[i] & cs::kStatusMask;
-      if (flags_host)
-        flags_host[i] = (uint8_t)(((sb[i] & cs::kFlagPerturbPending) ? 1 : 0) |
-                                  ((sb[i] & cs::kFlagResetPending) ? 2 : 0));
-    }
+  const cs::Layout& L = ctx->layout;
+  const size_t n = ctx->st.n;
+  HostTiles h;
+  h.ctx = ctx;
+  try {
+    h.buf.resize((size_t)ctx->st.ntiles * L.tile_bytes);
+  } catch (...) {
+    return fail(CS_ERR_MEMORY, "cs_get_state: host staging allocation failed");
   }
-  if (steps_host)
-    CS_HIP(hipMemcpy(steps_host, s.steps, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (episode_host)
-    CS_HIP(hipMemcpy(episode_host, s.episode, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (episode_return_host) {
-    if (!s.ep_return) return fail(CS_ERR_ARG, "cs_get_state: episode_stats is disabled");
-    std::vector<float> tmp(n);
-    CS_HIP(hipMemcpy(tmp.data(), s.ep_return, n * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) episode_return_host[i] = (double)tmp[i];
+  CS_HIP(hipMemcpy(h.buf.data(), ctx->st.tiles, h.buf.size(), hipMemcpyDeviceToHost));
+  const bool guard = ctx->cfg.state_mode == CS_STATE_F32G;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t meta = h.get_u32(i, L.meta);
+    if (x_host) {
+      for (int k = 0; k < 12; ++k) {
+        double v = h.get_word(i, L.x(k));
+        if (guard)
+          v = f32g_decode((float)v, (h.get_u32(i, L.g(k >> 2)) >> (8 * (k & 3))) & 0xFFu);
+        x_host[(size_t)k * n + i] = v;
+      }
+    }
+    if (status_host) status_host[i] = (uint8_t)((meta >> cs::kMetaStatusShift) & 3u);
+    if (steps_host) steps_host[i] = (int32_t)(meta & cs::kMetaStepsMask);
+    if (flags_host)
+      flags_host[i] = (uint8_t)(((meta & cs::kMetaPerturbPending) ? 1 : 0) |
+                                ((meta & cs::kMetaResetPending) ? 2 : 0));
+    if (prev_shaping_host) prev_shaping_host[i] = h.get_word(i, L.ps);
+    if (force_xyz_host)
+      for (int j = 0; j < 3; ++j) force_xyz_host[(size_t)j * n + i] = h.get_word(i, L.f(j));
+    if (episode_host) episode_host[i] = h.get_u32(i, L.epi);
+    if (episode_return_host) {
+      float f;
+      std::memcpy(&f, h.at(i, L.ret, 4), 4);
+      episode_return_host[i] = (double)f;
+    }
   }
   return CS_OK;
 }
@@ -455,42 +414,64 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
                  const double* force_xyz_host, const uint8_t* flags_host,
                  const double* episode_return_host, const uint32_t* episode_host, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (episode_return_host && !ctx->cfg.episode_stats)
+    return fail(CS_ERR_ARG, "cs_set_state: episode_stats is disabled");
   CS_HIP(hipSetDevice(ctx->cfg.device));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
-  const cs::DevState& s = ctx->st;
-  const size_t n = (size_t)s.n, stride = (size_t)s.stride;
-  int rc;
-  if (x_host && (rc = s.guard ? x_to_dev(ctx, x_host) : words_to_dev(ctx, s.x, 12, stride, x_host)))
-    return rc;
-  if (prev_shaping_host && (rc = words_to_dev(ctx, s.prev_shaping, 1, n, prev_shaping_host)))
-    return rc;
-  if (force_xyz_host && (rc = words_to_dev(ctx, s.force, 3, stride, force_xyz_host))) return rc;
-  if (status_host || flags_host) {
-    std::vector<uint8_t> sb(n);
-    CS_HIP(hipMemcpy(sb.data(), s.status, n, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) {
-      uint8_t st = sb[i] & cs::kStatusMask, fl = sb[i] & (uint8_t)~cs::kStatusMask;
-      if (status_host) {
-        if (status_host[i] > 3) return fail(CS_ERR_ARG, "cs_set_state: status out of range");
-        st = status_host[i];
+  const cs::Layout& L = ctx->layout;
+  const size_t n = ctx->st.n;
+  HostTiles h;
+  h.ctx = ctx;
+  try {
+    h.buf.resize((size_t)ctx->st.ntiles * L.tile_bytes);
+  } catch (...) {
+    return fail(CS_ERR_MEMORY, "cs_set_state: host staging allocation failed");
+  }
+  CS_HIP(hipMemcpy(h.buf.data(), ctx->st.tiles, h.buf.size(), hipMemcpyDeviceToHost));
+  const bool guard = ctx->cfg.state_mode == CS_STATE_F32G;
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t meta = h.get_u32(i, L.meta);
+    if (x_host) {
+      uint32_t gw[3] = {0, 0, 0};
+      for (int k = 0; k < 12; ++k) {
+        const double v = x_host[(size_t)k * n + i];
+        if (guard) {
+          float w;
+          uint32_t gb;
+          f32g_encode(v, &w, &gb);
+          std::memcpy(h.at(i, L.x(k), 4), &w, 4);
+          gw[k >> 2] |= gb << (8 * (k & 3));
+        } else {
+          h.set_word(i, L.x(k), v);
+        }
       }
-      if (flags_host)
-        fl = (uint8_t)(((flags_host[i] & 1) ? cs::kFlagPerturbPending : 0) |
-                       ((flags_host[i] & 2) ? cs::kFlagResetPending : 0));
-      sb[i] = st | fl;
+      if (guard)
+        for (int j = 0; j < 3; ++j) h.set_u32(i, L.g(j), gw[j]);
     }
-    CS_HIP(hipMemcpy(s.status, sb.data(), n, hipMemcpyHostToDevice));
+    if (status_host) {
+      if (status_host[i] > 3) return fail(CS_ERR_ARG, "cs_set_state: status out of range");
+      meta = (meta & ~(3u << cs::kMetaStatusShift)) | ((uint32_t)status_host[i] << cs::kMetaStatusShift);
+    }
+    if (steps_host) {
+      if (steps_host[i] < 0 || steps_host[i] > (int32_t)cs::kMetaStepsMask)
+        return fail(CS_ERR_ARG, "cs_set_state: steps out of range");
+      meta = (meta & ~cs::kMetaStepsMask) | (uint32_t)steps_host[i];
+    }
+    if (flags_host)
+      meta = (meta & ~(cs::kMetaPerturbPending | cs::kMetaResetPending)) |
+             ((flags_host[i] & 1) ? cs::kMetaPerturbPending : 0u) |
+             ((flags_host[i] & 2) ? cs::kMetaResetPending : 0u);
+    h.set_u32(i, L.meta, meta);
+    if (prev_shaping_host) h.set_word(i, L.ps, prev_shaping_host[i]);
+    if (force_xyz_host)
+      for (int j = 0; j < 3; ++j) h.set_word(i, L.f(j), force_xyz_host[(size_t)j * n + i]);
+    if (episode_host) h.set_u32(i, L.epi, episode_host[i]);
+    if (episode_return_host) {
+      const float f = (float)episode_return_host[i];
+      std::memcpy(h.at(i, L.ret, 4), &f, 4);
+    }
   }
-  if (steps_host)
-    CS_HIP(hipMemcpy(s.steps, steps_host, n * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (episode_host)
-    CS_HIP(hipMemcpy(s.episode, episode_host, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-  if (episode_return_host) {
-    if (!s.ep_return) return fail(CS_ERR_ARG, "cs_set_state: episode_stats is disabled");
-    std::vector<float> tmp(n);
-    for (size_t i = 0; i < n; ++i) tmp[i] = (float)episode_return_host[i];
-    CS_HIP(hipMemcpy(s.ep_return, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
-  }
+  CS_HIP(hipMemcpy(ctx->st.tiles, h.buf.data(), h.buf.size(), hipMemcpyHostToDevice));
   return CS_OK;
 }
 

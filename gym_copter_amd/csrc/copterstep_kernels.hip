@@ -1,7 +1,7 @@
 // copterstep_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for the
-// gym-copter rigid-body hot path.  One thread = one environment, 64 environments per
-// wavefront, struct-of-arrays state in HBM (every state load/store is one coalesced
-// dword per lane), the whole of _Task.step() fused into ONE kernel:
+// gym-copter rigid-body hot path.  One thread = one environment, one wavefront = one
+// 64-env tile of the wavefront-tiled struct-of-arrays state (copterstep_internal.h), the
+// whole of _Task.step() fused into ONE kernel:
 //
 //   action clip -> motor model -> body-Z->NED rotation -> flight-status machine ->
 //   forward-Euler integrate (x substeps) -> reward / termination -> (auto-reset with a
@@ -26,17 +26,48 @@
 namespace cs {
 namespace {
 
+// Diagnostic build only (make stamps): per-wavefront shader-clock stamps at phase
+// boundaries, written to a side buffer that nothing else reads.  Never defined in the
+// product library.
+#ifdef CS_STAMPS
+#define CS_STAMP(slot)                                                              \
+  do {                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    unsigned long long t_;                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    if (lane == 0 && s.stamps) s.stamps[(size_t)(i >> 6) * 8 + (slot)] = t_;        \
+  } while (0)
+#else
+#define CS_STAMP(slot) ((void)0)
+#endif
+
 constexpr int kBlock = 256;  // 4 wavefronts; one block per CU covers 65 536 envs exactly
 constexpr int kWave = 64;
 
 template <int MODE>
-struct WordOf {
-  using type = float;
+struct ModeOf {
+  using T = float;
+  static constexpr Layout L = make_layout(false);
 };
 template <>
-struct WordOf<CS_STATE_F64> {
-  using type = double;
+struct ModeOf<CS_STATE_F64> {
+  using T = double;
+  static constexpr Layout L = make_layout(true);
 };
+
+// Row access: `p` is the lane's address inside its tile, biased by kBias so that every
+// row offset fits the signed 13-bit instruction immediate of global_load/global_store.
+constexpr int kBias = 4096;
+
+template <class U>
+__device__ __forceinline__ U ld(const char* p, uint32_t row) {
+  return *reinterpret_cast<const U*>(p + ((int)row - kBias));
+}
+template <class U>
+__device__ __forceinline__ void st(char* p, uint32_t row, U v) {
+  *reinterpret_cast<U*>(p + ((int)row - kBias)) = v;
+}
 
 // ---------------------------------------------------------------------------------
 // counter-based RNG for the reset perturbation
@@ -65,17 +96,19 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // so it is invariant to batch size, sharding, launch history and hipGraph replay.
 // u*2F and the subtraction are kept un-fused so the CPU oracle reproduces the value
 // bit-for-bit.
-__device__ __forceinline__ void draw_force(const DevConst& c, uint32_t id_lo, uint32_t id_hi,
-                                           uint32_t episode, double (&f)[3]) {
+__device__ __forceinline__ void draw_force(const DevConst& c, uint32_t i, uint32_t episode,
+                                           double (&f)[3]) {
+  const uint32_t id_lo = c.id_lo + i;
+  const uint32_t id_hi = c.id_hi + (id_lo < c.id_lo ? 1u : 0u);
   uint32_t r[3];
   philox4x32_10(id_lo, id_hi, episode, 0u, c.seed_lo, c.seed_hi, r);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const double u = (double)(r[i] >> 8) * 0x1.0p-24;
+  for (int k = 0; k < 3; ++k) {
+    const double u = (double)(r[k] >> 8) * 0x1.0p-24;
     {
 #pragma clang fp contract(off)
       const double scaled = u * (2.0 * c.force_mag);
-      f[i] = scaled - c.force_mag;
+      f[k] = scaled - c.force_mag;
     }
   }
 }
@@ -87,18 +120,21 @@ __device__ __forceinline__ void draw_force(const DevConst& c, uint32_t id_lo, ui
 // ---------------------------------------------------------------------------------
 template <int MODE>
 struct Stored {
-  typename WordOf<MODE>::type word;  // what goes to the state array
-  uint32_t guard;                    // CS_STATE_F32G: next 8 mantissa bits
-  double value;                      // exact value of (word, guard)
+  typename ModeOf<MODE>::T word;  // what goes to the state row
+  uint32_t guard;                 // CS_STATE_F32G: next 8 mantissa bits
+  double value;                   // exact value of (word, guard)
 };
 
 template <int MODE>
-__device__ __forceinline__ double decode_word(typename WordOf<MODE>::type w, uint32_t guard) {
+__device__ __forceinline__ double decode_word(typename ModeOf<MODE>::T w, uint32_t gword, int k) {
   if constexpr (MODE == CS_STATE_F32G) {
     // float32 word = value truncated to 24 significant bits; the guard byte holds
-    // significant bits 25..32, i.e. bits 28..21 of the float64 mantissa.
+    // significant bits 25..32, i.e. bits 28..21 of the float64 mantissa.  Byte k&3 of the
+    // packed guard word is moved to bits 28..21 with one shift and one and-or.
+    const int sh = 21 - 8 * (k & 3);
+    const uint32_t moved = sh >= 0 ? (gword << sh) : (gword >> -sh);
     unsigned long long b = (unsigned long long)__double_as_longlong((double)w);
-    b |= (unsigned long long)guard << 21;
+    b |= (unsigned long long)(moved & 0x1FE00000u);
     return __longlong_as_double((long long)b);
   } else {
     return (double)w;
@@ -127,22 +163,7 @@ __device__ __forceinline__ Stored<MODE> encode_word(double v) {
   return o;
 }
 
-// float32 observation of a stored component: round-to-nearest of the stored value
-// (for F32G: bump the truncated word by one ulp when the guard byte is >= 1/2 ulp).
-template <int MODE>
-__device__ __forceinline__ float observe_word(typename WordOf<MODE>::type w, uint32_t guard) {
-  if constexpr (MODE == CS_STATE_F32G) {
-    return __uint_as_float(__float_as_uint(w) + (guard >> 7));
-  } else {
-    return (float)w;
-  }
-}
-
 __device__ __forceinline__ float clip01(float a) { return a < 0.f ? 0.f : (a > 1.f ? 1.f : a); }
-
-__device__ __forceinline__ uint32_t byte_of(const uint32_t (&w)[3], int k) {
-  return (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-}
 
 // ---------------------------------------------------------------------------------
 // float64 sin/cos and sqrt, sized for this kernel (no library slow paths, no scratch)
@@ -219,76 +240,75 @@ __device__ __forceinline__ Wrench motor_model(const DevConst& c, float a0, float
   return w;
 }
 
-// One Dynamics.setMotors() (dynamics/__init__.py:134-197) on the register-resident
-// state.  fs = flight status.  Returns what the call did, because the pending reset
-// perturbation (which upstream adds to the odd derivative slots twice) is applied by the
-// caller: it only ever enters the first call that integrates, survives a ground-contact
-// freeze, and is dropped by any other call.
 enum { kCallOther = 0, kCallIntegrated = 1, kCallFroze = 2 };
 
+// One Dynamics.setMotors() (dynamics/__init__.py:134-197) on the register-resident
+// state, written branch-free: every lane evaluates the derivative, and lanes that do
+// not integrate (grounded, crashed, ground contact) use dt = 0.  fs = flight status;
+// (px,py,pz) = 2*force/M, the pending reset perturbation in its doubled form (upstream
+// adds it inside the derivative, :263-271, and again at :183), zero when none is
+// pending.  Returns what the call did.
 __device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, double (&x)[12],
-                                            int& fs) {
+                                            int& fs, double px, double py, double pz) {
   double sph, cph, sth, cth, sps, cps;
   sincos_f64(x[6], sph, cph);
   sincos_f64(x[8], sth, cth);
   sincos_f64(x[10], sps, cps);
-  const double ax = w.bz * (sph * sps + cph * cps * sth);
-  const double ay = w.bz * (cph * sps * sth - cps * sph);
+  const double ax = w.bz * fma(cph * cps, sth, sph * sps);
+  const double ay = w.bz * fma(cph * sps, sth, -(cps * sph));
   const double netz = fma(w.bz, cph * cth, c.G);
 
   if (fs == CS_STATUS_LANDED && netz < 0.0) fs = CS_STATUS_AIRBORNE;
+  const bool leveling = fs == CS_STATUS_LEVELING;
+  const bool air = fs == CS_STATUS_AIRBORNE;
+  // ground contact: freeze (no integrate, perturbation kept).  Upstream tests dz against
+  // LANDING_VEL_Y and |dy| against LANDING_VEL_X (:166-171).
+  const bool contact = air && x[4] > 0.0 && x[5] > 0.0;
+  const bool hard = x[5] > c.land_vy || fabs(x[3]) > c.land_vx || fabs(x[6]) > c.land_ang;
+  const bool integ = air && !contact;
 
-  int what = kCallOther;
-  if (fs == CS_STATUS_LEVELING) {
-    x[6] = 0.0;
-    x[8] = 0.0;
-    fs = CS_STATUS_LANDED;
-  } else if (fs == CS_STATUS_AIRBORNE) {
-    if (x[4] > 0.0 && x[5] > 0.0) {
-      // ground contact: freeze (no integrate, perturbation kept).  Upstream tests
-      // dz against LANDING_VEL_Y and |dy| against LANDING_VEL_X (:166-171).
-      const bool hard = x[5] > c.land_vy || fabs(x[3]) > c.land_vx || fabs(x[6]) > c.land_ang;
-      fs = hard ? CS_STATUS_CRASHED : CS_STATUS_LEVELING;
-      what = kCallFroze;
-    } else {
-      const double dphi = x[7], dthe = x[9], dpsi = x[11];
-      const double d7 = fma(dpsi * dthe, c.c_dphi, w.aphi);
-      const double d9 = -fma(dpsi * dphi, c.c_dthe, w.athe);
-      const double d11 = fma(dthe * dphi, c.c_dpsi, w.apsi);
-      const double dt = c.dt;
-      x[0] = fma(dt, x[1], x[0]);
-      x[2] = fma(dt, x[3], x[2]);
-      x[4] = fma(dt, x[5], x[4]);
-      x[6] = fma(dt, dphi, x[6]);
-      x[8] = fma(dt, dthe, x[8]);
-      x[10] = fma(dt, dpsi, x[10]);
-      x[1] = fma(dt, ax, x[1]);
-      x[3] = fma(dt, ay, x[3]);
-      x[5] = fma(dt, netz, x[5]);
-      x[7] = fma(dt, d7, x[7]);
-      x[9] = fma(dt, d9, x[9]);
-      x[11] = fma(dt, d11, x[11]);
-      what = kCallIntegrated;
-    }
-  }
-  return what;
+  const double dt = integ ? c.dt : 0.0;
+  const double dphi = x[7], dthe = x[9], dpsi = x[11];
+  const double d7 = fma(dpsi * dthe, c.c_dphi, w.aphi);
+  const double d9 = -fma(dpsi * dphi, c.c_dthe, w.athe);
+  const double d11 = fma(dthe * dphi, c.c_dpsi, w.apsi);
+  x[0] = fma(dt, x[1], x[0]);
+  x[2] = fma(dt, x[3], x[2]);
+  x[4] = fma(dt, x[5], x[4]);
+  x[6] = leveling ? 0.0 : fma(dt, dphi, x[6]);
+  x[8] = leveling ? 0.0 : fma(dt, dthe, x[8]);
+  x[10] = fma(dt, dpsi, x[10]);
+  x[1] = fma(dt, ax + px, x[1]);
+  x[3] = fma(dt, ay + py, x[3]);
+  x[5] = fma(dt, netz + pz, x[5]);
+  x[7] = fma(dt, d7, x[7]);
+  x[9] = fma(dt, d9, x[9]);
+  x[11] = fma(dt, d11, x[11]);
+
+  fs = leveling ? CS_STATUS_LANDED
+                : (contact ? (hard ? CS_STATUS_CRASHED : CS_STATUS_LEVELING) : fs);
+  return integ ? kCallIntegrated : (contact ? kCallFroze : kCallOther);
 }
 
-// `nsub` x Dynamics.setMotors with one wrench.  pend = a reset perturbation is waiting;
-// k2[] = 2 * dt * force / M, i.e. the velocity kick of its double application (:263-271
-// inside the derivative plus :183).  It is consumed by the first call that does not
-// freeze on ground contact, and only an integrating call applies it.
+// `nsub` x Dynamics.setMotors with one wrench.  The pending perturbation (pend, force
+// f[] in newtons) can only enter the FIRST call: a call that freezes on ground contact
+// keeps it, but the status it leaves (CRASHED / LEVELING) makes the next call drop it.
 __device__ __forceinline__ void physics_substeps(const DevConst& c, const Wrench& w,
                                                  double (&x)[12], int& fs, bool& pend,
-                                                 const double (&k2)[3]) {
+                                                 const double (&f)[3]) {
+  double px = pend ? f[0] * c.two_inv_M : 0.0;
+  double py = pend ? f[1] * c.two_inv_M : 0.0;
+  double pz = pend ? f[2] * c.two_inv_M : 0.0;
+#pragma clang loop unroll(disable)
   for (int sub = 0; sub < c.nsub; ++sub) {
-    const int what = physics_call(c, w, x, fs);
-    if (pend && what == kCallIntegrated) {
-      x[1] += k2[0];
-      x[3] += k2[1];
-      x[5] += k2[2];
-    }
-    if (what != kCallFroze) pend = false;
+    const int what = physics_call(c, w, x, fs, px, py, pz);
+    // a call that froze keeps the perturbation (upstream's early return); it is inert
+    // there (dt = 0) and the next call, which cannot integrate either, drops it
+    const bool keep = pend && what == kCallFroze;
+    pend = keep;
+    px = keep ? px : 0.0;
+    py = keep ? py : 0.0;
+    pz = keep ? pz : 0.0;
   }
 }
 
@@ -341,61 +361,65 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
 template <int TASK, int MODE>
 __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const DevState s,
                                                       const cs_step_io io) {
-  using T = typename WordOf<MODE>::type;
+  using T = typename ModeOf<MODE>::T;
+  constexpr Layout L = ModeOf<MODE>::L;
   constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
-  const uint32_t n = (uint32_t)s.n, stride = (uint32_t)s.stride;
+  const uint32_t n = s.n;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t env0 = i - lane;
-  const bool valid = i < n;
-  const uint32_t ii = valid ? i : 0u;  // out-of-range lanes shadow env 0, never store
+  const bool valid = i < n;  // lanes past the end run on zeroed padding and never write out
+  // this lane's addresses inside its tile: 4-byte rows and word rows (same in float32 modes)
+  const uint32_t tile_off = (i >> 6) * L.tile_bytes + kBias;
+  char* const p4 = s.tiles + (tile_off + (uint32_t)lane * 4u);
+  char* const pw = s.tiles + (tile_off + (uint32_t)lane * L.word);
 
-  T* __restrict__ X = static_cast<T*>(s.x);
-  T* __restrict__ F = static_cast<T*>(s.force);
-  T* __restrict__ PS = static_cast<T*>(s.prev_shaping);
-  uint32_t* __restrict__ GD = s.guard;
-
+  CS_STAMP(0);
   // ---- loads, in order of first use ----
-  const uint8_t sb = s.status[ii];
-  const float4 act = reinterpret_cast<const float4*>(io.actions_dev)[ii];
+  const uint32_t meta = ld<uint32_t>(p4, L.meta);
+  const float4 act = reinterpret_cast<const float4*>(io.actions_dev)[valid ? i : 0u];
   T raw[12];
   uint32_t g[3] = {0, 0, 0};
-  raw[6] = X[6 * stride + ii];
-  raw[8] = X[8 * stride + ii];
-  raw[10] = X[10 * stride + ii];
+  raw[6] = ld<T>(pw, L.x(6));
+  raw[8] = ld<T>(pw, L.x(8));
+  raw[10] = ld<T>(pw, L.x(10));
   if constexpr (MODE == CS_STATE_F32G) {
-    g[1] = GD[1 * stride + ii];
-    g[2] = GD[2 * stride + ii];
-    g[0] = GD[0 * stride + ii];
+    g[1] = ld<uint32_t>(p4, L.g(1));
+    g[2] = ld<uint32_t>(p4, L.g(2));
+    g[0] = ld<uint32_t>(p4, L.g(0));
   }
 #pragma unroll
   for (int k = 0; k < 12; ++k)
-    if (k != 6 && k != 8 && k != 10) raw[k] = X[k * stride + ii];
-  int steps = s.steps[ii];
+    if (k != 6 && k != 8 && k != 10) raw[k] = ld<T>(pw, L.x(k));
   double prev_sh = 0.0;
-  if constexpr (TASK == CS_TASK_LANDER3D) prev_sh = (double)PS[ii];
+  if constexpr (TASK == CS_TASK_LANDER3D) prev_sh = (double)ld<T>(pw, L.ps);
   float ep_ret = 0.f;
-  if (c.stats) ep_ret = s.ep_return[ii];
+  if (c.stats) ep_ret = ld<float>(p4, L.ret);
 
-  // second-round loads, issued as soon as the status byte is back and consumed late:
-  // the pending reset perturbation and (for lanes that will reset) the episode number
-  int fs = sb & kStatusMask;
-  bool pend = (sb & kFlagPerturbPending) != 0;
-  const bool resetting = c.autoreset == CS_AUTORESET_NEXT_STEP && (sb & kFlagResetPending) != 0;
-  T fraw[3] = {(T)0, (T)0, (T)0};
+  // second-round loads, issued as soon as the meta word is back and consumed late:
+  // the pending reset perturbation and (when auto-reset is on) the episode number
+  int steps = (int)(meta & kMetaStepsMask);
+  int fs = (int)((meta >> kMetaStatusShift) & 3u);
+  bool pend = (meta & kMetaPerturbPending) != 0;
+  const bool resetting = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
+  double f[3] = {0.0, 0.0, 0.0};
   if (pend) {
-    fraw[0] = F[0 * stride + ii];
-    fraw[1] = F[1 * stride + ii];
-    fraw[2] = F[2 * stride + ii];
+    f[0] = (double)ld<T>(pw, L.f(0));
+    f[1] = (double)ld<T>(pw, L.f(1));
+    f[2] = (double)ld<T>(pw, L.f(2));
   }
   uint32_t episode = 0;
-  if (c.autoreset != CS_AUTORESET_DISABLED) episode = s.episode[ii];
+  if (c.autoreset != CS_AUTORESET_DISABLED) episode = ld<uint32_t>(p4, L.epi);
 
   double x[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], byte_of(g, k));
+  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], g[k >> 2], k);
+#ifdef CS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  CS_STAMP(1);
 
   double reward = 0.0;
   bool term = false, trunc = false;
@@ -407,20 +431,22 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   if (!resetting && status0 != CS_STATUS_LANDED) {
     // np.clip(action, 0, 1), task.py:91 (comparisons, so a NaN action stays NaN as upstream)
     const Wrench w = motor_model(c, clip01(act.x), clip01(act.y), clip01(act.z), clip01(act.w));
-    const double k2[3] = {(double)fraw[0] * c.kick, (double)fraw[1] * c.kick,
-                          (double)fraw[2] * c.kick};
-    physics_substeps(c, w, x, fs, pend, k2);
+    physics_substeps(c, w, x, fs, pend, f);
   }
 
+  CS_STAMP(2);
   // ---- round to the stored word; everything below sees exactly what is stored ----
+  float row[OBS];
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const Stored<MODE> e = encode_word<MODE>(x[k]);
     xs[k] = e.word;
     gs[k >> 2] |= e.guard << (8 * (k & 3));
     x[k] = e.value;
+    if (k < OBS) row[k] = (float)e.value;  // float32 observation: round-to-nearest of the stored value
   }
 
+  CS_STAMP(3);
   // ---- reward / termination (task.py:104-130, lander.py:46-74) ----
   if (!resetting) {
     bool done = false;
@@ -450,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
     } else {
       done = done || limit;
     }
-    steps += 1;
+    steps = min(steps + 1, (int)kMetaStepsMask);
     term = done;
     ep_ret += (float)reward;
   }
@@ -474,9 +500,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   }
 
   // ---- observation of the finished state (SAME_STEP keeps it in final_obs) ----
-  float row[OBS];
-#pragma unroll
-  for (int k = 0; k < OBS; ++k) row[k] = observe_word<MODE>(xs[k], byte_of(gs, k));
   float* lds_wave = lds + (threadIdx.x - lane) * OBS;
   const bool same_step = c.autoreset == CS_AUTORESET_SAME_STEP;
   if (same_step && io.final_obs_dev != nullptr && fin && valid) {
@@ -485,12 +508,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
     for (int k = 0; k < OBS; ++k) dst[k] = row[k];
   }
 
+  CS_STAMP(4);
   // ---- masked reset (task.py:145-197): fresh state, Philox force, shaping, steps = 1 ----
   const bool do_reset = resetting || (same_step && fin);
   const bool reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && fin;
   if (do_reset) {
-    double f[3];
-    draw_force(c, c.id_lo + ii, c.id_hi + ((c.id_lo + ii) < c.id_lo ? 1u : 0u), episode, f);
+    double fr[3];
+    draw_force(c, i, episode, fr);
 #pragma unroll
     for (int k = 0; k < 12; ++k) xs[k] = (T)0;
     xs[4] = (T)c.z0;
@@ -502,31 +526,36 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
     steps = 1;
     ep_ret = 0.f;
     prev_sh = c.reset_shaping;
-    if (valid) {
-      F[0 * stride + i] = (T)f[0];
-      F[1 * stride + i] = (T)f[1];
-      F[2 * stride + i] = (T)f[2];
-      s.episode[i] = episode + 1;
-    }
+    st<T>(pw, L.f(0), (T)fr[0]);
+    st<T>(pw, L.f(1), (T)fr[1]);
+    st<T>(pw, L.f(2), (T)fr[2]);
+    st<uint32_t>(p4, L.epi, episode + 1);
   }
 
+  CS_STAMP(5);
   // ---- stores ----
+#pragma unroll
+  for (int k = 0; k < 12; ++k) st<T>(pw, L.x(k), xs[k]);
+  if constexpr (MODE == CS_STATE_F32G) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) st<uint32_t>(p4, L.g(j), gs[j]);
+  }
+  st<uint32_t>(p4, L.meta,
+               (uint32_t)steps | ((uint32_t)fs << kMetaStatusShift) |
+                   (pend ? kMetaPerturbPending : 0u) | (reset_pending ? kMetaResetPending : 0u));
+  if constexpr (TASK == CS_TASK_LANDER3D) st<T>(pw, L.ps, (T)prev_sh);
+  if (c.stats) st<float>(p4, L.ret, ep_ret);
   if (valid) {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) X[k * stride + i] = xs[k];
-    if constexpr (MODE == CS_STATE_F32G) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) GD[j * stride + i] = gs[j];
-    }
-    s.status[i] = (uint8_t)(fs | (pend ? kFlagPerturbPending : 0) | (reset_pending ? kFlagResetPending : 0));
-    s.steps[i] = steps;
-    if constexpr (TASK == CS_TASK_LANDER3D) PS[i] = (T)prev_sh;
-    if (c.stats) s.ep_return[i] = ep_ret;
     if (io.reward_dev) io.reward_dev[i] = (float)reward;
     if (io.terminated_dev) io.terminated_dev[i] = term ? 1 : 0;
     if (io.truncated_dev) io.truncated_dev[i] = trunc ? 1 : 0;
   }
   write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, n, valid, row);
+  CS_STAMP(6);
+#ifdef CS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  CS_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------
@@ -535,45 +564,48 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, const DevState s,
                                                             const float* __restrict__ motors) {
-  using T = typename WordOf<MODE>::type;
-  const uint32_t n = (uint32_t)s.n, stride = (uint32_t)s.stride;
+  using T = typename ModeOf<MODE>::T;
+  constexpr Layout L = ModeOf<MODE>::L;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  T* __restrict__ X = static_cast<T*>(s.x);
-  const T* __restrict__ F = static_cast<const T*>(s.force);
-  uint32_t* __restrict__ GD = s.guard;
+  if (i >= s.n) return;
+  const uint32_t lane = i & 63u;
+  const uint32_t tile_off = (i >> 6) * L.tile_bytes + kBias;
+  char* const p4 = s.tiles + (tile_off + lane * 4u);
+  char* const pw = s.tiles + (tile_off + lane * L.word);
   const float4 mv = reinterpret_cast<const float4*>(motors)[i];
-  const uint8_t sb = s.status[i];
+  const uint32_t meta = ld<uint32_t>(p4, L.meta);
   uint32_t g[3] = {0, 0, 0};
   if constexpr (MODE == CS_STATE_F32G) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) g[j] = GD[j * stride + i];
+    for (int j = 0; j < 3; ++j) g[j] = ld<uint32_t>(p4, L.g(j));
   }
   double x[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(X[k * stride + i], byte_of(g, k));
-  int fs = sb & kStatusMask;
-  bool pend = (sb & kFlagPerturbPending) != 0;
-  double k2[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(ld<T>(pw, L.x(k)), g[k >> 2], k);
+  int fs = (int)((meta >> kMetaStatusShift) & 3u);
+  bool pend = (meta & kMetaPerturbPending) != 0;
+  double f[3] = {0.0, 0.0, 0.0};
   if (pend) {
-    k2[0] = (double)F[0 * stride + i] * c.kick;
-    k2[1] = (double)F[1 * stride + i] * c.kick;
-    k2[2] = (double)F[2 * stride + i] * c.kick;
+    f[0] = (double)ld<T>(pw, L.f(0));
+    f[1] = (double)ld<T>(pw, L.f(1));
+    f[2] = (double)ld<T>(pw, L.f(2));
   }
   const Wrench w = motor_model(c, mv.x, mv.y, mv.z, mv.w);
-  physics_substeps(c, w, x, fs, pend, k2);
+  physics_substeps(c, w, x, fs, pend, f);
   uint32_t gs[3] = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const Stored<MODE> e = encode_word<MODE>(x[k]);
-    X[k * stride + i] = e.word;
+    st<T>(pw, L.x(k), e.word);
     gs[k >> 2] |= e.guard << (8 * (k & 3));
   }
   if constexpr (MODE == CS_STATE_F32G) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) GD[j * stride + i] = gs[j];
+    for (int j = 0; j < 3; ++j) st<uint32_t>(p4, L.g(j), gs[j]);
   }
-  s.status[i] = (uint8_t)(fs | (pend ? kFlagPerturbPending : 0) | (sb & kFlagResetPending));
+  st<uint32_t>(p4, L.meta,
+               (meta & ~((3u << kMetaStatusShift) | kMetaPerturbPending)) |
+                   ((uint32_t)fs << kMetaStatusShift) | (pend ? kMetaPerturbPending : 0u));
 }
 
 // ---------------------------------------------------------------------------------
@@ -584,52 +616,51 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
                                                        const uint8_t* __restrict__ mask,
                                                        const float* __restrict__ force_xyz,
                                                        float* __restrict__ obs) {
-  using T = typename WordOf<MODE>::type;
+  using T = typename ModeOf<MODE>::T;
+  constexpr Layout L = ModeOf<MODE>::L;
   constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
-  const uint32_t n = (uint32_t)s.n, stride = (uint32_t)s.stride;
+  const uint32_t n = s.n;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  T* __restrict__ X = static_cast<T*>(s.x);
-  T* __restrict__ F = static_cast<T*>(s.force);
-  T* __restrict__ PS = static_cast<T*>(s.prev_shaping);
+  const uint32_t lane = i & 63u;
+  const uint32_t tile_off = (i >> 6) * L.tile_bytes + kBias;
+  char* const p4 = s.tiles + (tile_off + lane * 4u);
+  char* const pw = s.tiles + (tile_off + lane * L.word);
   if (mask == nullptr || mask[i] != 0) {
     double f[3];
-    const uint32_t episode = s.episode[i];
+    const uint32_t episode = ld<uint32_t>(p4, L.epi);
     if (force_xyz != nullptr) {
       f[0] = (double)force_xyz[0 * (size_t)n + i];
       f[1] = (double)force_xyz[1 * (size_t)n + i];
       f[2] = (double)force_xyz[2 * (size_t)n + i];
     } else {
-      draw_force(c, c.id_lo + i, c.id_hi + ((c.id_lo + i) < c.id_lo ? 1u : 0u), episode, f);
+      draw_force(c, i, episode, f);
     }
 #pragma unroll
-    for (int k = 0; k < 12; ++k) X[k * stride + i] = (k == 4) ? (T)c.z0 : (T)0;
-    if constexpr (MODE == CS_STATE_F32G) {
+    for (int k = 0; k < 12; ++k) st<T>(pw, L.x(k), (k == 4) ? (T)c.z0 : (T)0);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) s.guard[j * stride + i] = 0u;
-    }
-    F[0 * stride + i] = (T)f[0];
-    F[1 * stride + i] = (T)f[1];
-    F[2 * stride + i] = (T)f[2];
-    s.episode[i] = episode + 1;
-    s.status[i] = (uint8_t)(c.status0 | kFlagPerturbPending);
-    s.steps[i] = 1;
-    PS[i] = (T)c.reset_shaping;  // NaN (= None) for Hover3D
-    if (c.stats) s.ep_return[i] = 0.f;
+    for (int j = 0; j < 3; ++j) st<uint32_t>(p4, L.g(j), 0u);
+    st<T>(pw, L.f(0), (T)f[0]);
+    st<T>(pw, L.f(1), (T)f[1]);
+    st<T>(pw, L.f(2), (T)f[2]);
+    st<uint32_t>(p4, L.epi, episode + 1);
+    st<uint32_t>(p4, L.meta, 1u | ((uint32_t)c.status0 << kMetaStatusShift) | kMetaPerturbPending);
+    st<T>(pw, L.ps, (T)c.reset_shaping);  // NaN (= None) for Hover3D
+    st<float>(p4, L.ret, 0.f);
   }
   if (obs != nullptr) {
     uint32_t g[3] = {0, 0, 0};
     if constexpr (MODE == CS_STATE_F32G) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) g[j] = s.guard[j * stride + i];
+      for (int j = 0; j < 3; ++j) g[j] = ld<uint32_t>(p4, L.g(j));
     }
 #pragma unroll
     for (int k = 0; k < OBS; ++k)
-      obs[(size_t)i * OBS + k] = observe_word<MODE>(X[k * stride + i], byte_of(g, k));
+      obs[(size_t)i * OBS + k] = (float)decode_word<MODE>(ld<T>(pw, L.x(k)), g[k >> 2], k);
   }
 }
 
-inline int grid_for(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+inline int grid_for(uint32_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
 

@@ -93,16 +93,6 @@ def guard_round(x64):
     return b.view(np.float64)
 
 
-def guard_observe(x64):
-    """float32 observation of guard-mode state: the truncated float32 word, bumped one ulp
-    when the guard byte is >= 128 (integer add on the float32 bit pattern)."""
-    b = np.ascontiguousarray(x64, dtype=np.float64).view(np.uint64)
-    guard = ((b >> np.uint64(21)) & np.uint64(0xFF)).astype(np.uint32)
-    with np.errstate(over="ignore", invalid="ignore"):
-        w = (b & np.uint64(~0x1FFFFFFF & _M64)).view(np.float64).astype(np.float32)
-    return (w.view(np.uint32) + (guard >> np.uint32(7))).view(np.float32)
-
-
 # mode -> (dtype of the float words: prev_shaping / force / x words, container dtype of x, rounding)
 STORE_MODES = {"float32": (np.float32, np.float64, "guard"),
                "float32_guard": (np.float32, np.float64, "guard"),
@@ -246,9 +236,9 @@ class VecOracle:
         return self.observe()
 
     def observe(self):
-        if self.rounding == "guard":
-            return np.ascontiguousarray(guard_observe(self.x[:self.obs_dim]).T)
-        return np.ascontiguousarray(self.x[:self.obs_dim].T.astype(np.float32))
+        # float32 observation = round-to-nearest-even of the stored value, in every mode
+        with np.errstate(over="ignore"):
+            return np.ascontiguousarray(self.x[:self.obs_dim].T.astype(np.float32))
 
     # ------------------------------------------------------------------ reward
     def _shaping(self, x):
