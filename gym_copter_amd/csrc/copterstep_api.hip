@@ -191,7 +191,7 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   if (ctx == nullptr) return fail(CS_ERR_MEMORY, "cs_create: host allocation failed");
   std::memset(ctx, 0, sizeof *ctx);
   ctx->cfg = *cfg;
-  ctx->layout = cs::make_layout(cfg->state_mode == CS_STATE_F64);
+  ctx->layout = cs::make_layout(cfg->state_mode);
   cs::DevState& s = ctx->st;
   s.n = (uint32_t)cfg->num_envs;
   s.ntiles = (s.n + 255u) / 256u * 4u;  // whole 256-thread workgroups: no lane is ever out of range
@@ -331,33 +331,33 @@ namespace {
 struct HostTiles {
   std::vector<char> buf;
   const cs_ctx* ctx;
-  char* at(size_t i, uint32_t row, uint32_t word) {
-    return buf.data() + (i >> 6) * ctx->layout.tile_bytes + row + (i & 63) * word;
+  char* at(size_t i, cs::Field f) {
+    return buf.data() + (i >> 6) * ctx->layout.tile_bytes + f.off + (i & 63) * f.stride;
   }
-  double get_word(size_t i, uint32_t row) {
+  double get_word(size_t i, cs::Field f) {
     if (ctx->layout.word == 8) {
       double d;
-      std::memcpy(&d, at(i, row, 8), 8);
+      std::memcpy(&d, at(i, f), 8);
       return d;
     }
-    float f;
-    std::memcpy(&f, at(i, row, 4), 4);
-    return (double)f;
+    float v;
+    std::memcpy(&v, at(i, f), 4);
+    return (double)v;
   }
-  void set_word(size_t i, uint32_t row, double v) {
+  void set_word(size_t i, cs::Field f, double v) {
     if (ctx->layout.word == 8) {
-      std::memcpy(at(i, row, 8), &v, 8);
+      std::memcpy(at(i, f), &v, 8);
     } else {
-      const float f = (float)v;
-      std::memcpy(at(i, row, 4), &f, 4);
+      const float w = (float)v;
+      std::memcpy(at(i, f), &w, 4);
     }
   }
-  uint32_t get_u32(size_t i, uint32_t row) {
+  uint32_t get_u32(size_t i, cs::Field f) {
     uint32_t u;
-    std::memcpy(&u, at(i, row, 4), 4);
+    std::memcpy(&u, at(i, f), 4);
     return u;
   }
-  void set_u32(size_t i, uint32_t row, uint32_t u) { std::memcpy(at(i, row, 4), &u, 4); }
+  void set_u32(size_t i, cs::Field f, uint32_t u) { std::memcpy(at(i, f), &u, 4); }
 };
 
 }  // namespace
@@ -382,7 +382,7 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
   CS_HIP(hipMemcpy(h.buf.data(), ctx->st.tiles, h.buf.size(), hipMemcpyDeviceToHost));
   const bool guard = ctx->cfg.state_mode == CS_STATE_F32G;
   for (size_t i = 0; i < n; ++i) {
-    const uint32_t meta = h.get_u32(i, L.meta);
+    const uint32_t meta = h.get_u32(i, L.meta());
     if (x_host) {
       for (int k = 0; k < 12; ++k) {
         double v = h.get_word(i, L.x(k));
@@ -396,13 +396,13 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
     if (flags_host)
       flags_host[i] = (uint8_t)(((meta & cs::kMetaPerturbPending) ? 1 : 0) |
                                 ((meta & cs::kMetaResetPending) ? 2 : 0));
-    if (prev_shaping_host) prev_shaping_host[i] = h.get_word(i, L.ps);
+    if (prev_shaping_host) prev_shaping_host[i] = h.get_word(i, L.prev());
     if (force_xyz_host)
       for (int j = 0; j < 3; ++j) force_xyz_host[(size_t)j * n + i] = h.get_word(i, L.f(j));
-    if (episode_host) episode_host[i] = h.get_u32(i, L.epi);
+    if (episode_host) episode_host[i] = h.get_u32(i, L.epi());
     if (episode_return_host) {
       float f;
-      std::memcpy(&f, h.at(i, L.ret, 4), 4);
+      std::memcpy(&f, h.at(i, L.ret_()), 4);
       episode_return_host[i] = (double)f;
     }
   }
@@ -430,7 +430,7 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
   CS_HIP(hipMemcpy(h.buf.data(), ctx->st.tiles, h.buf.size(), hipMemcpyDeviceToHost));
   const bool guard = ctx->cfg.state_mode == CS_STATE_F32G;
   for (size_t i = 0; i < n; ++i) {
-    uint32_t meta = h.get_u32(i, L.meta);
+    uint32_t meta = h.get_u32(i, L.meta());
     if (x_host) {
       uint32_t gw[3] = {0, 0, 0};
       for (int k = 0; k < 12; ++k) {
@@ -439,7 +439,7 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
           float w;
           uint32_t gb;
           f32g_encode(v, &w, &gb);
-          std::memcpy(h.at(i, L.x(k), 4), &w, 4);
+          std::memcpy(h.at(i, L.x(k)), &w, 4);
           gw[k >> 2] |= gb << (8 * (k & 3));
         } else {
           h.set_word(i, L.x(k), v);
@@ -461,14 +461,14 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
       meta = (meta & ~(cs::kMetaPerturbPending | cs::kMetaResetPending)) |
              ((flags_host[i] & 1) ? cs::kMetaPerturbPending : 0u) |
              ((flags_host[i] & 2) ? cs::kMetaResetPending : 0u);
-    h.set_u32(i, L.meta, meta);
-    if (prev_shaping_host) h.set_word(i, L.ps, prev_shaping_host[i]);
+    h.set_u32(i, L.meta(), meta);
+    if (prev_shaping_host) h.set_word(i, L.prev(), prev_shaping_host[i]);
     if (force_xyz_host)
       for (int j = 0; j < 3; ++j) h.set_word(i, L.f(j), force_xyz_host[(size_t)j * n + i]);
-    if (episode_host) h.set_u32(i, L.epi, episode_host[i]);
+    if (episode_host) h.set_u32(i, L.epi(), episode_host[i]);
     if (episode_return_host) {
       const float f = (float)episode_return_host[i];
-      std::memcpy(h.at(i, L.ret, 4), &f, 4);
+      std::memcpy(h.at(i, L.ret_()), &f, 4);
     }
   }
   CS_HIP(hipMemcpy(ctx->st.tiles, h.buf.data(), h.buf.size(), hipMemcpyHostToDevice));

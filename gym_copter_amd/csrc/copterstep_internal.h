@@ -11,61 +11,71 @@
 namespace cs {
 
 // ---------------------------------------------------------------------------------
-// State layout in HBM: wavefront-tiled struct-of-arrays ("AoSoA", tile = 64 envs).
+// State layout in HBM: wavefront-tiled ("AoSoA", tile = one wavefront = 64 envs), with
+// the fields of one env grouped four to a 16-byte vector so that every access of the
+// step kernel is ONE 16-byte-per-lane instruction covering 1 KiB of contiguous memory:
 //
-//   tile t holds envs [64t, 64t+64); inside a tile every field is one ROW of 64
-//   consecutive lanes:  byte address = tiles + t*tile_bytes + row_offset(field) + lane*word
+//   byte address = tiles + tile*tile_bytes + field.off + lane*field.stride
 //
-// so a wavefront touches ONE contiguous ~5.6 KB region, every access is a coalesced
-// dword per lane, and every row is reached from a single per-lane base address with an
-// instruction immediate (no per-access address arithmetic).  Rows (float32 modes, 256 B
-// each; in CS_STATE_F64 the float rows are 512 B):
+//   X0  {x, dx, y, dy}            X1  {z, dz, phi, dphi}        X2  {theta, dtheta, psi, dpsi}
+//   GM  {guard0, guard1, guard2, meta}          (CS_STATE_F32G; otherwise META is a dword row)
+//   PS  prev_shaping (dword/qword row; NaN = upstream's None)
+//   FE  {force_x, force_y, force_z, episode}    pending reset perturbation [N] + episodes started
+//   RET running episode return (dword row, episode_stats)
 //
-//   META     steps (bits 0..23) | flight status (24..25) | flags (28: perturbation
-//            pending, 29: reset pending)                                    u32
-//   X0..X11  state words x,dx,y,dy,z,dz,phi,dphi,theta,dtheta,psi,dpsi     f32 / f64
-//   G0..G2   guard bytes of components 0-3 / 4-7 / 8-11 (CS_STATE_F32G)     u32
-//   PS       prev_shaping (NaN = upstream's None)                           f32 / f64
-//   F0..F2   pending reset perturbation force, newtons                      f32 / f64
-//   EPI      episodes started (Philox counter word)                         u32
-//   RET      running episode return (episode_stats)                         f32
+//   meta  = steps (bits 0..23) | flight status (24..25) | flags (28 perturbation pending,
+//           29 reset pending);   guard j = guard bytes of components 4j..4j+3.
+//
+// A wavefront therefore touches one contiguous 5.5 KB region, and every field is reached
+// from a per-lane base address with an instruction immediate.
 // ---------------------------------------------------------------------------------
 constexpr int kTileEnvs = 64;
 
-struct Layout {
-  uint32_t word;  // bytes per float word (4 or 8)
-  uint32_t meta, x0, g0, ps, f0, epi, ret, tile_bytes;
-  constexpr uint32_t x(int k) const { return x0 + (uint32_t)k * kTileEnvs * word; }
-  constexpr uint32_t g(int j) const { return g0 + (uint32_t)j * kTileEnvs * 4u; }
-  constexpr uint32_t f(int j) const { return f0 + (uint32_t)j * kTileEnvs * word; }
+struct Field {
+  uint32_t off, stride;
 };
 
-constexpr Layout make_layout(bool f64) {
+struct Layout {
+  uint32_t word;          // bytes per float word (4 or 8)
+  bool guard;             // guard words present (GM group) or bare META row
+  uint32_t xg[3];         // offsets of the X0..X2 groups (lane stride 4*word)
+  uint32_t gm;            // GM group (lane stride 16) or META row (lane stride 4)
+  uint32_t ps, fe, ret;   // PS row (stride word), FE group (stride 4*word), RET row (stride 4)
+  uint32_t tile_bytes;
+  constexpr Field x(int k) const { return {xg[k >> 2] + (uint32_t)(k & 3) * word, 4 * word}; }
+  constexpr Field g(int j) const { return {gm + (uint32_t)j * 4u, 16u}; }
+  constexpr Field meta() const { return guard ? Field{gm + 12u, 16u} : Field{gm, 4u}; }
+  constexpr Field prev() const { return {ps, word}; }
+  constexpr Field f(int j) const { return {fe + (uint32_t)j * word, 4 * word}; }
+  constexpr Field epi() const { return {fe + 3u * word, 4 * word}; }
+  constexpr Field ret_() const { return {ret, 4u}; }
+};
+
+constexpr Layout make_layout(int mode) {
   Layout l{};
-  l.word = f64 ? 8u : 4u;
-  const uint32_t r4 = kTileEnvs * 4u, rw = kTileEnvs * l.word;
+  l.word = mode == CS_STATE_F64 ? 8u : 4u;
+  l.guard = mode == CS_STATE_F32G;
+  const uint32_t n = kTileEnvs;
   uint32_t o = 0;
-  l.meta = o;
-  o += r4;
-  l.x0 = o;
-  o += 12 * rw;
-  l.g0 = o;
-  o += 3 * r4;
+  for (int j = 0; j < 3; ++j) {
+    l.xg[j] = o;
+    o += n * 4 * l.word;
+  }
+  l.gm = o;
+  o += l.guard ? n * 16u : n * 4u;
   l.ps = o;
-  o += rw;
-  l.f0 = o;
-  o += 3 * rw;
-  l.epi = o;
-  o += r4;
+  o += n * l.word;
+  l.fe = o;
+  o += n * 4 * l.word;
   l.ret = o;
-  o += r4;
-  l.tile_bytes = o;
+  o += n * 4u;
+  l.tile_bytes = (o + 255u) & ~255u;
   return l;
 }
 
 constexpr uint32_t kMetaStepsMask = 0x00FFFFFFu;
 constexpr int kMetaStatusShift = 24;
-constexpr uint32_t kMetaPerturbPending = 1u << 28;  // force rows not yet consumed by the physics
+constexpr uint32_t kMetaPerturbPending = 1u << 28;  // FE force not yet consumed by the physics
 constexpr uint32_t kMetaResetPending = 1u << 29;    // NEXT_STEP: env finished, reset on next step
 
 // Uniform (per-launch) constants, all float64, derived once on the host from cs_config.

@@ -48,26 +48,121 @@ constexpr int kWave = 64;
 template <int MODE>
 struct ModeOf {
   using T = float;
-  static constexpr Layout L = make_layout(false);
+  static constexpr Layout L = make_layout(MODE);
 };
 template <>
 struct ModeOf<CS_STATE_F64> {
   using T = double;
-  static constexpr Layout L = make_layout(true);
+  static constexpr Layout L = make_layout(CS_STATE_F64);
 };
 
-// Row access: `p` is the lane's address inside its tile, biased by kBias so that every
-// row offset fits the signed 13-bit instruction immediate of global_load/global_store.
+template <class T>
+struct alignas(4 * sizeof(T)) Vec4 {
+  T v[4];
+};
+
+// Per-lane view of this wavefront's tile.  Every field is base + immediate: the bases are
+// biased by kBias so that all offsets fit the signed 13-bit immediate of global_load/store,
+// and a whole 4-word group moves as one 16-byte-per-lane instruction (float32 modes).
 constexpr int kBias = 4096;
 
-template <class U>
-__device__ __forceinline__ U ld(const char* p, uint32_t row) {
-  return *reinterpret_cast<const U*>(p + ((int)row - kBias));
-}
-template <class U>
-__device__ __forceinline__ void st(char* p, uint32_t row, U v) {
-  *reinterpret_cast<U*>(p + ((int)row - kBias)) = v;
-}
+template <int MODE>
+struct TileIO {
+  using T = typename ModeOf<MODE>::T;
+  static constexpr Layout L = ModeOf<MODE>::L;
+  char* b16;  // lane stride 16      (GM group)
+  char* bg;   // lane stride 4*word  (X0..X2, FE groups)
+  char* b4;   // lane stride 4       (RET row, bare META row)
+  char* bw;   // lane stride word    (PS row)
+
+  __device__ __forceinline__ TileIO(const DevState& s, uint32_t i) {
+    const uint32_t lane = i & 63u;
+    const uint32_t off = (i >> 6) * L.tile_bytes + kBias;
+    b16 = s.tiles + (off + lane * 16u);
+    bg = s.tiles + (off + lane * (4u * L.word));
+    b4 = s.tiles + (off + lane * 4u);
+    bw = s.tiles + (off + lane * L.word);
+  }
+  template <class U>
+  static __device__ __forceinline__ U ld(const char* p, uint32_t off) {
+    return *reinterpret_cast<const U*>(p + ((int)off - kBias));
+  }
+  template <class U>
+  static __device__ __forceinline__ void st(char* p, uint32_t off, const U& v) {
+    *reinterpret_cast<U*>(p + ((int)off - kBias)) = v;
+  }
+
+  // 12 state words, 3 guard words, meta: 4 vector loads (float32 + guard mode)
+  __device__ __forceinline__ void load_state(T (&raw)[12], uint32_t (&g)[3], uint32_t& meta) const {
+    if constexpr (L.guard) {
+      const Vec4<uint32_t> gm = ld<Vec4<uint32_t>>(b16, L.gm);
+      g[0] = gm.v[0];
+      g[1] = gm.v[1];
+      g[2] = gm.v[2];
+      meta = gm.v[3];
+    } else {
+      g[0] = g[1] = g[2] = 0;
+      meta = ld<uint32_t>(b4, L.gm);
+    }
+    // attitude groups first: the physics needs the angles before anything else
+    const int order[3] = {1, 2, 0};
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int j = order[jj];
+      const Vec4<T> v = ld<Vec4<T>>(bg, L.xg[j]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) raw[4 * j + k] = v.v[k];
+    }
+  }
+  __device__ __forceinline__ void store_state(const T (&w)[12], const uint32_t (&g)[3],
+                                              uint32_t meta) const {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      Vec4<T> v;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v.v[k] = w[4 * j + k];
+      st(bg, L.xg[j], v);
+    }
+    if constexpr (L.guard) {
+      Vec4<uint32_t> gm;
+      gm.v[0] = g[0];
+      gm.v[1] = g[1];
+      gm.v[2] = g[2];
+      gm.v[3] = meta;
+      st(b16, L.gm, gm);
+    } else {
+      st(b4, L.gm, meta);
+    }
+  }
+  __device__ __forceinline__ T load_prev() const { return ld<T>(bw, L.ps); }
+  __device__ __forceinline__ void store_prev(T v) const { st(bw, L.ps, v); }
+  __device__ __forceinline__ float load_ret() const { return ld<float>(b4, L.ret); }
+  __device__ __forceinline__ void store_ret(float v) const { st(b4, L.ret, v); }
+  // FE group: pending force [N] + episodes started (kept in the low 32 bits of word 3)
+  __device__ __forceinline__ void load_fe(double (&f)[3], uint32_t& episode) const {
+    const Vec4<T> v = ld<Vec4<T>>(bg, L.fe);
+    f[0] = (double)v.v[0];
+    f[1] = (double)v.v[1];
+    f[2] = (double)v.v[2];
+    if constexpr (sizeof(T) == 4) {
+      episode = __float_as_uint((float)v.v[3]);
+    } else {
+      episode = (uint32_t)(unsigned long long)__double_as_longlong((double)v.v[3]);
+    }
+  }
+  __device__ __forceinline__ void store_fe(const double (&f)[3], uint32_t episode) const {
+    Vec4<T> v;
+    v.v[0] = (T)f[0];
+    v.v[1] = (T)f[1];
+    v.v[2] = (T)f[2];
+    if constexpr (sizeof(T) == 4) {
+      v.v[3] = (T)__uint_as_float(episode);
+    } else {
+      v.v[3] = (T)__longlong_as_double((long long)(unsigned long long)episode);
+    }
+    st(bg, L.fe, v);
+  }
+};
 
 // ---------------------------------------------------------------------------------
 // counter-based RNG for the reset perturbation
@@ -362,7 +457,6 @@ template <int TASK, int MODE>
 __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const DevState s,
                                                       const cs_step_io io) {
   using T = typename ModeOf<MODE>::T;
-  constexpr Layout L = ModeOf<MODE>::L;
   constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
@@ -371,47 +465,30 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t env0 = i - lane;
   const bool valid = i < n;  // lanes past the end run on zeroed padding and never write out
-  // this lane's addresses inside its tile: 4-byte rows and word rows (same in float32 modes)
-  const uint32_t tile_off = (i >> 6) * L.tile_bytes + kBias;
-  char* const p4 = s.tiles + (tile_off + (uint32_t)lane * 4u);
-  char* const pw = s.tiles + (tile_off + (uint32_t)lane * L.word);
+  const TileIO<MODE> tile(s, i);
 
   CS_STAMP(0);
-  // ---- loads, in order of first use ----
-  const uint32_t meta = ld<uint32_t>(p4, L.meta);
-  const float4 act = reinterpret_cast<const float4*>(io.actions_dev)[valid ? i : 0u];
+  // ---- loads: 4 x 16 B (state, guards + meta) + prev_shaping + the action row ----
   T raw[12];
-  uint32_t g[3] = {0, 0, 0};
-  raw[6] = ld<T>(pw, L.x(6));
-  raw[8] = ld<T>(pw, L.x(8));
-  raw[10] = ld<T>(pw, L.x(10));
-  if constexpr (MODE == CS_STATE_F32G) {
-    g[1] = ld<uint32_t>(p4, L.g(1));
-    g[2] = ld<uint32_t>(p4, L.g(2));
-    g[0] = ld<uint32_t>(p4, L.g(0));
-  }
-#pragma unroll
-  for (int k = 0; k < 12; ++k)
-    if (k != 6 && k != 8 && k != 10) raw[k] = ld<T>(pw, L.x(k));
+  uint32_t g[3];
+  uint32_t meta;
+  tile.load_state(raw, g, meta);
+  const float4 act = reinterpret_cast<const float4*>(io.actions_dev)[valid ? i : 0u];
   double prev_sh = 0.0;
-  if constexpr (TASK == CS_TASK_LANDER3D) prev_sh = (double)ld<T>(pw, L.ps);
+  if constexpr (TASK == CS_TASK_LANDER3D) prev_sh = (double)tile.load_prev();
   float ep_ret = 0.f;
-  if (c.stats) ep_ret = ld<float>(p4, L.ret);
+  if (c.stats) ep_ret = tile.load_ret();
 
-  // second-round loads, issued as soon as the meta word is back and consumed late:
-  // the pending reset perturbation and (when auto-reset is on) the episode number
+  // second-round load, issued as soon as the meta word is back and consumed late: the FE
+  // group (pending reset perturbation + episode number), only by lanes that need it
   int steps = (int)(meta & kMetaStepsMask);
   int fs = (int)((meta >> kMetaStatusShift) & 3u);
   bool pend = (meta & kMetaPerturbPending) != 0;
   const bool resetting = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
+  const bool same_step = c.autoreset == CS_AUTORESET_SAME_STEP;
   double f[3] = {0.0, 0.0, 0.0};
-  if (pend) {
-    f[0] = (double)ld<T>(pw, L.f(0));
-    f[1] = (double)ld<T>(pw, L.f(1));
-    f[2] = (double)ld<T>(pw, L.f(2));
-  }
   uint32_t episode = 0;
-  if (c.autoreset != CS_AUTORESET_DISABLED) episode = ld<uint32_t>(p4, L.epi);
+  if (pend || resetting || same_step) tile.load_fe(f, episode);
 
   double x[12];
 #pragma unroll
@@ -501,7 +578,6 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
 
   // ---- observation of the finished state (SAME_STEP keeps it in final_obs) ----
   float* lds_wave = lds + (threadIdx.x - lane) * OBS;
-  const bool same_step = c.autoreset == CS_AUTORESET_SAME_STEP;
   if (same_step && io.final_obs_dev != nullptr && fin && valid) {
     float* dst = io.final_obs_dev + (size_t)i * OBS;
 #pragma unroll
@@ -526,25 +602,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
     steps = 1;
     ep_ret = 0.f;
     prev_sh = c.reset_shaping;
-    st<T>(pw, L.f(0), (T)fr[0]);
-    st<T>(pw, L.f(1), (T)fr[1]);
-    st<T>(pw, L.f(2), (T)fr[2]);
-    st<uint32_t>(p4, L.epi, episode + 1);
+    tile.store_fe(fr, episode + 1);
   }
 
   CS_STAMP(5);
-  // ---- stores ----
-#pragma unroll
-  for (int k = 0; k < 12; ++k) st<T>(pw, L.x(k), xs[k]);
-  if constexpr (MODE == CS_STATE_F32G) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) st<uint32_t>(p4, L.g(j), gs[j]);
-  }
-  st<uint32_t>(p4, L.meta,
-               (uint32_t)steps | ((uint32_t)fs << kMetaStatusShift) |
-                   (pend ? kMetaPerturbPending : 0u) | (reset_pending ? kMetaResetPending : 0u));
-  if constexpr (TASK == CS_TASK_LANDER3D) st<T>(pw, L.ps, (T)prev_sh);
-  if (c.stats) st<float>(p4, L.ret, ep_ret);
+  // ---- stores: 4 x 16 B (state, guards + meta) + prev_shaping ----
+  tile.store_state(xs, gs,
+                   (uint32_t)steps | ((uint32_t)fs << kMetaStatusShift) |
+                       (pend ? kMetaPerturbPending : 0u) | (reset_pending ? kMetaResetPending : 0u));
+  if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)prev_sh);
+  if (c.stats) tile.store_ret(ep_ret);
   if (valid) {
     if (io.reward_dev) io.reward_dev[i] = (float)reward;
     if (io.terminated_dev) io.terminated_dev[i] = term ? 1 : 0;
@@ -565,47 +632,35 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, const DevState s,
                                                             const float* __restrict__ motors) {
   using T = typename ModeOf<MODE>::T;
-  constexpr Layout L = ModeOf<MODE>::L;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  const uint32_t lane = i & 63u;
-  const uint32_t tile_off = (i >> 6) * L.tile_bytes + kBias;
-  char* const p4 = s.tiles + (tile_off + lane * 4u);
-  char* const pw = s.tiles + (tile_off + lane * L.word);
+  const TileIO<MODE> tile(s, i);
   const float4 mv = reinterpret_cast<const float4*>(motors)[i];
-  const uint32_t meta = ld<uint32_t>(p4, L.meta);
-  uint32_t g[3] = {0, 0, 0};
-  if constexpr (MODE == CS_STATE_F32G) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) g[j] = ld<uint32_t>(p4, L.g(j));
-  }
+  T raw[12];
+  uint32_t g[3];
+  uint32_t meta;
+  tile.load_state(raw, g, meta);
   double x[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(ld<T>(pw, L.x(k)), g[k >> 2], k);
+  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], g[k >> 2], k);
   int fs = (int)((meta >> kMetaStatusShift) & 3u);
   bool pend = (meta & kMetaPerturbPending) != 0;
   double f[3] = {0.0, 0.0, 0.0};
-  if (pend) {
-    f[0] = (double)ld<T>(pw, L.f(0));
-    f[1] = (double)ld<T>(pw, L.f(1));
-    f[2] = (double)ld<T>(pw, L.f(2));
-  }
+  uint32_t episode = 0;
+  if (pend) tile.load_fe(f, episode);
   const Wrench w = motor_model(c, mv.x, mv.y, mv.z, mv.w);
   physics_substeps(c, w, x, fs, pend, f);
+  T xs[12];
   uint32_t gs[3] = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const Stored<MODE> e = encode_word<MODE>(x[k]);
-    st<T>(pw, L.x(k), e.word);
+    xs[k] = e.word;
     gs[k >> 2] |= e.guard << (8 * (k & 3));
   }
-  if constexpr (MODE == CS_STATE_F32G) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) st<uint32_t>(p4, L.g(j), gs[j]);
-  }
-  st<uint32_t>(p4, L.meta,
-               (meta & ~((3u << kMetaStatusShift) | kMetaPerturbPending)) |
-                   ((uint32_t)fs << kMetaStatusShift) | (pend ? kMetaPerturbPending : 0u));
+  tile.store_state(xs, gs,
+                   (meta & ~((3u << kMetaStatusShift) | kMetaPerturbPending)) |
+                       ((uint32_t)fs << kMetaStatusShift) | (pend ? kMetaPerturbPending : 0u));
 }
 
 // ---------------------------------------------------------------------------------
@@ -617,18 +672,15 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
                                                        const float* __restrict__ force_xyz,
                                                        float* __restrict__ obs) {
   using T = typename ModeOf<MODE>::T;
-  constexpr Layout L = ModeOf<MODE>::L;
   constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
   const uint32_t n = s.n;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const uint32_t lane = i & 63u;
-  const uint32_t tile_off = (i >> 6) * L.tile_bytes + kBias;
-  char* const p4 = s.tiles + (tile_off + lane * 4u);
-  char* const pw = s.tiles + (tile_off + lane * L.word);
+  const TileIO<MODE> tile(s, i);
   if (mask == nullptr || mask[i] != 0) {
-    double f[3];
-    const uint32_t episode = ld<uint32_t>(p4, L.epi);
+    double f[3], f_old[3];
+    uint32_t episode;
+    tile.load_fe(f_old, episode);
     if (force_xyz != nullptr) {
       f[0] = (double)force_xyz[0 * (size_t)n + i];
       f[1] = (double)force_xyz[1 * (size_t)n + i];
@@ -636,27 +688,23 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     } else {
       draw_force(c, i, episode, f);
     }
+    T xs[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) st<T>(pw, L.x(k), (k == 4) ? (T)c.z0 : (T)0);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) st<uint32_t>(p4, L.g(j), 0u);
-    st<T>(pw, L.f(0), (T)f[0]);
-    st<T>(pw, L.f(1), (T)f[1]);
-    st<T>(pw, L.f(2), (T)f[2]);
-    st<uint32_t>(p4, L.epi, episode + 1);
-    st<uint32_t>(p4, L.meta, 1u | ((uint32_t)c.status0 << kMetaStatusShift) | kMetaPerturbPending);
-    st<T>(pw, L.ps, (T)c.reset_shaping);  // NaN (= None) for Hover3D
-    st<float>(p4, L.ret, 0.f);
+    for (int k = 0; k < 12; ++k) xs[k] = (k == 4) ? (T)c.z0 : (T)0;
+    const uint32_t gs[3] = {0u, 0u, 0u};
+    tile.store_state(xs, gs, 1u | ((uint32_t)c.status0 << kMetaStatusShift) | kMetaPerturbPending);
+    tile.store_fe(f, episode + 1);
+    tile.store_prev((T)c.reset_shaping);  // NaN (= None) for Hover3D
+    tile.store_ret(0.f);
   }
   if (obs != nullptr) {
-    uint32_t g[3] = {0, 0, 0};
-    if constexpr (MODE == CS_STATE_F32G) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) g[j] = ld<uint32_t>(p4, L.g(j));
-    }
+    T raw[12];
+    uint32_t g[3];
+    uint32_t meta;
+    tile.load_state(raw, g, meta);
 #pragma unroll
     for (int k = 0; k < OBS; ++k)
-      obs[(size_t)i * OBS + k] = (float)decode_word<MODE>(ld<T>(pw, L.x(k)), g[k >> 2], k);
+      obs[(size_t)i * OBS + k] = (float)decode_word<MODE>(raw[k], g[k >> 2], k);
   }
 }
 
