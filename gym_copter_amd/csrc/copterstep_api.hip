@@ -169,7 +169,8 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
     return fail(CS_ERR_ARG, "cs_create: unknown autoreset mode");
   if (cfg->num_envs < 1 || cfg->num_envs > (int64_t)1 << 25)
     return fail(CS_ERR_ARG, "cs_create: num_envs must be in [1, 2^25] per context");
-  if (cfg->env_id_base < 0) return fail(CS_ERR_ARG, "cs_create: env_id_base must be >= 0");
+  if (cfg->env_id_base < 0 || cfg->env_id_base + cfg->num_envs > ((int64_t)1 << 32))
+    return fail(CS_ERR_ARG, "cs_create: global env ids must lie in [0, 2^32)");
   if (cfg->substeps < 1 || cfg->substeps > 1000)
     return fail(CS_ERR_ARG, "cs_create: substeps must be in [1, 1000]");
   if (cfg->max_steps < 1 || cfg->max_steps > (int32_t)cs::kMetaStepsMask - 2)

@@ -5,7 +5,7 @@
 //
 //   action clip -> motor model -> body-Z->NED rotation -> flight-status machine ->
 //   forward-Euler integrate (x substeps) -> reward / termination -> (auto-reset with a
-//   Philox4x32-10 perturbation draw) -> AoS observation row written through a
+//   Philox2x32-10 perturbation draw) -> AoS observation row written through a
 //   per-wavefront LDS transpose as full 16-byte-per-lane stores -> wave-ballot
 //   compaction of the finished-episode list.
 //
@@ -21,6 +21,8 @@
 // mantissa bits, four components packed per dword), so that 1000 forward-Euler
 // accumulations x += dt*dxdt do not stagnate when dt*dxdt << ulp(x).
 // This is an elementwise ODE: no MFMA.
+#include <type_traits>
+
 #include "copterstep_internal.h"
 
 namespace cs {
@@ -55,6 +57,12 @@ struct ModeOf<CS_STATE_F64> {
   using T = double;
   static constexpr Layout L = make_layout(CS_STATE_F64);
 };
+
+// caller-owned arrays: uniform base + 32-bit byte offset (global saddr + voffset addressing)
+template <class U, class P>
+__device__ __forceinline__ U* at32(P* base, uint32_t byte_off) {
+  return reinterpret_cast<U*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(base)) + byte_off);
+}
 
 template <class T>
 struct alignas(4 * sizeof(T)) Vec4 {
@@ -167,42 +175,38 @@ struct TileIO {
 // ---------------------------------------------------------------------------------
 // counter-based RNG for the reset perturbation
 // ---------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011); returns words 0..2 of the output block.
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&out)[3]) {
+// Philox2x32-10 (Salmon et al., SC'11): 64-bit counter, 32-bit key, ten rounds of one
+// 32x32->64 multiply each.
+__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t key,
+                                              uint32_t& o0, uint32_t& o1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53U, c0), lo0 = 0xD2511F53U * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57U, c2), lo1 = 0xCD9E8D57U * c2;
-    c0 = hi1 ^ c1 ^ k0;
-    c1 = lo1;
-    c2 = hi0 ^ c3 ^ k1;
-    c3 = lo0;
-    k0 += 0x9E3779B9U;
-    k1 += 0xBB67AE85U;
+    const uint32_t hi = __umulhi(0xD256D193U, c0), lo = 0xD256D193U * c0;
+    c0 = hi ^ key ^ c1;
+    c1 = lo;
+    key += 0x9E3779B9U;
   }
-  out[0] = c0;
-  out[1] = c1;
-  out[2] = c2;
+  o0 = c0;
+  o1 = c1;
 }
 
 // Reset perturbation force (task.py:177-188, :199-202): three U[-F, F) draws keyed by
 // (seed, global env id, this env's episode number) -- a pure function of those three,
 // so it is invariant to batch size, sharding, launch history and hipGraph replay.
-// u*2F and the subtraction are kept un-fused so the CPU oracle reproduces the value
-// bit-for-bit.
+// counter = (global env id, episode), key = seed_lo ^ seed_hi; the 64 output bits give
+// three 21-bit uniforms.  u*2F and the subtraction are kept un-fused so the CPU oracle
+// reproduces the value bit-for-bit.
 __device__ __forceinline__ void draw_force(const DevConst& c, uint32_t i, uint32_t episode,
                                            double (&f)[3]) {
-  const uint32_t id_lo = c.id_lo + i;
-  const uint32_t id_hi = c.id_hi + (id_lo < c.id_lo ? 1u : 0u);
-  uint32_t r[3];
-  philox4x32_10(id_lo, id_hi, episode, 0u, c.seed_lo, c.seed_hi, r);
+  uint32_t r0, r1;
+  philox2x32_10(c.id_lo + i, episode, c.seed_lo ^ c.seed_hi, r0, r1);
+  const uint32_t u[3] = {r0 >> 11, r1 >> 11, ((r0 & 0x7FFu) << 10) | (r1 & 0x3FFu)};
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double u = (double)(r[k] >> 8) * 0x1.0p-24;
+    const double v = (double)u[k] * 0x1.0p-21;
     {
 #pragma clang fp contract(off)
-      const double scaled = u * (2.0 * c.force_mag);
+      const double scaled = v * (2.0 * c.force_mag);
       f[k] = scaled - c.force_mag;
     }
   }
@@ -435,13 +439,13 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float4* dst = reinterpret_cast<float4*>(out + (size_t)env0 * OBS);
     const float4* src = reinterpret_cast<const float4*>(lds_wave);
     constexpr int kVec = kWave * OBS / 4;  // 160 (Lander3D) or 192 (Hover3D) float4
+    const uint32_t base = env0 * (uint32_t)(OBS * 4) + (uint32_t)lane * 16u;
 #pragma unroll
     for (int k = 0; k < (kVec + kWave - 1) / kWave; ++k) {
       const int v = k * kWave + lane;
-      if (v < kVec) dst[v] = src[v];
+      if (v < kVec) *at32<float4>(out, base + (uint32_t)k * 1024u) = src[v];
     }
   } else if (valid) {  // ragged last wavefront: plain row stores
     float* dst = out + (size_t)(env0 + lane) * OBS;
@@ -453,10 +457,16 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
 // ---------------------------------------------------------------------------------
 // the fused step kernel
 // ---------------------------------------------------------------------------------
-template <int TASK, int MODE>
+// LEAN = the common configuration (auto-reset DISABLED or NEXT_STEP, no episode statistics,
+// no done list / final_obs, time limit folded into `terminated`): the optional features are
+// compiled out instead of being skipped by uniform branches.
+template <int TASK, int MODE, bool LEAN>
 __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const DevState s,
                                                       const cs_step_io io) {
   using T = typename ModeOf<MODE>::T;
+  const bool opt_stats = !LEAN && c.stats;
+  const bool opt_trunc = !LEAN && c.tl_trunc;
+  const bool opt_done_list = !LEAN && io.done_count_dev != nullptr;
   constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
@@ -473,11 +483,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   uint32_t g[3];
   uint32_t meta;
   tile.load_state(raw, g, meta);
-  const float4 act = reinterpret_cast<const float4*>(io.actions_dev)[valid ? i : 0u];
+  const float4 act = *at32<const float4>(io.actions_dev, (valid ? i : 0u) << 4);
   double prev_sh = 0.0;
   if constexpr (TASK == CS_TASK_LANDER3D) prev_sh = (double)tile.load_prev();
   float ep_ret = 0.f;
-  if (c.stats) ep_ret = tile.load_ret();
+  if (opt_stats) ep_ret = tile.load_ret();
 
   // second-round load, issued as soon as the meta word is back and consumed late: the FE
   // group (pending reset perturbation + episode number), only by lanes that need it
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   int fs = (int)((meta >> kMetaStatusShift) & 3u);
   bool pend = (meta & kMetaPerturbPending) != 0;
   const bool resetting = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
-  const bool same_step = c.autoreset == CS_AUTORESET_SAME_STEP;
+  const bool same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
   double f[3] = {0.0, 0.0, 0.0};
   uint32_t episode = 0;
   if (pend || resetting || same_step) tile.load_fe(f, episode);
@@ -548,7 +558,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
       done = true;
     }
     const bool limit = steps == c.max_steps;
-    if (c.tl_trunc) {
+    if (opt_trunc) {
       trunc = limit && !done;
     } else {
       done = done || limit;
@@ -560,7 +570,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   const bool fin = term || trunc;
 
   // ---- finished-episode list: wave ballot -> one atomic per wavefront ----
-  if (io.done_count_dev != nullptr) {
+  if (opt_done_list) {
     const unsigned long long m = __ballot(fin && valid);
     if (m != 0ULL) {
       const int leader = __ffsll((long long)m) - 1;
@@ -611,11 +621,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
                    (uint32_t)steps | ((uint32_t)fs << kMetaStatusShift) |
                        (pend ? kMetaPerturbPending : 0u) | (reset_pending ? kMetaResetPending : 0u));
   if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)prev_sh);
-  if (c.stats) tile.store_ret(ep_ret);
+  if (opt_stats) tile.store_ret(ep_ret);
   if (valid) {
-    if (io.reward_dev) io.reward_dev[i] = (float)reward;
-    if (io.terminated_dev) io.terminated_dev[i] = term ? 1 : 0;
-    if (io.truncated_dev) io.truncated_dev[i] = trunc ? 1 : 0;
+    if (io.reward_dev) *at32<float>(io.reward_dev, i << 2) = (float)reward;
+    if (io.terminated_dev) *at32<uint8_t>(io.terminated_dev, i) = term ? 1 : 0;
+    if (io.truncated_dev) *at32<uint8_t>(io.truncated_dev, i) = trunc ? 1 : 0;
   }
   write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, n, valid, row);
   CS_STAMP(6);
@@ -715,10 +725,15 @@ inline int grid_for(uint32_t n) { return (int)((n + kBlock - 1) / kBlock); }
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                        const cs_step_io& io, hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
-#define CS_LAUNCH(TASK, MODE)                                                    \
-  if (task == TASK && mode == MODE) {                                            \
-    hipLaunchKernelGGL((step_kernel<TASK, MODE>), grid, block, 0, stream, c, s, io); \
-    return hipGetLastError();                                                    \
+  const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc &&
+                    io.done_count_dev == nullptr && io.final_obs_dev == nullptr;
+#define CS_LAUNCH(TASK, MODE)                                                               \
+  if (task == TASK && mode == MODE) {                                                       \
+    if (lean)                                                                               \
+      hipLaunchKernelGGL((step_kernel<TASK, MODE, true>), grid, block, 0, stream, c, s, io);  \
+    else                                                                                    \
+      hipLaunchKernelGGL((step_kernel<TASK, MODE, false>), grid, block, 0, stream, c, s, io); \
+    return hipGetLastError();                                                               \
   }
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)

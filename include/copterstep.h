@@ -135,7 +135,7 @@ int cs_obs_dim(const cs_ctx* ctx, int32_t* out);
 int cs_seed(cs_ctx* ctx, uint64_t seed);
 int cs_set_altitude(cs_ctx* ctx, double altitude);
 /* Reset envs with mask_dev[i] != 0 (NULL = all).  force_xyz_dev: [3,N] perturbation
- * forces in newtons to install (NULL = draw U[-F,F) with Philox4x32-10 keyed by
+ * forces in newtons to install (NULL = draw U[-F,F) with Philox2x32-10 keyed by
  * (seed, global env id, that env's episode number)).  obs_dev (nullable) receives ALL envs' observations. */
 int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, float* obs_dev,
              void* stream);

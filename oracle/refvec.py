@@ -8,7 +8,7 @@ proves the two agree bit-for-bit, so this file inherits that pin.  On top of
 the reference semantics it models the *batch* features the device library adds
 (none of which exist upstream): struct-of-arrays state, storage dtype
 (float32 state words with float64 arithmetic), inner substeps, masked
-auto-reset with a counter-based Philox4x32-10 perturbation draw keyed by
+auto-reset with a counter-based Philox2x32-10 perturbation draw keyed by
 (seed, global env id, episode number), and the
 time-limit-as-truncation option.  It is the checker the GPU parity tests and
 __graft_entry__.smoke() compare the HIP kernels against, and the
@@ -32,48 +32,46 @@ from .refcpu import (AIRBORNE, CRASHED, DJI_PHANTOM, G, LANDED, LANDING_ANGLE,
 AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
 
 # ---------------------------------------------------------------------------
-# Philox4x32-10 (Salmon et al., SC'11).  counter = 4 x u32, key = 2 x u32.
+# Philox2x32-10 (Salmon et al., SC'11): 64-bit counter, 32-bit key.
 # ---------------------------------------------------------------------------
-_PH_M0, _PH_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
-_PH_W0, _PH_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+_PH_M = np.uint64(0xD256D193)
+_PH_W = np.uint32(0x9E3779B9)
 _U32 = np.uint64(0xFFFFFFFF)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """All arguments uint32 arrays (broadcastable).  Returns 4 uint32 arrays."""
-    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
-    k0 = np.asarray(k0, dtype=np.uint32)
-    k1 = np.asarray(k1, dtype=np.uint32)
+def philox2x32_10(c0, c1, key):
+    """All arguments uint32 arrays (broadcastable).  Returns 2 uint32 arrays."""
+    c0 = np.asarray(c0, dtype=np.uint32)
+    c1 = np.asarray(c1, dtype=np.uint32)
+    key = np.asarray(key, dtype=np.uint32)
     with np.errstate(over="ignore"):
-        for r in range(10):
-            p0 = _PH_M0 * c0.astype(np.uint64)
-            p1 = _PH_M1 * c2.astype(np.uint64)
-            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & _U32).astype(np.uint32)
-            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & _U32).astype(np.uint32)
-            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
-            if r < 9:
-                k0 = (k0 + _PH_W0).astype(np.uint32)
-                k1 = (k1 + _PH_W1).astype(np.uint32)
-    return c0, c1, c2, c3
+        for _ in range(10):
+            p = _PH_M * c0.astype(np.uint64)
+            hi, lo = (p >> np.uint64(32)).astype(np.uint32), (p & _U32).astype(np.uint32)
+            c0, c1 = hi ^ key ^ c1, lo
+            key = (key + _PH_W).astype(np.uint32)
+    return c0, c1
 
 
 def draw_forces(seed, env_ids, episode, magnitude):
     """Perturbation force draw shared (by specification) with the device kernel.
 
-    counter = (env_id lo, env_id hi, episode number of that env, 0), key = (seed lo, seed hi);
-    u = (word >> 8) * 2^-24 in [0,1);  F = u * (2*magnitude) - magnitude, float64,
-    un-fused multiply then add.  Returns [3, n] float64.
+    counter = (global env id, episode number of that env), key = lo32(seed) ^ hi32(seed);
+    the 64 output bits give three 21-bit uniforms u = bits * 2^-21 in [0,1);
+    F = u * (2*magnitude) - magnitude, float64, un-fused multiply then add.
+    Returns [3, n] float64.
     """
     env_ids = np.asarray(env_ids, dtype=np.uint64)
+    assert np.all(env_ids < (1 << 32))
     episode = np.broadcast_to(np.asarray(episode, dtype=np.uint32), env_ids.shape)
-    seed = np.uint64(seed)
-    sh = np.uint64(32)
-    r = philox4x32_10((env_ids & _U32).astype(np.uint32), (env_ids >> sh).astype(np.uint32),
-                      episode, np.uint32(0),
-                      np.uint32(seed & _U32), np.uint32(seed >> sh))
+    seed = int(seed) & ((1 << 64) - 1)
+    key = np.uint32((seed & 0xFFFFFFFF) ^ (seed >> 32))
+    r0, r1 = philox2x32_10(env_ids.astype(np.uint32), episode, key)
+    bits = (r0 >> np.uint32(11), r1 >> np.uint32(11),
+            ((r0 & np.uint32(0x7FF)) << np.uint32(10)) | (r1 & np.uint32(0x3FF)))
     out = np.empty((3, env_ids.shape[0]))
     for i in range(3):
-        u = (r[i] >> np.uint32(8)).astype(np.float64) * (2.0 ** -24)
+        u = bits[i].astype(np.float64) * (2.0 ** -21)
         out[i] = u * (2.0 * float(magnitude)) - float(magnitude)
     return out
 
