@@ -146,16 +146,14 @@ struct TileIO {
   __device__ __forceinline__ void store_prev(T v) const { st(bw, L.ps, v); }
   __device__ __forceinline__ float load_ret() const { return ld<float>(b4, L.ret); }
   __device__ __forceinline__ void store_ret(float v) const { st(b4, L.ret, v); }
-  // FE group: pending force [N] + episodes started (kept in the low 32 bits of word 3)
-  __device__ __forceinline__ void load_fe(double (&f)[3], uint32_t& episode) const {
-    const Vec4<T> v = ld<Vec4<T>>(bg, L.fe);
-    f[0] = (double)v.v[0];
-    f[1] = (double)v.v[1];
-    f[2] = (double)v.v[2];
+  // FE group: pending force [N] + episodes started (kept in the low 32 bits of word 3).
+  // Returned raw so that nothing forces a wait on this (second-round) load before its use.
+  __device__ __forceinline__ Vec4<T> load_fe() const { return ld<Vec4<T>>(bg, L.fe); }
+  static __device__ __forceinline__ uint32_t episode_of(const Vec4<T>& v) {
     if constexpr (sizeof(T) == 4) {
-      episode = __float_as_uint((float)v.v[3]);
+      return __float_as_uint((float)v.v[3]);
     } else {
-      episode = (uint32_t)(unsigned long long)__double_as_longlong((double)v.v[3]);
+      return (uint32_t)(unsigned long long)__double_as_longlong((double)v.v[3]);
     }
   }
   __device__ __forceinline__ void store_fe(const double (&f)[3], uint32_t episode) const {
@@ -392,12 +390,13 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, 
 // `nsub` x Dynamics.setMotors with one wrench.  The pending perturbation (pend, force
 // f[] in newtons) can only enter the FIRST call: a call that freezes on ground contact
 // keeps it, but the status it leaves (CRASHED / LEVELING) makes the next call drop it.
+template <class T>
 __device__ __forceinline__ void physics_substeps(const DevConst& c, const Wrench& w,
                                                  double (&x)[12], int& fs, bool& pend,
-                                                 const double (&f)[3]) {
-  double px = pend ? f[0] * c.two_inv_M : 0.0;
-  double py = pend ? f[1] * c.two_inv_M : 0.0;
-  double pz = pend ? f[2] * c.two_inv_M : 0.0;
+                                                 const Vec4<T>& f) {
+  double px = pend ? (double)f.v[0] * c.two_inv_M : 0.0;
+  double py = pend ? (double)f.v[1] * c.two_inv_M : 0.0;
+  double pz = pend ? (double)f.v[2] * c.two_inv_M : 0.0;
 #pragma clang loop unroll(disable)
   for (int sub = 0; sub < c.nsub; ++sub) {
     const int what = physics_call(c, w, x, fs, px, py, pz);
@@ -461,9 +460,22 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
 // no done list / final_obs, time limit folded into `terminated`): the optional features are
 // compiled out instead of being skipped by uniform branches.
 template <int TASK, int MODE, bool LEAN>
-__global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const DevState s,
-                                                      const cs_step_io io) {
+__global__ __launch_bounds__(kBlock) void step_kernel(
+    // leading scalar arguments: preloaded into SGPRs with the wave (kernarg preload), so the
+    // first loads do not wait for an s_load of the argument block
+    char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
+    float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
+    const DevConst c, const DevState s_rest, const cs_step_io io_rest) {
   using T = typename ModeOf<MODE>::T;
+  DevState s = s_rest;
+  s.tiles = tiles;
+  s.n = n_envs;
+  cs_step_io io = io_rest;
+  io.actions_dev = actions_dev;
+  io.obs_dev = obs_dev;
+  io.reward_dev = reward_dev;
+  io.terminated_dev = terminated_dev;
+  io.truncated_dev = truncated_dev;
   const bool opt_stats = !LEAN && c.stats;
   const bool opt_trunc = !LEAN && c.tl_trunc;
   const bool opt_done_list = !LEAN && io.done_count_dev != nullptr;
@@ -496,9 +508,11 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   bool pend = (meta & kMetaPerturbPending) != 0;
   const bool resetting = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
   const bool same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
-  double f[3] = {0.0, 0.0, 0.0};
-  uint32_t episode = 0;
-  if (pend || resetting || same_step) tile.load_fe(f, episode);
+  // (a run-time zero, not a literal: a literal lets the compiler fold the float64
+  // conversion of `fe` into the branch below and wait for this load right there)
+  const T zero = (T)(c.nsub >> 30);
+  Vec4<T> fe = {{zero, zero, zero, zero}};
+  if (pend || resetting || same_step) fe = tile.load_fe();
 
   double x[12];
 #pragma unroll
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   if (!resetting && status0 != CS_STATUS_LANDED) {
     // np.clip(action, 0, 1), task.py:91 (comparisons, so a NaN action stays NaN as upstream)
     const Wrench w = motor_model(c, clip01(act.x), clip01(act.y), clip01(act.z), clip01(act.w));
-    physics_substeps(c, w, x, fs, pend, f);
+    physics_substeps(c, w, x, fs, pend, fe);
   }
 
   CS_STAMP(2);
@@ -600,6 +614,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const DevConst c, const De
   const bool reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && fin;
   if (do_reset) {
     double fr[3];
+    const uint32_t episode = TileIO<MODE>::episode_of(fe);
     draw_force(c, i, episode, fr);
 #pragma unroll
     for (int k = 0; k < 12; ++k) xs[k] = (T)0;
@@ -655,11 +670,10 @@ __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, co
   for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], g[k >> 2], k);
   int fs = (int)((meta >> kMetaStatusShift) & 3u);
   bool pend = (meta & kMetaPerturbPending) != 0;
-  double f[3] = {0.0, 0.0, 0.0};
-  uint32_t episode = 0;
-  if (pend) tile.load_fe(f, episode);
+  Vec4<T> fe = {{(T)0, (T)0, (T)0, (T)0}};
+  if (pend) fe = tile.load_fe();
   const Wrench w = motor_model(c, mv.x, mv.y, mv.z, mv.w);
-  physics_substeps(c, w, x, fs, pend, f);
+  physics_substeps(c, w, x, fs, pend, fe);
   T xs[12];
   uint32_t gs[3] = {0, 0, 0};
 #pragma unroll
@@ -688,9 +702,8 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
   if (i >= n) return;
   const TileIO<MODE> tile(s, i);
   if (mask == nullptr || mask[i] != 0) {
-    double f[3], f_old[3];
-    uint32_t episode;
-    tile.load_fe(f_old, episode);
+    double f[3];
+    const uint32_t episode = TileIO<MODE>::episode_of(tile.load_fe());
     if (force_xyz != nullptr) {
       f[0] = (double)force_xyz[0 * (size_t)n + i];
       f[1] = (double)force_xyz[1 * (size_t)n + i];
@@ -730,9 +743,13 @@ hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
 #define CS_LAUNCH(TASK, MODE)                                                               \
   if (task == TASK && mode == MODE) {                                                       \
     if (lean)                                                                               \
-      hipLaunchKernelGGL((step_kernel<TASK, MODE, true>), grid, block, 0, stream, c, s, io);  \
+      hipLaunchKernelGGL((step_kernel<TASK, MODE, true>), grid, block, 0, stream, s.tiles, s.n,      \
+                         io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,             \
+                         io.truncated_dev, c, s, io);  \
     else                                                                                    \
-      hipLaunchKernelGGL((step_kernel<TASK, MODE, false>), grid, block, 0, stream, c, s, io); \
+      hipLaunchKernelGGL((step_kernel<TASK, MODE, false>), grid, block, 0, stream, s.tiles, s.n,     \
+                         io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,             \
+                         io.truncated_dev, c, s, io); \
     return hipGetLastError();                                                               \
   }
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
