@@ -90,6 +90,7 @@ cs::DevConst make_const(const cs_ctx* ctx) {
   c.seed_hi = (uint32_t)(g.seed >> 32);
   c.id_lo = (uint32_t)(uint64_t)g.env_id_base;
   c.id_hi = (uint32_t)((uint64_t)g.env_id_base >> 32);
+  cs::trig_constants(c.trig);
   return c;
 }
 

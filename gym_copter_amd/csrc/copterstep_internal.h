@@ -96,7 +96,22 @@ struct DevConst {
   int32_t max_steps, nsub, autoreset, tl_trunc, stats, status0;
   uint32_t seed_lo, seed_hi;  // Philox key (the counter holds env id + episode number)
   uint32_t id_lo, id_hi;      // global id of local env 0
+  // sin/cos constants: [0] 2/pi, [1..3] pi/2 in three pieces (33+33+53 bits, fdlibm
+  // pio2_1, pio2_2, pio2_2t), [4..9] S1..S6, [10..15] C1..C6 (fdlibm k_sin / k_cos)
+  double trig[16];
 };
+
+inline void trig_constants(double (&t)[16]) {
+  const double v[16] = {6.36619772367581382433e-01,  1.57079632673412561417e+00,
+                        6.07710050630396597660e-11,  2.02226624879595063154e-21,
+                        -1.66666666666666324348e-01, 8.33333333332248946124e-03,
+                        -1.98412698298579493134e-04, 2.75573137070700676789e-06,
+                        -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+                        4.16666666666666019037e-02,  -1.38888888888741095749e-03,
+                        2.48015872894767294178e-05,  -2.75573143513906633035e-07,
+                        2.08757232129817482790e-09,  -1.13596475577881948265e-11};
+  for (int i = 0; i < 16; ++i) t[i] = v[i];
+}
 
 struct DevState {
   char* tiles;      // ntiles * tile_bytes

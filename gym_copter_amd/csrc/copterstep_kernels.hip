@@ -269,7 +269,7 @@ __device__ __forceinline__ float clip01(float a) { return a < 0.f ? 0.f : (a > 1
 // kernels: <= ~1 ulp for |x| < 2^19*pi/2.  Larger angles (not reached by a physical
 // trajectory: 8e5 rad) are first folded by multiples of 2^17 * 2pi, which keeps full
 // accuracy up to ~8e11 rad and degrades gracefully beyond.
-__device__ __forceinline__ void sincos_f64(double x, double& s, double& c) {
+__device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& s, double& c) {
   if (__builtin_expect(fabs(x) >= 8.0e5, 0)) {
     const double n1 = rint(x * (1.0 / (6.283185307179586476925 * 131072.0)));
     // 2pi * 2^17 in the same three pieces as pi/2 below (power-of-two scalings are exact)
@@ -277,23 +277,26 @@ __device__ __forceinline__ void sincos_f64(double x, double& s, double& c) {
     x = fma(-n1, 6.07710050630396597660e-11 * 524288.0, x);
     x = fma(-n1, 2.02226624879595063154e-21 * 524288.0, x);
   }
-  const double fn = rint(x * 6.36619772367581382433e-01);
-  double y = fma(-fn, 1.57079632673412561417e+00, x);
-  y = fma(-fn, 6.07710050630396597660e-11, y);
-  y = fma(-fn, 2.02226624879595063154e-21, y);
+  // the constants come from the kernel-argument block (DevConst::trig, filled by
+  // trig_constants()): two wide scalar loads instead of ~32 literal moves per wavefront
+  const double* t = k.trig;
+  const double fn = rint(x * t[0]);
+  double y = fma(-fn, t[1], x);
+  y = fma(-fn, t[2], y);
+  y = fma(-fn, t[3], y);
   const int q = (int)fn;
   const double z = y * y;
-  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-  ps = fma(z, ps, 2.75573137070700676789e-06);
-  ps = fma(z, ps, -1.98412698298579493134e-04);
-  ps = fma(z, ps, 8.33333333332248946124e-03);
-  ps = fma(z, ps, -1.66666666666666324348e-01);
+  double ps = fma(z, t[9], t[8]);
+  ps = fma(z, ps, t[7]);
+  ps = fma(z, ps, t[6]);
+  ps = fma(z, ps, t[5]);
+  ps = fma(z, ps, t[4]);
   const double sy = fma(y * z, ps, y);
-  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-  pc = fma(z, pc, -2.75573143513906633035e-07);
-  pc = fma(z, pc, 2.48015872894767294178e-05);
-  pc = fma(z, pc, -1.38888888888741095749e-03);
-  pc = fma(z, pc, 4.16666666666666019037e-02);
+  double pc = fma(z, t[15], t[14]);
+  pc = fma(z, pc, t[13]);
+  pc = fma(z, pc, t[12]);
+  pc = fma(z, pc, t[11]);
+  pc = fma(z, pc, t[10]);
   const double cy = 1.0 - fma(0.5, z, -(z * z) * pc);
   const double s0 = (q & 1) ? cy : sy;
   const double c0 = (q & 1) ? sy : cy;
@@ -348,9 +351,9 @@ enum { kCallOther = 0, kCallIntegrated = 1, kCallFroze = 2 };
 __device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, double (&x)[12],
                                             int& fs, double px, double py, double pz) {
   double sph, cph, sth, cth, sps, cps;
-  sincos_f64(x[6], sph, cph);
-  sincos_f64(x[8], sth, cth);
-  sincos_f64(x[10], sps, cps);
+  sincos_f64(c, x[6], sph, cph);
+  sincos_f64(c, x[8], sth, cth);
+  sincos_f64(c, x[10], sps, cps);
   const double ax = w.bz * fma(cph * cps, sth, sph * sps);
   const double ay = w.bz * fma(cph * sps, sth, -(cps * sph));
   const double netz = fma(w.bz, cph * cth, c.G);
