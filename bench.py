@@ -205,8 +205,9 @@ def main():
 
     extra = {}
     if a.gather and dist is not None:
-        gathered = torch.empty((world * n, env.obs_dim), dtype=torch.float32, device=device)
-        post = lambda: dist.all_gather_into_tensor(gathered, env._obs)
+        from gym_copter_amd.sharded import ShardGather
+        gather = ShardGather(n, world)           # the product's RCCL all-gather of the obs rows
+        post = lambda: gather("obs", env._obs)
         st2 = Stepper(torch, env, actions, False, chunk, post=post)
         st2.run(min(a.warmup, 50))
         w2, _ = timed(st2, a.steps)

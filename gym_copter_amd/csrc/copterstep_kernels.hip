@@ -260,7 +260,11 @@ __device__ __forceinline__ Stored<MODE> encode_word(double v) {
   return o;
 }
 
-__device__ __forceinline__ float clip01(float a) { return a < 0.f ? 0.f : (a > 1.f ? 1.f : a); }
+// np.clip(a, 0, 1) incl. its NaN passthrough (v_med3_f32 alone would turn NaN into 0)
+__device__ __forceinline__ float clip01(float a) {
+  const float m = __builtin_amdgcn_fmed3f(a, 0.f, 1.f);
+  return a != a ? a : m;
+}
 
 // ---------------------------------------------------------------------------------
 // float64 sin/cos and sqrt, sized for this kernel (no library slow paths, no scratch)
@@ -269,6 +273,23 @@ __device__ __forceinline__ float clip01(float a) { return a < 0.f ? 0.f : (a > 1
 // kernels: <= ~1 ulp for |x| < 2^19*pi/2.  Larger angles (not reached by a physical
 // trajectory: 8e5 rad) are first folded by multiples of 2^17 * 2pi, which keeps full
 // accuracy up to ~8e11 rad and degrades gracefully beyond.
+// sin and cos of a reduced argument |y| <= pi/4 (fdlibm k_sin / k_cos polynomials)
+__device__ __forceinline__ void sincos_kernel(const double* t, double y, double& sy, double& cy) {
+  const double z = y * y;
+  double ps = fma(z, t[9], t[8]);
+  ps = fma(z, ps, t[7]);
+  ps = fma(z, ps, t[6]);
+  ps = fma(z, ps, t[5]);
+  ps = fma(z, ps, t[4]);
+  sy = fma(y * z, ps, y);
+  double pc = fma(z, t[15], t[14]);
+  pc = fma(z, pc, t[13]);
+  pc = fma(z, pc, t[12]);
+  pc = fma(z, pc, t[11]);
+  pc = fma(z, pc, t[10]);
+  cy = 1.0 - fma(0.5, z, -(z * z) * pc);
+}
+
 __device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& s, double& c) {
   if (__builtin_expect(fabs(x) >= 8.0e5, 0)) {
     const double n1 = rint(x * (1.0 / (6.283185307179586476925 * 131072.0)));
@@ -285,19 +306,8 @@ __device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& 
   y = fma(-fn, t[2], y);
   y = fma(-fn, t[3], y);
   const int q = (int)fn;
-  const double z = y * y;
-  double ps = fma(z, t[9], t[8]);
-  ps = fma(z, ps, t[7]);
-  ps = fma(z, ps, t[6]);
-  ps = fma(z, ps, t[5]);
-  ps = fma(z, ps, t[4]);
-  const double sy = fma(y * z, ps, y);
-  double pc = fma(z, t[15], t[14]);
-  pc = fma(z, pc, t[13]);
-  pc = fma(z, pc, t[12]);
-  pc = fma(z, pc, t[11]);
-  pc = fma(z, pc, t[10]);
-  const double cy = 1.0 - fma(0.5, z, -(z * z) * pc);
+  double sy, cy;
+  sincos_kernel(t, y, sy, cy);
   const double s0 = (q & 1) ? cy : sy;
   const double c0 = (q & 1) ? sy : cy;
   s = (q & 2) ? -s0 : s0;
@@ -351,8 +361,16 @@ enum { kCallOther = 0, kCallIntegrated = 1, kCallFroze = 2 };
 __device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, double (&x)[12],
                                             int& fs, double px, double py, double pz) {
   double sph, cph, sth, cth, sps, cps;
-  sincos_f64(c, x[6], sph, cph);
-  sincos_f64(c, x[8], sth, cth);
+  // roll and pitch of a live env are inside +-pi/4 (the task ends the episode beyond,
+  // task.py:116): when that holds for the whole wavefront the reduction is the identity
+  // (fn = 0, y = x exactly) and is skipped -- bit-identical to the general path
+  if (__all(fabs(x[6]) < 0.785 && fabs(x[8]) < 0.785)) {
+    sincos_kernel(c.trig, x[6], sph, cph);
+    sincos_kernel(c.trig, x[8], sth, cth);
+  } else {
+    sincos_f64(c, x[6], sph, cph);
+    sincos_f64(c, x[8], sth, cth);
+  }
   sincos_f64(c, x[10], sps, cps);
   const double ax = w.bz * fma(cph * cps, sth, sph * sps);
   const double ay = w.bz * fma(cph * sps, sth, -(cps * sph));
