@@ -11,6 +11,8 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --steps 1000 --warmup 200 --no-cpu-baseline"
 # 1. per-kernel time, the same command as the bench default (65 536 envs, hipGraph replay)
 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- $BENCH > $OUT/trace.log 2>&1
+# 1b. the same at 4 194 304 envs, where the per-dispatch cost of tracing (a few us) is negligible
+rocprofv3 --kernel-trace --stats -d $OUT/trace_4m --output-format csv -- $BENCH --envs 4194304 --steps 200 --warmup 50 --ring 4 > $OUT/trace_4m.log 2>&1
 # 2. HBM traffic of the step kernel: FETCH_SIZE and WRITE_SIZE in their own passes (TCC slots),
 #    eager launches so that every dispatch is attributed; at 65 536 envs and at 4 194 304 envs
 for N in 65536 4194304; do

@@ -17,15 +17,24 @@ def find(sub, pat):
     return f[0] if f else None
 
 
-f = find("trace", "*kernel_stats.csv")
-if f:
-    print("== rocprofv3 --kernel-trace --stats (bench default command) ==")
+import re
+for sub, label in (("trace", "bench default command, 65 536 envs"), ("trace_4m", "4 194 304 envs")):
+    f = find(sub, "*kernel_stats.csv")
+    if not f:
+        continue
+    print("== rocprofv3 --kernel-trace --stats (%s) ==" % label)
     for r in csv.DictReader(open(f)):
         print("%-110s calls=%6s avg_ns=%10s min=%8s max=%8s pct=%s" % (
             r["Name"][:110], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
         if "step_kernel" in r["Name"]:
-            res["step_kernel_avg_ns"] = float(r["AverageNs"])
-            res["step_kernel_calls"] = int(r["Calls"])
+            res[sub + "_step_kernel_avg_ns"] = float(r["AverageNs"])
+            res[sub + "_step_kernel_calls"] = int(r["Calls"])
+    log = os.path.join(out, sub + ".log")
+    if os.path.exists(log):
+        m = re.search(r'"launch_us": ([0-9.]+)', open(log).read())
+        if m:
+            res[sub + "_hip_event_launch_us_in_profiled_run"] = float(m.group(1))
+            print("   bench.py's own HIP-event launch time in this (profiled) run: %s us" % m.group(1))
 
 
 def counters(sub):
