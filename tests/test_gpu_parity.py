@@ -443,3 +443,50 @@ def test_no_out_of_bounds_writes(n):
         assert bool((bufs["obs"][pad:pad + n * od] != -7.0).all())
         assert bool((bufs["term"][pad:pad + n] <= 1).all())
         env.close()
+
+
+def test_hipgraph_replay_matches_eager_and_oracle():
+    """bench.py times hipGraph replays of captured step launches: a replayed chunk must advance
+    the envs exactly like eager launches (no host-side state is baked into the captured
+    kernels; the reset draw is keyed by per-env episode counters kept on the device)."""
+    import torch
+    rng = np.random.default_rng(8)
+    n, chunk, reps = 5000, 10, 4
+    env, orc = make_pair("lander3d", n, "float32", autoreset="next_step", seed=21)
+    eager, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=21)
+    acts = rng.uniform(-1, 1, (chunk, n, 4)).astype(np.float32)
+    dev_acts = torch.from_numpy(acts).to(env.device)
+    env.reset()
+    eager.reset()
+    orc.reset()
+    side = torch.cuda.Stream(device=env.device)
+    side.wait_stream(torch.cuda.current_stream(env.device))
+    with torch.cuda.stream(side):
+        env.step(dev_acts[0])          # warm-up launch outside capture ...
+    torch.cuda.current_stream(env.device).wait_stream(side)
+    torch.cuda.synchronize()
+    eager.step(dev_acts[0])            # ... mirrored on the eager twin and the oracle
+    orc.step(acts[0].astype(np.float64))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for j in range(chunk):
+            env.step(dev_acts[j])
+    for rep in range(reps):
+        graph.replay()
+        torch.cuda.synchronize()
+        for j in range(chunk):
+            got_e = eager.step(dev_acts[j])
+            want = orc.step(acts[j].astype(np.float64))
+        # after each replayed chunk: last step's outputs and the whole state agree
+        obs_g = to_np(env._obs)
+        assert np.array_equal(obs_g, to_np(got_e[0])), rep
+        assert np.array_equal(to_np(env._reward), to_np(got_e[1])), rep
+        assert np.array_equal(to_np(env._term), to_np(eager._term)), rep
+        sg, se = env.get_state(), eager.get_state()
+        for k in ("x", "status", "steps", "episode", "force", "flags", "prev_shaping"):
+            assert np.array_equal(sg[k], se[k], equal_nan=True), (rep, k)
+        assert_state_close(env, orc, 2e-6, ctx="replay %d" % rep)
+        assert np.array_equal(sg["episode"], orc.episode)
+    assert sg["episode"].max() > 3      # several auto-resets happened inside the replays
+    env.close()
+    eager.close()
