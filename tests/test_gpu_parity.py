@@ -490,3 +490,29 @@ def test_hipgraph_replay_matches_eager_and_oracle():
     assert sg["episode"].max() > 3      # several auto-resets happened inside the replays
     env.close()
     eager.close()
+
+
+def test_lander_demo_csv_matches_reference_trace(tmp_path):
+    """gym_copter_amd.demo (the batch counterpart of the reference's lander.py --save): the CSV
+    trace of one env under the constant-thrust law equals the reference's own episode (golden
+    E02: same forces, same MOTORVAL) column by column to the printed precision."""
+    import gym_copter_amd
+    from gym_copter_amd import demo
+    g = ENV["E02_lander_const"]
+    n, k = 300, 137
+    forces = np.zeros((3, n), np.float32)
+    forces[:, k] = g["force"]
+    env = gym_copter_amd.make("Lander-v0", num_envs=n, autoreset_mode="disabled")
+    path = str(tmp_path / "traj.csv")
+    steps, total = demo.heuristic(env, path, random=False, env_index=k, forces=forces, verbose=False)
+    env.close()
+    fd = int(g["first_done"])
+    assert steps == fd + 1
+    assert abs(total - g["reward"][:fd + 1].sum()) < 1e-2
+    rows = open(path).read().strip().split("\n")
+    assert rows[0] == "t,m1,m2,m3,m4,X,dX,Y,dY,Z,dZ,Phi,dPhi,Theta,dTheta"
+    data = np.array([[float(v) for v in r.split(",")] for r in rows[1:]])
+    assert data.shape == (fd + 1, 15)
+    assert np.allclose(data[:, 0], 0.01 * np.arange(fd + 1), atol=1e-6)
+    assert np.allclose(data[:, 1:5], np.float32(1.625e-2), atol=1e-6)
+    assert np.allclose(data[:, 5:], g["obs"][:fd + 1], atol=2e-6, rtol=1e-5)
