@@ -71,6 +71,7 @@ SYMBOLS = {
     "cs_reset": (C.c_int, [_P, _P, _P, _P, _P]),
     "cs_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "cs_step_ex": (C.c_int, [_P, C.POINTER(StepIO), _P]),
+    "cs_step_many": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_set_motors": (C.c_int, [_P, _P, _P]),
     "cs_get_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
     "cs_set_state": (C.c_int, [_P] + [_P] * 8 + [_P]),

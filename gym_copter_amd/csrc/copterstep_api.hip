@@ -90,6 +90,7 @@ cs::DevConst make_const(const cs_ctx* ctx) {
   c.seed_hi = (uint32_t)(g.seed >> 32);
   c.id_lo = (uint32_t)(uint64_t)g.env_id_base;
   c.id_hi = (uint32_t)((uint64_t)g.env_id_base >> 32);
+  c.guard_mask = 0x1FE00000u;
   cs::trig_constants(c.trig);
   return c;
 }
@@ -292,6 +293,19 @@ int cs_step(cs_ctx* ctx, const float* actions_dev, float* obs_dev, float* reward
   io.terminated_dev = terminated_dev;
   io.truncated_dev = truncated_dev;
   return cs_step_ex(ctx, &io, stream);
+}
+
+int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float* obs_dev,
+                 float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (actions_dev == nullptr) return fail(CS_ERR_ARG, "cs_step_many: actions_dev is required");
+  if (num_steps < 1) return fail(CS_ERR_ARG, "cs_step_many: num_steps must be >= 1");
+  const cs::DevConst c = make_const(ctx);
+  hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
+                                      actions_dev, obs_dev, reward_dev, terminated_dev,
+                                      truncated_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_step_many: kernel launch");
+  return CS_OK;
 }
 
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {

@@ -96,6 +96,8 @@ struct DevConst {
   int32_t max_steps, nsub, autoreset, tl_trunc, stats, status0;
   uint32_t seed_lo, seed_hi;  // Philox key (the counter holds env id + episode number)
   uint32_t id_lo, id_hi;      // global id of local env 0
+  uint32_t guard_mask;        // 0x1FE00000 (bits 28..21), kept in an SGPR for v_and_or_b32
+  uint32_t pad_;
   // sin/cos constants: [0] 2/pi, [1..3] pi/2 in three pieces (33+33+53 bits, fdlibm
   // pio2_1, pio2_2, pio2_2t), [4..9] S1..S6, [10..15] C1..C6 (fdlibm k_sin / k_cos)
   double trig[16];
@@ -124,6 +126,9 @@ struct DevState {
 
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                        const cs_step_io& io, hipStream_t stream);
+hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
+                            const float* actions, float* obs, float* reward, uint8_t* term,
+                            uint8_t* trunc, hipStream_t stream);
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,
                              hipStream_t stream);
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,

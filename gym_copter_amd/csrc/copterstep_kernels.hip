@@ -156,7 +156,7 @@ struct TileIO {
       return (uint32_t)(unsigned long long)__double_as_longlong((double)v.v[3]);
     }
   }
-  __device__ __forceinline__ void store_fe(const double (&f)[3], uint32_t episode) const {
+  static __device__ __forceinline__ Vec4<T> make_fe(const double (&f)[3], uint32_t episode) {
     Vec4<T> v;
     v.v[0] = (T)f[0];
     v.v[1] = (T)f[1];
@@ -166,8 +166,9 @@ struct TileIO {
     } else {
       v.v[3] = (T)__longlong_as_double((long long)(unsigned long long)episode);
     }
-    st(bg, L.fe, v);
+    return v;
   }
+  __device__ __forceinline__ void store_fe(const Vec4<T>& v) const { st(bg, L.fe, v); }
 };
 
 // ---------------------------------------------------------------------------------
@@ -223,16 +224,22 @@ struct Stored {
 };
 
 template <int MODE>
-__device__ __forceinline__ double decode_word(typename ModeOf<MODE>::T w, uint32_t gword, int k) {
+__device__ __forceinline__ double decode_word(typename ModeOf<MODE>::T w, uint32_t gword, int k,
+                                              uint32_t guard_mask) {
   if constexpr (MODE == CS_STATE_F32G) {
     // float32 word = value truncated to 24 significant bits; the guard byte holds
     // significant bits 25..32, i.e. bits 28..21 of the float64 mantissa.  Byte k&3 of the
     // packed guard word is moved to bits 28..21 with one shift and one and-or.
     const int sh = 21 - 8 * (k & 3);
     const uint32_t moved = sh >= 0 ? (gword << sh) : (gword >> -sh);
-    unsigned long long b = (unsigned long long)__double_as_longlong((double)w);
-    b |= (unsigned long long)(moved & 0x1FE00000u);
-    return __longlong_as_double((long long)b);
+    // lo |= moved & 0x1FE00000 as ONE instruction (the mask sits in an SGPR; the low dword of
+    // the converted word has only bits 31..29 possibly set)
+    const double d = (double)w;
+    uint32_t lo;
+    asm("v_and_or_b32 %0, %1, %2, %3"
+        : "=v"(lo)
+        : "v"(moved), "s"(guard_mask), "v"((uint32_t)__double2loint(d)));
+    return __hiloint2double(__double2hiint(d), (int)lo);
   } else {
     return (double)w;
   }
@@ -475,6 +482,166 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
 }
 
 // ---------------------------------------------------------------------------------
+// one env, register-resident, and one _Task.step() on it
+// ---------------------------------------------------------------------------------
+template <int MODE>
+struct Env {
+  using T = typename ModeOf<MODE>::T;
+  double x[12];        // the values the stored representation decodes to
+  T xs[12];            // stored words of x   } valid after advance()
+  uint32_t gs[3];      // guard words of x    }
+  int steps, fs;       // step counter, flight status
+  bool pend;           // reset perturbation (fe.v[0..2]) not yet consumed
+  bool reset_pending;  // NEXT_STEP: finished, resets at the next step
+  bool fe_dirty;       // fe was rewritten by a reset and has to be stored
+  double prev_sh;
+  float ep_ret;
+  Vec4<T> fe;          // FE group, raw: force [N] + episodes started
+};
+
+template <int OBS>
+struct StepOut {
+  float row[OBS];  // observation returned by this step
+  double reward;
+  bool term, trunc;
+};
+
+struct StepOpts {  // uniform switches (compiled out in LEAN builds)
+  bool stats, trunc, done_list, same_step;
+};
+
+// _Task.step() (task.py:77-137) for one register-resident env: Dynamics.setMotors x
+// substeps -> stored-word rounding -> reward / termination -> optional done list and
+// final_obs -> masked auto-reset (task.py:145-197).  Shared by the one-step and the
+// K-step kernels, so both advance an env bit-identically.  ONE_STEP: the env is stored right
+// after this call, so a reset writes the FE group from inside its branch and does not keep
+// the register copies (x, fe) up to date.
+template <int TASK, int MODE, int OBS, bool ONE_STEP>
+__device__ __forceinline__ void advance(const DevConst& c, const StepOpts& o, Env<MODE>& e,
+                                        const float4 act, const cs_step_io& io, uint32_t i,
+                                        int lane, bool valid, const TileIO<MODE>& tile,
+                                        StepOut<OBS>& out) {
+  using T = typename ModeOf<MODE>::T;
+  const bool resetting = e.reset_pending;  // only ever set under NEXT_STEP auto-reset
+  double reward = 0.0;
+  bool term = false, trunc = false;
+  e.gs[0] = e.gs[1] = e.gs[2] = 0;
+
+  // ---- Dynamics.setMotors x substeps (skipped when the env entered LANDED) ----
+  const int status0 = e.fs;
+  if (!resetting && status0 != CS_STATUS_LANDED) {
+    // np.clip(action, 0, 1), task.py:91
+    const Wrench w = motor_model(c, clip01(act.x), clip01(act.y), clip01(act.z), clip01(act.w));
+    physics_substeps(c, w, e.x, e.fs, e.pend, e.fe);
+  }
+
+  // ---- round to the stored word; everything below sees exactly what is stored ----
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const Stored<MODE> w = encode_word<MODE>(e.x[k]);
+    e.xs[k] = w.word;
+    e.gs[k >> 2] |= w.guard << (8 * (k & 3));
+    e.x[k] = w.value;
+    if (k < OBS) out.row[k] = (float)w.value;  // float32 observation: round-to-nearest of the stored value
+  }
+
+  // ---- reward / termination (task.py:104-130, lander.py:46-74) ----
+  if (!resetting) {
+    bool done = false;
+    if constexpr (TASK == CS_TASK_LANDER3D) {
+      const double sh = lander_shaping(c, e.x);
+      reward = (e.prev_sh != e.prev_sh) ? 0.0 : sh - e.prev_sh;  // NaN == None
+      e.prev_sh = (double)(T)sh;
+      if (status0 == CS_STATUS_LANDED) {
+        done = true;
+        if (e.x[0] * e.x[0] + e.x[2] * e.x[2] < c.target_r2) reward += c.bonus;
+      }
+    } else {
+      reward = 1.0;
+    }
+    if (fabs(e.x[0]) >= c.bounds || fabs(e.x[2]) >= c.bounds) {
+      done = true;
+      reward -= c.oob_penalty;
+    } else if (fabs(e.x[6]) >= c.max_angle || fabs(e.x[8]) >= c.max_angle) {
+      done = true;
+      reward = -c.oob_penalty;
+    } else if (status0 == CS_STATUS_CRASHED) {
+      done = true;
+    }
+    const bool limit = e.steps == c.max_steps;
+    if (o.trunc) {
+      trunc = limit && !done;
+    } else {
+      done = done || limit;
+    }
+    e.steps = min(e.steps + 1, (int)kMetaStepsMask);
+    term = done;
+    e.ep_ret += (float)reward;
+  }
+  const bool fin = term || trunc;
+
+  // ---- finished-episode list: wave ballot -> one atomic per wavefront ----
+  if (o.done_list) {
+    const unsigned long long m = __ballot(fin && valid);
+    if (m != 0ULL) {
+      const int leader = __ffsll((long long)m) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(io.done_count_dev, (int)__popcll(m));
+      base = __shfl(base, leader);
+      if (fin && valid) {
+        const int slot = base + (int)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (io.done_ids_dev) io.done_ids_dev[slot] = (int32_t)i;
+        if (io.done_return_dev) io.done_return_dev[slot] = e.ep_ret;
+        if (io.done_length_dev) io.done_length_dev[slot] = e.steps - 1;
+      }
+    }
+  }
+
+  // ---- observation of the finished state (SAME_STEP keeps it in final_obs) ----
+  if (o.same_step && io.final_obs_dev != nullptr && fin && valid) {
+    float* dst = io.final_obs_dev + (size_t)i * OBS;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) dst[k] = out.row[k];
+  }
+
+  // ---- masked reset (task.py:145-197): fresh state, Philox force, shaping, steps = 1 ----
+  const bool do_reset = resetting || (o.same_step && fin);
+  e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && fin;
+  if (do_reset) {
+    double fr[3];
+    const uint32_t episode = TileIO<MODE>::episode_of(e.fe);
+    draw_force(c, i, episode, fr);
+    if constexpr (ONE_STEP) {
+      tile.store_fe(TileIO<MODE>::make_fe(fr, episode + 1));
+    } else {
+      e.fe = TileIO<MODE>::make_fe(fr, episode + 1);
+      e.fe_dirty = true;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      e.xs[k] = (k == 4) ? (T)c.z0 : (T)0;
+      if constexpr (!ONE_STEP) e.x[k] = (double)e.xs[k];
+    }
+    e.gs[0] = e.gs[1] = e.gs[2] = 0;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) out.row[k] = (float)e.xs[k];
+    e.fs = c.status0;
+    e.pend = true;
+    e.steps = 1;
+    e.ep_ret = 0.f;
+    e.prev_sh = c.reset_shaping;
+  }
+  out.reward = reward;
+  out.term = term;
+  out.trunc = trunc;
+}
+
+__device__ __forceinline__ uint32_t pack_meta(int steps, int fs, bool pend, bool reset_pending) {
+  return (uint32_t)steps | ((uint32_t)fs << kMetaStatusShift) | (pend ? kMetaPerturbPending : 0u) |
+         (reset_pending ? kMetaResetPending : 0u);
+}
+
+// ---------------------------------------------------------------------------------
 // the fused step kernel
 // ---------------------------------------------------------------------------------
 // LEAN = the common configuration (auto-reset DISABLED or NEXT_STEP, no episode statistics,
@@ -524,151 +691,136 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
 
   // second-round load, issued as soon as the meta word is back and consumed late: the FE
   // group (pending reset perturbation + episode number), only by lanes that need it
-  int steps = (int)(meta & kMetaStepsMask);
-  int fs = (int)((meta >> kMetaStatusShift) & 3u);
-  bool pend = (meta & kMetaPerturbPending) != 0;
-  const bool resetting = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
-  const bool same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
+  Env<MODE> e;
+  e.steps = (int)(meta & kMetaStepsMask);
+  e.fs = (int)((meta >> kMetaStatusShift) & 3u);
+  e.pend = (meta & kMetaPerturbPending) != 0;
+  e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
+  e.fe_dirty = false;
+  e.prev_sh = prev_sh;
+  e.ep_ret = ep_ret;
+  StepOpts o;
+  o.stats = opt_stats;
+  o.trunc = opt_trunc;
+  o.done_list = opt_done_list;
+  o.same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
   // (a run-time zero, not a literal: a literal lets the compiler fold the float64
   // conversion of `fe` into the branch below and wait for this load right there)
   const T zero = (T)(c.nsub >> 30);
-  Vec4<T> fe = {{zero, zero, zero, zero}};
-  if (pend || resetting || same_step) fe = tile.load_fe();
+  e.fe = {{zero, zero, zero, zero}};
+  if (e.pend || e.reset_pending || o.same_step) e.fe = tile.load_fe();
 
-  double x[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], g[k >> 2], k);
+  for (int k = 0; k < 12; ++k) e.x[k] = decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
 #ifdef CS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   CS_STAMP(1);
 
-  double reward = 0.0;
-  bool term = false, trunc = false;
-  T xs[12];
-  uint32_t gs[3] = {0, 0, 0};
-
-  // ---- Dynamics.setMotors x substeps (skipped when the env entered LANDED) ----
-  const int status0 = fs;
-  if (!resetting && status0 != CS_STATUS_LANDED) {
-    // np.clip(action, 0, 1), task.py:91 (comparisons, so a NaN action stays NaN as upstream)
-    const Wrench w = motor_model(c, clip01(act.x), clip01(act.y), clip01(act.z), clip01(act.w));
-    physics_substeps(c, w, x, fs, pend, fe);
-  }
-
-  CS_STAMP(2);
-  // ---- round to the stored word; everything below sees exactly what is stored ----
-  float row[OBS];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const Stored<MODE> e = encode_word<MODE>(x[k]);
-    xs[k] = e.word;
-    gs[k >> 2] |= e.guard << (8 * (k & 3));
-    x[k] = e.value;
-    if (k < OBS) row[k] = (float)e.value;  // float32 observation: round-to-nearest of the stored value
-  }
-
-  CS_STAMP(3);
-  // ---- reward / termination (task.py:104-130, lander.py:46-74) ----
-  if (!resetting) {
-    bool done = false;
-    if constexpr (TASK == CS_TASK_LANDER3D) {
-      const double sh = lander_shaping(c, x);
-      reward = (prev_sh != prev_sh) ? 0.0 : sh - prev_sh;  // NaN == None
-      prev_sh = (double)(T)sh;
-      if (status0 == CS_STATUS_LANDED) {
-        done = true;
-        if (x[0] * x[0] + x[2] * x[2] < c.target_r2) reward += c.bonus;
-      }
-    } else {
-      reward = 1.0;
-    }
-    if (fabs(x[0]) >= c.bounds || fabs(x[2]) >= c.bounds) {
-      done = true;
-      reward -= c.oob_penalty;
-    } else if (fabs(x[6]) >= c.max_angle || fabs(x[8]) >= c.max_angle) {
-      done = true;
-      reward = -c.oob_penalty;
-    } else if (status0 == CS_STATUS_CRASHED) {
-      done = true;
-    }
-    const bool limit = steps == c.max_steps;
-    if (opt_trunc) {
-      trunc = limit && !done;
-    } else {
-      done = done || limit;
-    }
-    steps = min(steps + 1, (int)kMetaStepsMask);
-    term = done;
-    ep_ret += (float)reward;
-  }
-  const bool fin = term || trunc;
-
-  // ---- finished-episode list: wave ballot -> one atomic per wavefront ----
-  if (opt_done_list) {
-    const unsigned long long m = __ballot(fin && valid);
-    if (m != 0ULL) {
-      const int leader = __ffsll((long long)m) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(io.done_count_dev, (int)__popcll(m));
-      base = __shfl(base, leader);
-      if (fin && valid) {
-        const int slot = base + (int)__popcll(m & ((1ULL << lane) - 1ULL));
-        if (io.done_ids_dev) io.done_ids_dev[slot] = (int32_t)i;
-        if (io.done_return_dev) io.done_return_dev[slot] = ep_ret;
-        if (io.done_length_dev) io.done_length_dev[slot] = steps - 1;
-      }
-    }
-  }
-
-  // ---- observation of the finished state (SAME_STEP keeps it in final_obs) ----
-  float* lds_wave = lds + (threadIdx.x - lane) * OBS;
-  if (same_step && io.final_obs_dev != nullptr && fin && valid) {
-    float* dst = io.final_obs_dev + (size_t)i * OBS;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) dst[k] = row[k];
-  }
-
-  CS_STAMP(4);
-  // ---- masked reset (task.py:145-197): fresh state, Philox force, shaping, steps = 1 ----
-  const bool do_reset = resetting || (same_step && fin);
-  const bool reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && fin;
-  if (do_reset) {
-    double fr[3];
-    const uint32_t episode = TileIO<MODE>::episode_of(fe);
-    draw_force(c, i, episode, fr);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) xs[k] = (T)0;
-    xs[4] = (T)c.z0;
-    gs[0] = gs[1] = gs[2] = 0;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) row[k] = (float)xs[k];
-    fs = c.status0;
-    pend = true;
-    steps = 1;
-    ep_ret = 0.f;
-    prev_sh = c.reset_shaping;
-    tile.store_fe(fr, episode + 1);
-  }
+  StepOut<OBS> out;
+  advance<TASK, MODE, OBS, true>(c, o, e, act, io, i, lane, valid, tile, out);
 
   CS_STAMP(5);
   // ---- stores: 4 x 16 B (state, guards + meta) + prev_shaping ----
-  tile.store_state(xs, gs,
-                   (uint32_t)steps | ((uint32_t)fs << kMetaStatusShift) |
-                       (pend ? kMetaPerturbPending : 0u) | (reset_pending ? kMetaResetPending : 0u));
-  if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)prev_sh);
-  if (opt_stats) tile.store_ret(ep_ret);
+  tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
+  if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)e.prev_sh);
+  if (opt_stats) tile.store_ret(e.ep_ret);
   if (valid) {
-    if (io.reward_dev) *at32<float>(io.reward_dev, i << 2) = (float)reward;
-    if (io.terminated_dev) *at32<uint8_t>(io.terminated_dev, i) = term ? 1 : 0;
-    if (io.truncated_dev) *at32<uint8_t>(io.truncated_dev, i) = trunc ? 1 : 0;
+    if (io.reward_dev) *at32<float>(io.reward_dev, i << 2) = (float)out.reward;
+    if (io.terminated_dev) *at32<uint8_t>(io.terminated_dev, i) = out.term ? 1 : 0;
+    if (io.truncated_dev) *at32<uint8_t>(io.truncated_dev, i) = out.trunc ? 1 : 0;
   }
-  write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, n, valid, row);
+  float* lds_wave = lds + (threadIdx.x - lane) * OBS;
+  write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, n, valid, out.row);
   CS_STAMP(6);
 #ifdef CS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   CS_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------------
+// K consecutive steps in one launch (open-loop: the K action batches are resident).
+// The env stays in registers between steps: state, guards, meta, prev_shaping and the FE
+// group cross HBM once per launch instead of once per step; per step only the action row
+// comes in and the observation row, reward and flags go out.  Bit-identical to K
+// launches of step_kernel (both call advance()).
+// ---------------------------------------------------------------------------------
+template <int TASK, int MODE>
+__global__ __launch_bounds__(kBlock) void step_many_kernel(
+    char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
+    float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
+    const int num_steps, const DevConst c, const DevState s_rest) {
+  using T = typename ModeOf<MODE>::T;
+  DevState s = s_rest;
+  s.tiles = tiles;
+  s.n = n_envs;
+  constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
+  __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
+
+  const uint32_t n = s.n;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t env0 = i - lane;
+  const bool valid = i < n;
+  const TileIO<MODE> tile(s, i);
+  float* lds_wave = lds + (threadIdx.x - lane) * OBS;
+
+  T raw[12];
+  uint32_t g[3];
+  uint32_t meta;
+  tile.load_state(raw, g, meta);
+  Env<MODE> e;
+  e.steps = (int)(meta & kMetaStepsMask);
+  e.fs = (int)((meta >> kMetaStatusShift) & 3u);
+  e.pend = (meta & kMetaPerturbPending) != 0;
+  e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
+  e.fe_dirty = false;
+  e.prev_sh = 0.0;
+  if constexpr (TASK == CS_TASK_LANDER3D) e.prev_sh = (double)tile.load_prev();
+  e.ep_ret = c.stats ? tile.load_ret() : 0.f;
+  e.fe = tile.load_fe();
+  StepOpts o;
+  o.stats = c.stats != 0;
+  o.trunc = c.tl_trunc != 0;
+  o.done_list = false;
+  o.same_step = c.autoreset == CS_AUTORESET_SAME_STEP;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) e.x[k] = decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
+  e.gs[0] = g[0];
+  e.gs[1] = g[1];
+  e.gs[2] = g[2];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) e.xs[k] = raw[k];
+
+  cs_step_io io;  // no optional outputs in the K-step form
+  io.actions_dev = nullptr;
+  io.obs_dev = io.reward_dev = io.final_obs_dev = io.done_return_dev = nullptr;
+  io.terminated_dev = io.truncated_dev = nullptr;
+  io.done_count_dev = io.done_ids_dev = io.done_length_dev = nullptr;
+
+  const uint32_t ia = (valid ? i : 0u) << 4;
+  float4 act = *at32<const float4>(actions_dev, ia);
+  for (int k = 0; k < num_steps; ++k) {
+    // rows of step k (64-bit uniform offsets: K * N can exceed 32 bits)
+    const size_t row = (size_t)k * n;
+    const int kn = (k + 1 < num_steps) ? k + 1 : k;
+    const float4 act_next = *at32<const float4>(actions_dev + (size_t)kn * n * 4, ia);  // prefetch
+    StepOut<OBS> out;
+    advance<TASK, MODE, OBS, false>(c, o, e, act, io, i, lane, valid, tile, out);
+    if (valid) {
+      if (reward_dev) *at32<float>(reward_dev + row, i << 2) = (float)out.reward;
+      if (terminated_dev) *at32<uint8_t>(terminated_dev + row, i) = out.term ? 1 : 0;
+      if (truncated_dev) *at32<uint8_t>(truncated_dev + row, i) = out.trunc ? 1 : 0;
+    }
+    write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds_wave, lane, env0, n, valid, out.row);
+    act = act_next;
+  }
+
+  if (e.fe_dirty) tile.store_fe(e.fe);
+  tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
+  if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)e.prev_sh);
+  if (c.stats) tile.store_ret(e.ep_ret);
 }
 
 // ---------------------------------------------------------------------------------
@@ -688,7 +840,7 @@ __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, co
   tile.load_state(raw, g, meta);
   double x[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], g[k >> 2], k);
+  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
   int fs = (int)((meta >> kMetaStatusShift) & 3u);
   bool pend = (meta & kMetaPerturbPending) != 0;
   Vec4<T> fe = {{(T)0, (T)0, (T)0, (T)0}};
@@ -737,7 +889,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     for (int k = 0; k < 12; ++k) xs[k] = (k == 4) ? (T)c.z0 : (T)0;
     const uint32_t gs[3] = {0u, 0u, 0u};
     tile.store_state(xs, gs, 1u | ((uint32_t)c.status0 << kMetaStatusShift) | kMetaPerturbPending);
-    tile.store_fe(f, episode + 1);
+    tile.store_fe(TileIO<MODE>::make_fe(f, episode + 1));
     tile.store_prev((T)c.reset_shaping);  // NaN (= None) for Hover3D
     tile.store_ret(0.f);
   }
@@ -748,7 +900,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     tile.load_state(raw, g, meta);
 #pragma unroll
     for (int k = 0; k < OBS; ++k)
-      obs[(size_t)i * OBS + k] = (float)decode_word<MODE>(raw[k], g[k >> 2], k);
+      obs[(size_t)i * OBS + k] = (float)decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
   }
 }
 
@@ -772,6 +924,26 @@ hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                          io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,             \
                          io.truncated_dev, c, s, io); \
     return hipGetLastError();                                                               \
+  }
+  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
+  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)
+  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F64)
+  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32G)
+  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_RN)
+  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F64)
+#undef CS_LAUNCH
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
+                            const float* actions, float* obs, float* reward, uint8_t* term,
+                            uint8_t* trunc, hipStream_t stream) {
+  const dim3 grid(grid_for(s.n)), block(kBlock);
+#define CS_LAUNCH(TASK, MODE)                                                                   \
+  if (task == TASK && mode == MODE) {                                                           \
+    hipLaunchKernelGGL((step_many_kernel<TASK, MODE>), grid, block, 0, stream, s.tiles, s.n,     \
+                       actions, obs, reward, term, trunc, num_steps, c, s);                     \
+    return hipGetLastError();                                                                   \
   }
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)

@@ -112,7 +112,6 @@ class CopterVecEnv:
             self._reward = torch.empty(n, dtype=torch.float32, device=self.device)
             self._term = torch.empty(n, dtype=torch.uint8, device=self.device)
             self._trunc = torch.empty(n, dtype=torch.uint8, device=self.device)
-            self._actions = torch.empty((n, 4), dtype=torch.float32, device=self.device)
             self._final_obs = None
             self._done = None
 
@@ -222,6 +221,32 @@ class CopterVecEnv:
             return (self._obs.cpu().numpy(), self._reward.cpu().numpy(), term.cpu().numpy(),
                     trunc.cpu().numpy(), {k: _to_numpy(v) for k, v in infos.items()})
         return self._obs, self._reward, term, trunc, infos
+
+    def step_many(self, actions):
+        """K steps in ONE kernel launch for resident action batches: actions [K,N,4] ->
+        (obs [K,N,obs_dim], reward [K,N], terminated [K,N], truncated [K,N]).  Bit-identical to
+        K calls of step(actions[k]); the env state stays in registers between the steps."""
+        self._check_open()
+        torch = _torch()
+        if not isinstance(actions, torch.Tensor):
+            actions = torch.from_numpy(np.ascontiguousarray(np.asarray(actions, dtype=np.float32)))
+        if actions.dim() != 3 or tuple(actions.shape[1:]) != (self.num_envs, 4):
+            raise ValueError("actions must have shape (K, %d, 4), got %s" % (self.num_envs, tuple(actions.shape)))
+        a = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        K, n = int(a.shape[0]), self.num_envs
+        buf = getattr(self, "_many", None)
+        if buf is None or buf[0].shape[0] != K:
+            buf = (torch.empty((K, n, self.obs_dim), dtype=torch.float32, device=self.device),
+                   torch.empty((K, n), dtype=torch.float32, device=self.device),
+                   torch.empty((K, n), dtype=torch.uint8, device=self.device),
+                   torch.empty((K, n), dtype=torch.uint8, device=self.device))
+            self._many = buf
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_step_many(self._ctx, K, p(a), p(buf[0]), p(buf[1]), p(buf[2]),
+                                              p(buf[3]), self._stream()))
+        self._keep = a
+        return buf[0], buf[1], buf[2].view(torch.bool), buf[3].view(torch.bool)
 
     def close(self):                                            # task.py:139-143
         if not self.closed and self._ctx:

@@ -17,6 +17,7 @@
  *   cs_step / cs_step_ex     _Task.step + Lander._get_reward    envs/task.py:77-137, envs/lander.py:39-74
  *                            (+ attic hover.py:18-21, hover3d.py:32-37 for CS_TASK_HOVER3D)
  *                            which calls Dynamics.setMotors     dynamics/__init__.py:114-197,249-302
+ *   cs_step_many             K x _Task.step in one launch       envs/task.py:77-137 (lander.py:40-65 loop)
  *   cs_set_motors            Dynamics.setMotors (used directly) dynamics/__init__.py:114-197
  *   cs_get_state             Dynamics.getState / getStatus      dynamics/__init__.py:199-207,223-225
  *   cs_set_state             Dynamics.setState / perturb        dynamics/__init__.py:210-217,227-229
@@ -143,6 +144,15 @@ int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, f
 int cs_step(cs_ctx* ctx, const float* actions_dev, float* obs_dev, float* reward_dev,
             uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
 int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream);
+
+/* K consecutive steps in ONE launch for action batches that are already resident (open
+ * loop: recorded or random actions, shooting-style planners).  actions_dev [K,N,4];
+ * obs_dev [K,N,obs_dim], reward_dev [K,N], terminated_dev / truncated_dev [K,N] (each
+ * nullable).  The result is bit-identical to K calls of cs_step with actions_dev[k]; the
+ * env state stays in registers between the steps instead of crossing HBM every step.
+ * The optional outputs of cs_step_ex (done list, final_obs) are not produced here. */
+int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float* obs_dev,
+                 float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
 
 /* Physics only: `substeps` x Dynamics.setMotors(motors[i]) on every env, raw motor
  * values (no clipping, no task logic). */

@@ -516,3 +516,39 @@ def test_lander_demo_csv_matches_reference_trace(tmp_path):
     assert np.allclose(data[:, 0], 0.01 * np.arange(fd + 1), atol=1e-6)
     assert np.allclose(data[:, 1:5], np.float32(1.625e-2), atol=1e-6)
     assert np.allclose(data[:, 5:], g["obs"][:fd + 1], atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("task,mode,autoreset", [
+    ("lander3d", "float32", "next_step"), ("lander3d", "float32", "same_step"),
+    ("lander3d", "float32", "disabled"), ("hover3d", "float32", "next_step"),
+    ("lander3d", "float64", "next_step"), ("lander3d", "float32_rn", "next_step")])
+def test_step_many_is_bit_identical_to_single_steps(task, mode, autoreset):
+    """cs_step_many (K steps in one launch, env state kept in registers) returns exactly what K
+    calls of cs_step return -- every output of every step and the final state, bit for bit --
+    and both match the oracle."""
+    import torch
+    rng = np.random.default_rng(17)
+    n, K = 4133, 24
+    many, orc = make_pair(task, n, mode, autoreset=autoreset, seed=5, episode_stats=True)
+    single, _ = make_pair(task, n, mode, autoreset=autoreset, seed=5, episode_stats=True)
+    many.reset()
+    single.reset()
+    orc.reset()
+    for chunk in range(3):
+        law = rng.uniform(-1, 1, (K, n, 4)) if chunk != 1 else HOVER * (1 + 0.05 * rng.standard_normal((K, n, 4)))
+        acts = law.astype(np.float32)
+        dev = torch.from_numpy(acts).to(many.device)
+        obs_m, rew_m, term_m, trunc_m = many.step_many(dev)
+        for k in range(K):
+            o, r, t, tr, _ = single.step(dev[k])
+            assert torch.equal(obs_m[k], o) and torch.equal(rew_m[k], r), (chunk, k)
+            assert torch.equal(term_m[k], t) and torch.equal(trunc_m[k], tr), (chunk, k)
+            want = orc.step(acts[k].astype(np.float64))
+        sm, ss = many.get_state(), single.get_state()
+        for key in sm:
+            assert np.array_equal(sm[key], ss[key], equal_nan=True), (chunk, key)
+        assert_step_close((to_np(obs_m[K - 1]), to_np(rew_m[K - 1]), to_np(term_m[K - 1]), to_np(trunc_m[K - 1])),
+                          want, 2e-6, r_abs=2e-3, r_rel=2e-6)
+        assert_state_close(many, orc, 2e-6 if mode != "float64" else 1e-9)
+    many.close()
+    single.close()
