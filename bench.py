@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--gather", action="store_true", help="also time with the RCCL obs all-gather")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--many", type=int, default=100,
+                   help="also time cs_step_many with this many steps per launch (0 = skip)")
     return p.parse_args()
 
 
@@ -213,6 +215,31 @@ def main():
         w2, _ = timed(st2, a.steps)
         extra["value_with_allgather"] = total_envs * a.steps / w2
         extra["ms_per_step_with_allgather"] = w2 / a.steps * 1e3
+
+    if a.many > 0:
+        # K steps per launch (env state stays in registers): same envs, same resident action ring
+        k = min(a.many, actions.shape[0])
+        block = actions[:k].contiguous()
+        reps = max(1, a.steps // k)
+
+        class Many:
+            def run(self, count):
+                for _ in range(count // k):
+                    env.step_many(block)
+        m = Many()
+        m.run(2 * k)
+        wm, evm = timed(m, reps * k)
+        per_step = evm / (reps * k)
+        od = env.obs_dim
+        bytes_step = 16 + 4 * od + 4 + 2 + 200.0 / k     # action in; obs, reward, flags out; state once per launch
+        extra["step_many"] = {
+            "steps_per_launch": k, "value": total_envs * reps * k / wm, "unit": "env-steps/s",
+            "us_per_step": per_step * 1e6,
+            "algorithmic_bytes_per_env_step": bytes_step,
+            "achieved_GBps": bytes_step * n / per_step / 1e9,
+            "note": "cs_step_many: bit-identical to K single-step launches "
+                    "(tests/test_gpu_parity.py::test_step_many_is_bit_identical_to_single_steps); "
+                    "open-loop actions only, so it is reported beside, not as, the headline value"}
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -746,7 +746,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
 // comes in and the observation row, reward and flags go out.  Bit-identical to K
 // launches of step_kernel (both call advance()).
 // ---------------------------------------------------------------------------------
-template <int TASK, int MODE>
+template <int TASK, int MODE, bool LEAN>
 __global__ __launch_bounds__(kBlock) void step_many_kernel(
     char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
@@ -778,13 +778,14 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   e.fe_dirty = false;
   e.prev_sh = 0.0;
   if constexpr (TASK == CS_TASK_LANDER3D) e.prev_sh = (double)tile.load_prev();
-  e.ep_ret = c.stats ? tile.load_ret() : 0.f;
+  const bool opt_stats = !LEAN && c.stats;
+  e.ep_ret = opt_stats ? tile.load_ret() : 0.f;
   e.fe = tile.load_fe();
   StepOpts o;
-  o.stats = c.stats != 0;
-  o.trunc = c.tl_trunc != 0;
+  o.stats = opt_stats;
+  o.trunc = !LEAN && c.tl_trunc;
   o.done_list = false;
-  o.same_step = c.autoreset == CS_AUTORESET_SAME_STEP;
+  o.same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
 #pragma unroll
   for (int k = 0; k < 12; ++k) e.x[k] = decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
   e.gs[0] = g[0];
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   if (e.fe_dirty) tile.store_fe(e.fe);
   tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
   if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)e.prev_sh);
-  if (c.stats) tile.store_ret(e.ep_ret);
+  if (opt_stats) tile.store_ret(e.ep_ret);
 }
 
 // ---------------------------------------------------------------------------------
@@ -939,11 +940,16 @@ hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevStat
                             const float* actions, float* obs, float* reward, uint8_t* term,
                             uint8_t* trunc, hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
-#define CS_LAUNCH(TASK, MODE)                                                                   \
-  if (task == TASK && mode == MODE) {                                                           \
-    hipLaunchKernelGGL((step_many_kernel<TASK, MODE>), grid, block, 0, stream, s.tiles, s.n,     \
-                       actions, obs, reward, term, trunc, num_steps, c, s);                     \
-    return hipGetLastError();                                                                   \
+  const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc;
+#define CS_LAUNCH(TASK, MODE)                                                                    \
+  if (task == TASK && mode == MODE) {                                                            \
+    if (lean)                                                                                    \
+      hipLaunchKernelGGL((step_many_kernel<TASK, MODE, true>), grid, block, 0, stream, s.tiles,  \
+                         s.n, actions, obs, reward, term, trunc, num_steps, c, s);               \
+    else                                                                                         \
+      hipLaunchKernelGGL((step_many_kernel<TASK, MODE, false>), grid, block, 0, stream, s.tiles, \
+                         s.n, actions, obs, reward, term, trunc, num_steps, c, s);               \
+    return hipGetLastError();                                                                    \
   }
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)
