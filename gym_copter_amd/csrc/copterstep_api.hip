@@ -197,7 +197,7 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   ctx->layout = cs::make_layout(cfg->state_mode);
   cs::DevState& s = ctx->st;
   s.n = (uint32_t)cfg->num_envs;
-  s.ntiles = (s.n + 255u) / 256u * 4u;  // whole 256-thread workgroups: no lane is ever out of range
+  s.ntiles = (s.n + 255u) / 256u * 4u;  // whole tiles (rounded up to 4): no lane is ever out of range
   const size_t bytes = (size_t)s.ntiles * ctx->layout.tile_bytes;
   // zero-filled tiles: steps 0, status CRASHED, nothing pending; cs_reset makes them live
   if (hipMalloc((void**)&s.tiles, bytes) != hipSuccess ||

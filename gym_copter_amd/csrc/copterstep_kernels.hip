@@ -44,7 +44,7 @@ namespace {
 #define CS_STAMP(slot) ((void)0)
 #endif
 
-constexpr int kBlock = 256;  // 4 wavefronts; one block per CU covers 65 536 envs exactly
+constexpr int kBlock = 64;  // one wavefront = one tile = one workgroup (measured best at 65 536 envs: tools/ab.sh)
 constexpr int kWave = 64;
 
 template <int MODE>
