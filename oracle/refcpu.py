@@ -235,3 +235,84 @@ class TaskOracle:
         self.steps += 1
         obs = np.array(x[:self.obs_dim], dtype=np.float32)
         return obs, reward, self.done, False, {}
+
+
+# ---------------------------------------------------------------------------------------
+# PID heuristic policy ("next" row N1).  Restates the retired upstream controllers
+#   attic/mars/pidcontrollers/__init__.py:12-146  (_PidController, _SetPointPidController,
+#                                                  PositionHold / Descent / AngularVelocity)
+#   attic/mars/lander3d.py:32-36 (wiring), :64-87 (heuristic + mixer)
+# in float64, one env per object.  Pinned bit-for-bit (actions and trajectories) against
+# tests/golden/pid_traces.npz, which was produced by the real controller classes driving the
+# real live Lander (tests/golden/generate_golden.py: run_pid_episode).
+# ---------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class PidGains:
+    rate_kp: float = 1.0          # AngularVelocityPidController(Kp=1.0, Ki=0, Kd=1)
+    rate_ki: float = 0.0
+    rate_kd: float = 1.0
+    rate_windup: float = 6.0      # WINDUP_MAX
+    rate_big: float = 40.0        # BIG_DEGREES_PER_SECOND
+    pos_kp: float = 0.00001       # PositionHoldPidController(Kp=0.00001, Ki=0.1, Kd=4, target=0)
+    pos_ki: float = 0.1
+    pos_kd: float = 4.0
+    pos_target: float = 0.0
+    pos_windup: float = 0.2       # _PidController default windup_max
+    descent_kp: float = 1.15      # DescentPidController(Kp=1.15, Kd=1.33)
+    descent_kd: float = 1.33
+
+
+class _Pid:
+    def __init__(self, kp, ki, kd, windup):
+        self.kp, self.ki, self.kd, self.windup = kp, ki, kd, windup
+        self.last = 0
+        self.err_i = 0
+        self.d1 = 0
+        self.d2 = 0
+
+    def compute(self, target, actual):
+        error = target - actual
+        pterm = error * self.kp
+        iterm = 0
+        if self.ki > 0:
+            v = self.err_i + error
+            self.err_i = -self.windup if v < -self.windup else (self.windup if v > self.windup else v)
+            iterm = self.err_i * self.ki
+        dterm = 0
+        if self.kd > 0:
+            de = error - self.last
+            dterm = (self.d1 + self.d2 + de) * self.kd
+            self.d2 = self.d1
+            self.d1 = de
+            self.last = error
+        return pterm + iterm + dterm
+
+
+class PidHeuristic:
+    """obs[10] (as Python floats) -> 4 motor demands, with the controllers' internal state."""
+
+    def __init__(self, g=PidGains()):
+        self.g = g
+        self.rate_phi = _Pid(g.rate_kp, g.rate_ki, g.rate_kd, g.rate_windup)
+        self.rate_theta = _Pid(g.rate_kp, g.rate_ki, g.rate_kd, g.rate_windup)
+        self.pos_for_roll = _Pid(g.pos_kp, g.pos_ki, g.pos_kd, g.pos_windup)    # upstream's x_poshold_pid, fed y
+        self.pos_for_pitch = _Pid(g.pos_kp, g.pos_ki, g.pos_kd, g.pos_windup)   # upstream's y_poshold_pid, fed x
+        self.big = np.radians(g.rate_big)
+
+    def _rate(self, pid, w):
+        if abs(w) > self.big:          # AngularVelocityPidController.getDemand: reset()
+            pid.err_i = 0
+            pid.last = 0
+        return pid.compute(0, w)
+
+    def _pos(self, pid, x, dx):
+        target_velocity = (self.g.pos_target - x) * 1      # posPid = _PidController(1, 0, 0)
+        return pid.compute(target_velocity, dx)
+
+    def action(self, obs):
+        x, dx, y, dy, z, dz, phi, dphi, theta, dtheta = [float(v) for v in obs[:10]]
+        phi_todo = self._rate(self.rate_phi, dphi) + self._pos(self.pos_for_roll, y, dy)
+        theta_todo = self._rate(self.rate_theta, -dtheta) + self._pos(self.pos_for_pitch, x, dx)
+        descent_todo = z * self.g.descent_kp + dz * self.g.descent_kd
+        t, r, p = (descent_todo + 1) / 2, phi_todo, theta_todo
+        return np.array([t - r - p, t + r + p, t + r - p, t - r + p])

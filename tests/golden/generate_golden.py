@@ -30,6 +30,7 @@ Usage:  python tests/golden/generate_golden.py   (rewrites tests/golden/*.npz)
 """
 
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -319,9 +320,92 @@ def main():
     print("numpy", np.__version__, "reference", REF)
     save("dynamics_traces.npz", d_series(Dynamics, vp))
     save("env_traces.npz", e_series(_Task, Lander, vp))
+    save("pid_traces.npz", p_series(Lander, load_mars_pid()))
     # known-answer constants observed from the reference (used as spot checks)
     meta = dict(numpy_version=np.array(np.__version__), hover_motor=np.float64(hover_motor(vp)))
     np.savez(os.path.join(OUT, "meta.npz"), **meta)
+
+
+
+
+# --------------------------------------------------------------------------
+# P-series: closed loop with the reference's PID heuristic (attic/mars) on the LIVE Lander
+# --------------------------------------------------------------------------
+def load_mars_pid():
+    """attic/mars/pidcontrollers/__init__.py depends on NumPy only."""
+    spec = importlib.util.spec_from_file_location(
+        "mars_pidcontrollers", os.path.join(REF, "attic", "mars", "pidcontrollers", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def run_pid_episode(Lander, pid, seed, steps, altitude=None, gains=None):
+    """The heuristic loop of attic/mars/task.py:134-179 with the controller wiring of
+    attic/mars/lander3d.py:32-36 + heuristic() :64-87 (restated here because that class needs
+    modules that no longer import), driving the live reference Lander.  The observation is
+    handed to the controllers as Python floats and the action is rounded to float32 before
+    env.step (the action space is float32), so a device path can be fed identical numbers."""
+    gains = gains or {}
+    rate = dict(Kp=1.0, Ki=0, Kd=1)
+    rate.update(gains.get("rate", {}))
+    pos = dict(Kp=0.00001, Ki=0.1, Kd=4, target=0)
+    pos.update(gains.get("pos", {}))
+    des = dict(Kp=1.15, Kd=1.33)
+    des.update(gains.get("descent", {}))
+    phi_rate_pid = pid.AngularVelocityPidController(**rate)
+    theta_rate_pid = pid.AngularVelocityPidController(**rate)
+    x_poshold_pid = pid.PositionHoldPidController(**pos)
+    y_poshold_pid = pid.PositionHoldPidController(**pos)
+    descent_pid = pid.DescentPidController(**des)
+
+    env = Lander()
+    if altitude is not None:
+        env.set_altitude(altitude)
+    np.random.seed(seed)
+    obs, _ = env.reset()
+    d = env.dynamics
+    force = f32r(d._perturb * d.M)
+    d.perturb(force.copy())
+    rec = dict(obs=[], reward=[], done=[], action=[], x=[])
+    for t in range(steps):
+        x, dx, y, dy, z, dz, phi, dphi, theta, dtheta = [float(v) for v in obs]
+        phi_rate_todo = phi_rate_pid.getDemand(dphi)
+        y_pos_todo = x_poshold_pid.getDemand(y, dy)
+        phi_todo = phi_rate_todo + y_pos_todo
+        theta_rate_todo = theta_rate_pid.getDemand(-dtheta)
+        x_pos_todo = y_poshold_pid.getDemand(x, dx)
+        theta_todo = theta_rate_todo + x_pos_todo
+        descent_todo = descent_pid.getDemand(z, dz)
+        tt, r, p = (descent_todo + 1) / 2, phi_todo, theta_todo
+        action = f32r([tt - r - p, tt + r + p, tt + r - p, tt - r + p])
+        obs, reward, done, _, _ = env.step(action)
+        rec["obs"].append(obs)
+        rec["reward"].append(float(reward))
+        rec["done"].append(bool(done))
+        rec["action"].append(action)
+        rec["x"].append(d._x.copy())
+        if done:
+            break
+    return dict(seed=np.int64(seed), altitude=np.float64(env.initial_altitude), force=force[:3],
+                obs=np.asarray(rec["obs"], dtype=np.float32), reward=np.asarray(rec["reward"]),
+                done=np.asarray(rec["done"]), action=np.asarray(rec["action"]), x=np.asarray(rec["x"]),
+                rate_gains=np.array([rate["Kp"], rate["Ki"], rate["Kd"]], dtype=np.float64),
+                pos_gains=np.array([pos["Kp"], pos["Ki"], pos["Kd"], pos["target"]], dtype=np.float64),
+                descent_gains=np.array([des["Kp"], des["Kd"]], dtype=np.float64))
+
+
+def p_series(Lander, pid):
+    cases = {}
+    # reference gains (tuned upstream for the retired mars dynamics: bang-bang on the live model)
+    cases["P01_pid_default"] = run_pid_episode(Lander, pid, seed=20, steps=400)
+    cases["P02_pid_default_low"] = run_pid_episode(Lander, pid, seed=21, steps=400, altitude=2.0)
+    # gains scaled to the live vehicle (hover motor value 0.01656): a descent that lands
+    soft = dict(descent=dict(Kp=0.004, Kd=0.012), rate=dict(Kp=0.002, Kd=0.002),
+                pos=dict(Kp=0.0002, Ki=0.0, Kd=0.0))
+    cases["P03_pid_soft"] = run_pid_episode(Lander, pid, seed=22, steps=1100, gains=soft)
+    cases["P04_pid_soft"] = run_pid_episode(Lander, pid, seed=23, steps=1100, gains=soft)
+    return cases
 
 
 if __name__ == "__main__":

@@ -70,3 +70,26 @@ def test_known_answers():
     assert g["status"][-1] == LANDED and g["done"][-1]
     # step limit fires on the 1000th user step
     assert ENV["E06_lander_hover_limit"]["first_done"] == 999
+
+
+PID = load_cases("pid_traces.npz")
+
+
+@pytest.mark.parametrize("name", PID.names())
+def test_pid_heuristic_closed_loop_bit_exact(name):
+    """oracle PidHeuristic + TaskOracle reproduce, bit for bit, the episode the reference's own
+    controller classes (attic/mars/pidcontrollers) flew on the reference's live Lander."""
+    from oracle.refcpu import PidGains, PidHeuristic
+    g = PID[name]
+    rk, pk, dk = g["rate_gains"], g["pos_gains"], g["descent_gains"]
+    gains = PidGains(rate_kp=rk[0], rate_ki=rk[1], rate_kd=rk[2], pos_kp=pk[0], pos_ki=pk[1],
+                     pos_kd=pk[2], pos_target=pk[3], descent_kp=dk[0], descent_kd=dk[1])
+    pol = PidHeuristic(gains)
+    env = TaskOracle("lander3d", TaskParams(initial_altitude=float(g["altitude"])))
+    obs = env.reset(force_xyz=g["force"])
+    for t in range(len(g["reward"])):
+        a = pol.action(obs).astype(np.float32).astype(np.float64)    # the action space is float32
+        assert np.array_equal(a, g["action"][t]), (name, t)
+        obs, r, done, _, _ = env.step(a)
+        assert np.array_equal(obs, g["obs"][t]) and r == g["reward"][t] and done == g["done"][t], (name, t)
+        assert np.array_equal(env.body.x, g["x"][t]), (name, t)
