@@ -58,6 +58,13 @@ class StepIO(C.Structure):
 
 # every symbol include/copterstep.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+class PidGains(C.Structure):
+    """cs_pid_gains (include/copterstep.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32)] + \
+               [(k, C.c_double) for k in ("rate_kp rate_ki rate_kd rate_windup rate_big_deg pos_kp pos_ki "
+                                          "pos_kd pos_target pos_windup descent_kp descent_kd").split()]
+
+
 SYMBOLS = {
     "cs_version": (C.c_int, []),
     "cs_last_error": (C.c_char_p, []),
@@ -73,6 +80,11 @@ SYMBOLS = {
     "cs_step_ex": (C.c_int, [_P, C.POINTER(StepIO), _P]),
     "cs_step_many": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_set_motors": (C.c_int, [_P, _P, _P]),
+    "cs_pid_gains_init": (C.c_int, [_P]),
+    "cs_pid_configure": (C.c_int, [_P, _P]),
+    "cs_pid_get_state": (C.c_int, [_P, _P, _P]),
+    "cs_pid_set_state": (C.c_int, [_P, _P, _P]),
+    "cs_rollout_pid": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_get_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
     "cs_set_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
 }

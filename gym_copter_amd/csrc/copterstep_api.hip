@@ -15,6 +15,11 @@ struct cs_ctx {
   cs_config cfg;
   cs::DevState st;
   cs::Layout layout;
+  // on-device PID heuristic (cs_pid_configure): gains + [16][pid_stride] float64 controller state
+  bool pid_on = false;
+  cs::PidConst pid{};
+  double* pid_state = nullptr;
+  uint32_t pid_stride = 0;
 };
 
 namespace {
@@ -228,6 +233,7 @@ int cs_destroy(cs_ctx* ctx) {
   if (ctx == nullptr) return CS_OK;
   (void)hipSetDevice(ctx->cfg.device);
   if (ctx->st.tiles) (void)hipFree(ctx->st.tiles);
+  if (ctx->pid_state) (void)hipFree(ctx->pid_state);
   delete ctx;
   return CS_OK;
 }
@@ -261,7 +267,8 @@ int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, f
   if (check_ctx(ctx)) return CS_ERR_ARG;
   const cs::DevConst c = make_const(ctx);
   hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
-                                  force_xyz_dev, obs_dev, (hipStream_t)stream);
+                                  force_xyz_dev, obs_dev, ctx->pid_state, ctx->pid_stride,
+                                  (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_reset: kernel launch");
   return CS_OK;
 }
@@ -302,9 +309,108 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_step_many: num_steps must be >= 1");
   const cs::DevConst c = make_const(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
-                                      actions_dev, obs_dev, reward_dev, terminated_dev,
-                                      truncated_dev, (hipStream_t)stream);
+                                      const_cast<float*>(actions_dev), obs_dev, reward_dev,
+                                      terminated_dev, truncated_dev, nullptr, nullptr, 0,
+                                      (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_step_many: kernel launch");
+  return CS_OK;
+}
+
+int cs_pid_gains_init(cs_pid_gains* g) {
+  if (g == nullptr) return fail(CS_ERR_ARG, "cs_pid_gains_init: null argument");
+  *g = cs_pid_gains{};
+  g->struct_size = (uint32_t)sizeof(cs_pid_gains);
+  // attic/mars/lander3d.py:32-36 and the class defaults of attic/mars/pidcontrollers
+  g->rate_kp = 1.0;
+  g->rate_ki = 0.0;
+  g->rate_kd = 1.0;
+  g->rate_windup = 6.0;
+  g->rate_big_deg = 40.0;
+  g->pos_kp = 0.00001;
+  g->pos_ki = 0.1;
+  g->pos_kd = 4.0;
+  g->pos_target = 0.0;
+  g->pos_windup = 0.2;
+  g->descent_kp = 1.15;
+  g->descent_kd = 1.33;
+  return CS_OK;
+}
+
+int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* g) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (g == nullptr || g->struct_size != sizeof(cs_pid_gains))
+    return fail(CS_ERR_ARG, "cs_pid_configure: gains missing or struct_size mismatch");
+  CS_HIP(hipSetDevice(ctx->cfg.device));
+  if (ctx->pid_state == nullptr) {
+    // one float64 row per controller field, padded like the tiles so that lanes past the
+    // last env have somewhere harmless to read and write
+    const uint32_t stride = ctx->st.ntiles * 64u;
+    const size_t bytes = (size_t)16 * stride * sizeof(double);
+    double* p = nullptr;
+    CS_HIP(hipMalloc((void**)&p, bytes));
+    hipError_t e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      (void)hipFree(p);
+      return hip_fail(e, "cs_pid_configure: zero-fill");
+    }
+    ctx->pid_state = p;
+    ctx->pid_stride = stride;
+  }
+  const double kPi = 3.14159265358979323846;
+  cs::PidConst& p = ctx->pid;
+  p.rate_kp = g->rate_kp;
+  p.rate_ki = g->rate_ki;
+  p.rate_kd = g->rate_kd;
+  p.rate_windup = g->rate_windup;
+  p.rate_big = g->rate_big_deg * (kPi / 180.0);  // np.radians
+  p.pos_kp = g->pos_kp;
+  p.pos_ki = g->pos_ki;
+  p.pos_kd = g->pos_kd;
+  p.pos_target = g->pos_target;
+  p.pos_windup = g->pos_windup;
+  p.descent_kp = g->descent_kp;
+  p.descent_kd = g->descent_kd;
+  ctx->pid_on = true;
+  return CS_OK;
+}
+
+int cs_pid_get_state(cs_ctx* ctx, double* state_host, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_pid_get_state: call cs_pid_configure first");
+  if (state_host == nullptr) return fail(CS_ERR_ARG, "cs_pid_get_state: null buffer");
+  const size_t n = (size_t)ctx->cfg.num_envs;
+  CS_HIP(hipMemcpy2DAsync(state_host, n * sizeof(double), ctx->pid_state,
+                          (size_t)ctx->pid_stride * sizeof(double), n * sizeof(double), 16,
+                          hipMemcpyDeviceToHost, (hipStream_t)stream));
+  CS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return CS_OK;
+}
+
+int cs_pid_set_state(cs_ctx* ctx, const double* state_host, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_pid_set_state: call cs_pid_configure first");
+  if (state_host == nullptr) return fail(CS_ERR_ARG, "cs_pid_set_state: null buffer");
+  const size_t n = (size_t)ctx->cfg.num_envs;
+  CS_HIP(hipMemcpy2DAsync(ctx->pid_state, (size_t)ctx->pid_stride * sizeof(double), state_host,
+                          n * sizeof(double), n * sizeof(double), 16, hipMemcpyHostToDevice,
+                          (hipStream_t)stream));
+  CS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return CS_OK;
+}
+
+int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
+                   float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
+                   void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_rollout_pid: call cs_pid_configure first");
+  if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_pid: num_steps must be >= 1");
+  const cs::DevConst c = make_const(ctx);
+  hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
+                                      actions_out_dev, obs_dev, reward_dev, terminated_dev,
+                                      truncated_dev, &ctx->pid, ctx->pid_state, ctx->pid_stride,
+                                      (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_rollout_pid: kernel launch");
   return CS_OK;
 }
 

@@ -115,6 +115,13 @@ inline void trig_constants(double (&t)[16]) {
   for (int i = 0; i < 16; ++i) t[i] = v[i];
 }
 
+// Gains of the on-device PID landing heuristic (attic/mars/lander3d.py:32-36), float64.
+struct PidConst {
+  double rate_kp, rate_ki, rate_kd, rate_windup, rate_big;  // rate_big in rad/s
+  double pos_kp, pos_ki, pos_kd, pos_target, pos_windup;
+  double descent_kp, descent_kd;
+};
+
 struct DevState {
   char* tiles;      // ntiles * tile_bytes
   uint32_t n;       // envs
@@ -126,13 +133,16 @@ struct DevState {
 
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                        const cs_step_io& io, hipStream_t stream);
+// pid == nullptr: open loop, `actions` is the [K,N,4] input.  Otherwise closed loop under the
+// on-device PID heuristic: `actions` is an optional [K,N,4] output, `pid_state` is required.
 hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
-                            const float* actions, float* obs, float* reward, uint8_t* term,
-                            uint8_t* trunc, hipStream_t stream);
+                            float* actions, float* obs, float* reward, uint8_t* term,
+                            uint8_t* trunc, const PidConst* pid, double* pid_state,
+                            uint32_t pid_stride, hipStream_t stream);
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,
                              hipStream_t stream);
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,
                         const uint8_t* mask, const float* force_xyz, float* obs,
-                        hipStream_t stream);
+                        double* pid_state, uint32_t pid_stride, hipStream_t stream);
 
 }  // namespace cs

@@ -504,6 +504,7 @@ struct StepOut {
   float row[OBS];  // observation returned by this step
   double reward;
   bool term, trunc;
+  bool did_reset;  // the env started a new episode inside this step
 };
 
 struct StepOpts {  // uniform switches (compiled out in LEAN builds)
@@ -634,6 +635,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const StepOpts& o, En
   out.reward = reward;
   out.term = term;
   out.trunc = trunc;
+  out.did_reset = do_reset;
 }
 
 __device__ __forceinline__ uint32_t pack_meta(int steps, int fs, bool pend, bool reset_pending) {
@@ -740,17 +742,88 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// On-device PID landing heuristic (the retired upstream controllers,
+// attic/mars/pidcontrollers/__init__.py:12-146, wired as attic/mars/lander3d.py:64-87).
+// Same float64 operation order as the Python classes: observation float32 -> float64,
+// controller arithmetic float64, action rounded to float32 (the action space's dtype).
+// Controller state per env: 4 controllers x {errorI, lastError, deltaError1, deltaError2}.
+// ---------------------------------------------------------------------------------
+struct PidCtl {
+  double err_i, last, d1, d2;
+};
+
+// _PidController.compute (pidcontrollers/__init__.py:33-63)
+__device__ __forceinline__ double pid_compute(PidCtl& s, double kp, double ki, double kd,
+                                              double windup, double target, double actual) {
+#pragma clang fp contract(off)  // the controller arithmetic is reproduced bit for bit
+  const double error = target - actual;
+  double acc = error * kp;
+  double iterm = 0.0;
+  if (ki > 0.0) {
+    const double v = s.err_i + error;
+    s.err_i = v < -windup ? -windup : (v > windup ? windup : v);
+    iterm = s.err_i * ki;
+  }
+  acc = acc + iterm;
+  double dterm = 0.0;
+  if (kd > 0.0) {
+    const double de = error - s.last;
+    dterm = ((s.d1 + s.d2) + de) * kd;
+    s.d2 = s.d1;
+    s.d1 = de;
+    s.last = error;
+  }
+  return acc + dterm;
+}
+
+// AngularVelocityPidController.getDemand (:135-146): a wild rate restarts the controller
+__device__ __forceinline__ double pid_rate(const PidConst& p, PidCtl& s, double w) {
+  if (fabs(w) > p.rate_big) {
+    s.err_i = 0.0;
+    s.last = 0.0;
+  }
+  return pid_compute(s, p.rate_kp, p.rate_ki, p.rate_kd, p.rate_windup, 0.0, w);
+}
+
+// PositionHoldPidController.getDemand (:94-108): unit-gain position loop -> velocity loop
+__device__ __forceinline__ double pid_pos(const PidConst& p, PidCtl& s, double x, double dx) {
+#pragma clang fp contract(off)  // the controller arithmetic is reproduced bit for bit
+  const double target_velocity = (p.pos_target - x) * 1.0;
+  return pid_compute(s, p.pos_kp, p.pos_ki, p.pos_kd, p.pos_windup, target_velocity, dx);
+}
+
+// heuristic + mixer (attic/mars/lander3d.py:64-87)
+template <int OBS>
+__device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[4],
+                                             const float (&obs)[OBS]) {
+#pragma clang fp contract(off)  // the controller arithmetic is reproduced bit for bit
+  const double x = obs[0], dx = obs[1], y = obs[2], dy = obs[3], z = obs[4], dz = obs[5];
+  const double dphi = obs[7], dtheta = obs[9];
+  const double r = pid_rate(p, ctl[0], dphi) + pid_pos(p, ctl[2], y, dy);
+  const double q = pid_rate(p, ctl[1], -dtheta) + pid_pos(p, ctl[3], x, dx);
+  const double t = ((z * p.descent_kp + dz * p.descent_kd) + 1.0) / 2.0;
+  return make_float4((float)((t - r) - q), (float)((t + r) + q), (float)((t + r) - q),
+                     (float)((t - r) + q));
+}
+
+// ---------------------------------------------------------------------------------
 // K consecutive steps in one launch (open-loop: the K action batches are resident).
 // The env stays in registers between steps: state, guards, meta, prev_shaping and the FE
 // group cross HBM once per launch instead of once per step; per step only the action row
 // comes in and the observation row, reward and flags go out.  Bit-identical to K
 // launches of step_kernel (both call advance()).
 // ---------------------------------------------------------------------------------
-template <int TASK, int MODE, bool LEAN>
+//
+// POLICY: closed loop instead -- each step's action comes from the on-device PID heuristic
+// applied to the previous observation row (`actions_dev` is then an optional OUTPUT [K,N,4]);
+// the controller state lives in `pid_state` ([16][pid_stride] float64) between launches and is
+// zeroed whenever its env starts a new episode.
+template <int TASK, int MODE, bool LEAN, bool POLICY>
 __global__ __launch_bounds__(kBlock) void step_many_kernel(
-    char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
+    char* const tiles, const uint32_t n_envs, float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
-    const int num_steps, const DevConst c, const DevState s_rest) {
+    const int num_steps, const DevConst c, const DevState s_rest, const PidConst pc,
+    double* const pid_state, const uint32_t pid_stride) {
   using T = typename ModeOf<MODE>::T;
   DevState s = s_rest;
   s.tiles = tiles;
@@ -801,14 +874,43 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   io.done_count_dev = io.done_ids_dev = io.done_length_dev = nullptr;
 
   const uint32_t ia = (valid ? i : 0u) << 4;
-  float4 act = *at32<const float4>(actions_dev, ia);
+  float4 act = make_float4(0.f, 0.f, 0.f, 0.f);
+  PidCtl ctl[4];
+  float seen[OBS];  // the observation the policy acts on: what the previous step returned
+  if constexpr (POLICY) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ctl[j].err_i = pid_state[(size_t)(4 * j + 0) * pid_stride + i];
+      ctl[j].last = pid_state[(size_t)(4 * j + 1) * pid_stride + i];
+      ctl[j].d1 = pid_state[(size_t)(4 * j + 2) * pid_stride + i];
+      ctl[j].d2 = pid_state[(size_t)(4 * j + 3) * pid_stride + i];
+    }
+#pragma unroll
+    for (int j = 0; j < OBS; ++j) seen[j] = (float)e.x[j];
+  } else {
+    act = *at32<const float4>(actions_dev, ia);
+  }
   for (int k = 0; k < num_steps; ++k) {
     // rows of step k (64-bit uniform offsets: K * N can exceed 32 bits)
     const size_t row = (size_t)k * n;
-    const int kn = (k + 1 < num_steps) ? k + 1 : k;
-    const float4 act_next = *at32<const float4>(actions_dev + (size_t)kn * n * 4, ia);  // prefetch
+    float4 act_next = act;
+    if constexpr (POLICY) {
+      act = pid_policy<OBS>(pc, ctl, seen);
+      if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia) = act;
+    } else {
+      const int kn = (k + 1 < num_steps) ? k + 1 : k;
+      act_next = *at32<const float4>(actions_dev + (size_t)kn * n * 4, ia);  // prefetch
+    }
     StepOut<OBS> out;
     advance<TASK, MODE, OBS, false>(c, o, e, act, io, i, lane, valid, tile, out);
+    if constexpr (POLICY) {
+#pragma unroll
+      for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
+      if (out.did_reset) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
+      }
+    }
     if (valid) {
       if (reward_dev) *at32<float>(reward_dev + row, i << 2) = (float)out.reward;
       if (terminated_dev) *at32<uint8_t>(terminated_dev + row, i) = out.term ? 1 : 0;
@@ -822,6 +924,15 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
   if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)e.prev_sh);
   if (opt_stats) tile.store_ret(e.ep_ret);
+  if constexpr (POLICY) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pid_state[(size_t)(4 * j + 0) * pid_stride + i] = ctl[j].err_i;
+      pid_state[(size_t)(4 * j + 1) * pid_stride + i] = ctl[j].last;
+      pid_state[(size_t)(4 * j + 2) * pid_stride + i] = ctl[j].d1;
+      pid_state[(size_t)(4 * j + 3) * pid_stride + i] = ctl[j].d2;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -868,7 +979,9 @@ template <int TASK, int MODE>
 __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const DevState s,
                                                        const uint8_t* __restrict__ mask,
                                                        const float* __restrict__ force_xyz,
-                                                       float* __restrict__ obs) {
+                                                       float* __restrict__ obs,
+                                                       double* __restrict__ pid_state,
+                                                       const uint32_t pid_stride) {
   using T = typename ModeOf<MODE>::T;
   constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
   const uint32_t n = s.n;
@@ -876,6 +989,10 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
   if (i >= n) return;
   const TileIO<MODE> tile(s, i);
   if (mask == nullptr || mask[i] != 0) {
+    if (pid_state != nullptr) {  // a new episode flies with fresh controllers
+#pragma unroll
+      for (int j = 0; j < 16; ++j) pid_state[(size_t)j * pid_stride + i] = 0.0;
+    }
     double f[3];
     const uint32_t episode = TileIO<MODE>::episode_of(tile.load_fe());
     if (force_xyz != nullptr) {
@@ -937,19 +1054,30 @@ hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
 }
 
 hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
-                            const float* actions, float* obs, float* reward, uint8_t* term,
-                            uint8_t* trunc, hipStream_t stream) {
+                            float* actions, float* obs, float* reward, uint8_t* term,
+                            uint8_t* trunc, const PidConst* pid, double* pid_state,
+                            uint32_t pid_stride, hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
   const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc;
-#define CS_LAUNCH(TASK, MODE)                                                                    \
-  if (task == TASK && mode == MODE) {                                                            \
-    if (lean)                                                                                    \
-      hipLaunchKernelGGL((step_many_kernel<TASK, MODE, true>), grid, block, 0, stream, s.tiles,  \
-                         s.n, actions, obs, reward, term, trunc, num_steps, c, s);               \
-    else                                                                                         \
-      hipLaunchKernelGGL((step_many_kernel<TASK, MODE, false>), grid, block, 0, stream, s.tiles, \
-                         s.n, actions, obs, reward, term, trunc, num_steps, c, s);               \
-    return hipGetLastError();                                                                    \
+  const PidConst pc = pid ? *pid : PidConst{};
+#define CS_ARGS s.tiles, s.n, actions, obs, reward, term, trunc, num_steps, c, s, pc, pid_state, pid_stride
+#define CS_LAUNCH(TASK, MODE)                                                                       \
+  if (task == TASK && mode == MODE) {                                                               \
+    if (pid != nullptr) {                                                                           \
+      if (lean)                                                                                     \
+        hipLaunchKernelGGL((step_many_kernel<TASK, MODE, true, true>), grid, block, 0, stream,      \
+                           CS_ARGS);                                                                \
+      else                                                                                          \
+        hipLaunchKernelGGL((step_many_kernel<TASK, MODE, false, true>), grid, block, 0, stream,     \
+                           CS_ARGS);                                                                \
+    } else if (lean) {                                                                              \
+      hipLaunchKernelGGL((step_many_kernel<TASK, MODE, true, false>), grid, block, 0, stream,       \
+                         CS_ARGS);                                                                  \
+    } else {                                                                                        \
+      hipLaunchKernelGGL((step_many_kernel<TASK, MODE, false, false>), grid, block, 0, stream,      \
+                         CS_ARGS);                                                                  \
+    }                                                                                               \
+    return hipGetLastError();                                                                       \
   }
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)
@@ -958,6 +1086,7 @@ hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevStat
   CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_RN)
   CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F64)
 #undef CS_LAUNCH
+#undef CS_ARGS
   return hipErrorInvalidValue;
 }
 
@@ -978,12 +1107,12 @@ hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, con
 
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,
                         const uint8_t* mask, const float* force_xyz, float* obs,
-                        hipStream_t stream) {
+                        double* pid_state, uint32_t pid_stride, hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
 #define CS_LAUNCH(TASK, MODE)                                                          \
   if (task == TASK && mode == MODE) {                                                  \
     hipLaunchKernelGGL((reset_kernel<TASK, MODE>), grid, block, 0, stream, c, s, mask, \
-                       force_xyz, obs);                                                \
+                       force_xyz, obs, pid_state, pid_stride);                         \
     return hipGetLastError();                                                          \
   }
   CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)

@@ -248,6 +248,66 @@ class CopterVecEnv:
         self._keep = a
         return buf[0], buf[1], buf[2].view(torch.bool), buf[3].view(torch.bool)
 
+    # -- closed-loop rollouts under the on-device PID landing heuristic ----------------
+    def configure_pid(self, **gains):
+        """Install the PID landing heuristic (attic/mars/lander3d.py:32-36, :64-87 with the
+        controllers of attic/mars/pidcontrollers).  Keywords override upstream's gains:
+        rate_kp, rate_ki, rate_kd, rate_windup, rate_big_deg, pos_kp, pos_ki, pos_kd, pos_target,
+        pos_windup, descent_kp, descent_kd.  Returns the gains in effect."""
+        self._check_open()
+        g = _lib.PidGains()
+        _lib.check(self._lib.cs_pid_gains_init(C.byref(g)))
+        for k, v in gains.items():
+            if k in ("struct_size", "reserved") or not hasattr(g, k):
+                raise TypeError("unknown PID gain %r" % (k,))
+            setattr(g, k, float(v))
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_pid_configure(self._ctx, C.byref(g)))
+        self._pid = True
+        return {k: getattr(g, k) for k, _ in g._fields_[2:]}
+
+    def rollout_pid(self, num_steps, return_actions=False):
+        """K closed-loop steps in ONE kernel launch: every step's action is the PID heuristic of
+        the observation the previous step returned.  -> (obs [K,N,obs_dim], reward [K,N],
+        terminated [K,N], truncated [K,N]) and, with return_actions, the float32 actions [K,N,4]
+        appended."""
+        self._check_open()
+        if not getattr(self, "_pid", False):
+            self.configure_pid()
+        torch = _torch()
+        K, n = int(num_steps), self.num_envs
+        buf = getattr(self, "_roll", None)
+        if buf is None or buf[0].shape[0] != K:
+            buf = (torch.empty((K, n, self.obs_dim), dtype=torch.float32, device=self.device),
+                   torch.empty((K, n), dtype=torch.float32, device=self.device),
+                   torch.empty((K, n), dtype=torch.uint8, device=self.device),
+                   torch.empty((K, n), dtype=torch.uint8, device=self.device),
+                   torch.empty((K, n, 4), dtype=torch.float32, device=self.device))
+            self._roll = buf
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_rollout_pid(self._ctx, K, p(buf[4]) if return_actions else None,
+                                                p(buf[0]), p(buf[1]), p(buf[2]), p(buf[3]), self._stream()))
+        out = (buf[0], buf[1], buf[2].view(torch.bool), buf[3].view(torch.bool))
+        return out + (buf[4],) if return_actions else out
+
+    def pid_get_state(self):
+        """Controller state as a host array [16, N] float64 (rows: see include/copterstep.h)."""
+        self._check_open()
+        out = np.empty((16, self.num_envs), dtype=np.float64)
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_pid_get_state(self._ctx, out.ctypes.data_as(C.c_void_p), self._stream()))
+        return out
+
+    def pid_set_state(self, state):
+        self._check_open()
+        st = np.ascontiguousarray(np.asarray(state, dtype=np.float64).reshape(16, self.num_envs))
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_pid_set_state(self._ctx, st.ctypes.data_as(C.c_void_p), self._stream()))
+
     def close(self):                                            # task.py:139-143
         if not self.closed and self._ctx:
             self._lib.cs_destroy(self._ctx)

@@ -154,6 +154,39 @@ int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream);
 int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float* obs_dev,
                  float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
 
+/* ---- closed-loop rollouts under the on-device PID landing heuristic -----------------------
+ * Replaces, per env, the retired upstream controllers and their wiring:
+ *   attic/mars/pidcontrollers/__init__.py:12-146  _PidController.compute, PositionHold /
+ *                                                 Descent / AngularVelocity getDemand
+ *   attic/mars/lander3d.py:32-36, :64-87          gains, heuristic(), mixer
+ * Defaults of cs_pid_gains_init() are upstream's (rate 1/0/1, windup 6, 40 deg/s;
+ * position 1e-5/0.1/4, target 0, windup 0.2; descent 1.15/1.33). */
+typedef struct cs_pid_gains {
+  uint32_t struct_size; /* sizeof(cs_pid_gains) */
+  uint32_t reserved;
+  double rate_kp, rate_ki, rate_kd, rate_windup, rate_big_deg; /* AngularVelocityPidController */
+  double pos_kp, pos_ki, pos_kd, pos_target, pos_windup;       /* PositionHoldPidController */
+  double descent_kp, descent_kd;                               /* DescentPidController */
+} cs_pid_gains;
+
+int cs_pid_gains_init(cs_pid_gains* gains);
+/* Install gains and (first call) allocate the controller state: 16 float64 per env, zeroed =
+ * freshly constructed controllers.  Synchronous; call outside stream capture.  From then on
+ * cs_reset() and the auto-reset inside rollouts also restart the controllers of the envs they
+ * reset. */
+int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* gains);
+/* Controller state <-> HOST [16,N] float64: row 4*c+f, controller c in {roll rate, pitch rate,
+ * roll position (fed y), pitch position (fed x)}, field f in {errorI, lastError, deltaError1,
+ * deltaError2}.  Synchronises `stream`. */
+int cs_pid_get_state(cs_ctx* ctx, double* state_host, void* stream);
+int cs_pid_set_state(cs_ctx* ctx, const double* state_host, void* stream);
+/* K closed-loop steps in ONE launch: action_k = heuristic(observation returned by step k-1,
+ * or the current observation for k = 0), rounded to float32, then exactly cs_step().  Outputs as
+ * cs_step_many, plus actions_out_dev [K,N,4] (nullable).  Only the kernel launch is enqueued. */
+int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
+                   float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
+                   void* stream);
+
 /* Physics only: `substeps` x Dynamics.setMotors(motors[i]) on every env, raw motor
  * values (no clipping, no task logic). */
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream);

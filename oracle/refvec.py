@@ -327,11 +327,76 @@ class VecOracle:
         self.last_length = self.ep_length[fin].copy()
         self.final_obs = obs.copy()
 
+        self.last_reset = np.zeros(n, dtype=bool)      # lanes whose episode restarted in this step
         if self.autoreset == AUTORESET_NEXT_STEP:
             self._reset_lanes(resetting)
             obs[resetting] = self.observe()[resetting]
             self.done_pending = fin
+            self.last_reset = resetting
         elif self.autoreset == AUTORESET_SAME_STEP:
             self._reset_lanes(fin)
             obs[fin] = self.observe()[fin]
+            self.last_reset = fin
         return obs, reward, term, trunc
+
+
+class VecPid:
+    """oracle.refcpu.PidHeuristic over a batch (same float64 operation order, lane by lane):
+    attic/mars/pidcontrollers/__init__.py:12-146 + attic/mars/lander3d.py:64-87.  Controller state
+    per env: 4 controllers x (errorI, lastError, deltaError1, deltaError2).  `reset(mask)` gives
+    the masked envs fresh controllers (a new episode)."""
+
+    ROLL_RATE, PITCH_RATE, ROLL_POS, PITCH_POS = range(4)
+
+    def __init__(self, num_envs, gains=None):
+        from oracle.refcpu import PidGains
+        self.g = gains or PidGains()
+        self.n = num_envs
+        self.state = np.zeros((4, 4, num_envs))        # [controller][errI, last, d1, d2][env]
+        self.big = np.radians(self.g.rate_big)
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.state[:] = 0
+        else:
+            self.state[:, :, np.asarray(mask).astype(bool)] = 0
+
+    def _compute(self, c, kp, ki, kd, windup, target, actual):
+        st = self.state[c]
+        error = target - actual
+        out = error * kp
+        iterm = np.zeros(self.n)
+        if ki > 0:
+            st[0] = np.clip(st[0] + error, -windup, windup)
+            iterm = st[0] * ki
+        out = out + iterm
+        dterm = np.zeros(self.n)
+        if kd > 0:
+            de = error - st[1]
+            dterm = ((st[2] + st[3]) + de) * kd
+            st[3] = st[2].copy()
+            st[2] = de
+            st[1] = error
+        return out + dterm
+
+    def _rate(self, c, w):
+        g = self.g
+        wild = np.abs(w) > self.big
+        self.state[c][0][wild] = 0
+        self.state[c][1][wild] = 0
+        return self._compute(c, g.rate_kp, g.rate_ki, g.rate_kd, g.rate_windup, 0.0, w)
+
+    def _pos(self, c, x, dx):
+        g = self.g
+        return self._compute(c, g.pos_kp, g.pos_ki, g.pos_kd, g.pos_windup, (g.pos_target - x) * 1, dx)
+
+    def action(self, obs):
+        """obs [n, >=10] float32 -> [n, 4] float32 motor demands (unclipped)."""
+        o = np.asarray(obs, dtype=np.float32).astype(np.float64).T
+        x, dx, y, dy, z, dz, phi, dphi, theta, dtheta = o[:10]
+        r = self._rate(self.ROLL_RATE, dphi) + self._pos(self.ROLL_POS, y, dy)
+        p = self._rate(self.PITCH_RATE, -dtheta) + self._pos(self.PITCH_POS, x, dx)
+        t = ((z * self.g.descent_kp + dz * self.g.descent_kd) + 1) / 2
+        a = np.stack([t - r - p, t + r + p, t + r - p, t - r + p], axis=1)
+        with np.errstate(over="ignore"):
+            return a.astype(np.float32)

@@ -552,3 +552,120 @@ def test_step_many_is_bit_identical_to_single_steps(task, mode, autoreset):
         assert_state_close(many, orc, 2e-6 if mode != "float64" else 1e-9)
     many.close()
     single.close()
+
+
+# ---------------------------------------------------------------------------------------
+# closed-loop rollouts under the on-device PID heuristic (cs_rollout_pid)
+# ---------------------------------------------------------------------------------------
+PID = load_cases("pid_traces.npz")
+PID_GAINS = {
+    "upstream": {},
+    "soft": dict(rate_kp=0.002, rate_kd=0.002, pos_kp=0.0002, pos_ki=0.0, pos_kd=0.0,
+                 descent_kp=0.004, descent_kd=0.012),
+    "integral": dict(rate_ki=0.05, pos_ki=0.3, rate_big_deg=5.0),
+}
+
+
+def _oracle_gains(kw):
+    from oracle.refcpu import PidGains
+    return PidGains(**{("rate_big" if k == "rate_big_deg" else k): v for k, v in kw.items()})
+
+
+@pytest.mark.parametrize("gains", list(PID_GAINS))
+@pytest.mark.parametrize("task,mode,autoreset", [("lander3d", "float32", "next_step"),
+                                                 ("lander3d", "float64", "same_step"),
+                                                 ("lander3d", "float32_rn", "disabled"),
+                                                 ("hover3d", "float32", "next_step")])
+def test_rollout_pid_policy_is_bit_exact(task, mode, autoreset, gains):
+    """The on-device controllers against the oracle's (VecPid), bit for bit: a twin device env is
+    stepped one cs_step at a time with the ORACLE's actions computed from the observations the
+    device returned.  Both envs share the HIP physics, so every action, every output of every step,
+    the final env state and the final controller state must be identical -- any float64 operation
+    of the device policy that differed from upstream's order would show up in the actions."""
+    import torch
+    from oracle.refvec import VecPid
+    n, K = 2500, 40
+    kw = PID_GAINS[gains]
+    roll, _ = make_pair(task, n, mode, autoreset=autoreset, seed=21, episode_stats=True)
+    twin, _ = make_pair(task, n, mode, autoreset=autoreset, seed=21, episode_stats=True)
+    roll.configure_pid(**kw)
+    pid = VecPid(n, _oracle_gains(kw))
+    obs, _ = roll.reset()
+    obs_t, _ = twin.reset()
+    seen = to_np(obs_t).copy()
+    resets = 0
+    for chunk in range(4):
+        obs_k, rew_k, term_k, trunc_k, act_k = roll.rollout_pid(K, return_actions=True)
+        for k in range(K):
+            a = pid.action(seen)
+            assert np.array_equal(a, to_np(act_k[k]), equal_nan=True), (chunk, k)
+            before = twin.get_state()["episode"] if autoreset != "disabled" else None
+            o, r, t, tr, _ = twin.step(torch.from_numpy(a).to(twin.device))
+            assert torch.equal(obs_k[k], o) and torch.equal(rew_k[k], r), (chunk, k)
+            assert torch.equal(term_k[k], t) and torch.equal(trunc_k[k], tr), (chunk, k)
+            seen = to_np(o).copy()
+            if before is not None:     # envs that began a new episode fly with fresh controllers
+                started = twin.get_state()["episode"] != before
+                pid.reset(started)
+                resets += int(started.sum())
+        sr, st = roll.get_state(), twin.get_state()
+        for key in sr:
+            assert np.array_equal(sr[key], st[key], equal_nan=True), (chunk, key)
+        assert np.array_equal(roll.pid_get_state(), pid.state.reshape(16, n)), chunk
+    if autoreset != "disabled" and gains == "upstream":
+        assert resets > 0      # the bang-bang upstream gains tip the copter over within ~130 steps
+    roll.close()
+    twin.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_rollout_pid_golden_traces(mode):
+    """The episodes the reference's own controller classes flew on the reference's live Lander
+    (tests/golden/pid_traces.npz), replayed as device rollouts: observations, rewards, done flags
+    and actions through the first done."""
+    import torch
+    cs = PID.names()
+    for c in cs:
+        g = PID[c]
+        rk, pk, dk = g["rate_gains"], g["pos_gains"], g["descent_gains"]
+        env, _ = make_pair("lander3d", 1, mode, initial_altitude=float(g["altitude"]))
+        env.configure_pid(rate_kp=rk[0], rate_ki=rk[1], rate_kd=rk[2], pos_kp=pk[0], pos_ki=pk[1],
+                          pos_kd=pk[2], pos_target=pk[3], descent_kp=dk[0], descent_kd=dk[1])
+        env.reset(options={"forces": g["force"][:3].astype(np.float32).reshape(3, 1)})
+        T = len(g["reward"])
+        obs, rew, term, trunc, act = (to_np(v) for v in env.rollout_pid(T, return_actions=True))
+        # float32_rn (bare float32 words, not the default): the derivative terms of the bang-bang
+        # upstream gains feed the word rounding back into the motors, so the closed loop is held
+        # to 1e-3 there; the default guarded mode meets the north-star bar, float64 mode 1e-9
+        tol = {"float64": 1e-9, "float32": BAR, "float32_rn": 1e-3}[mode]
+        assert np.array_equal(term[:, 0], g["done"].astype(bool)), c
+        assert not trunc.any()
+        e_obs = scaled_err(obs[:, 0], g["obs"])
+        e_act = scaled_err(act[:, 0], g["action"])
+        e_rew = float(np.max(np.abs(rew[:, 0] - g["reward"]) / np.maximum(np.abs(g["reward"]), 100.0)))
+        assert e_obs <= tol and e_act <= max(10 * tol, 1e-7) and e_rew <= max(tol, 1e-5), (c, mode, e_obs, e_act, e_rew)
+        env.close()
+
+
+@pytest.mark.parametrize("gains", ["upstream", "soft"])
+def test_rollout_pid_matches_full_oracle(gains):
+    """Device rollout vs the complete CPU closed loop (VecOracle physics + VecPid), default storage
+    mode, auto-reset on: flags exact, observations within the mode tolerance while the loops are
+    still on the same trajectory."""
+    from oracle.refvec import VecPid
+    n, K = 1024, 300
+    kw = PID_GAINS[gains]
+    env, orc = make_pair("lander3d", n, "float32", autoreset="next_step", seed=8)
+    env.configure_pid(**kw)
+    pid = VecPid(n, _oracle_gains(kw))
+    env.reset()
+    seen = orc.reset()
+    obs, rew, term, trunc = (to_np(v) for v in env.rollout_pid(K))
+    for k in range(K):
+        a = pid.action(seen)
+        seen, r, t, tr = orc.step(a.astype(np.float64))
+        pid.reset(orc.last_reset)
+        assert np.array_equal(term[k], t) and np.array_equal(trunc[k], tr), k
+        assert scaled_err(obs[k], seen) <= 2e-6, (k, scaled_err(obs[k], seen))
+        assert np.all(np.abs(rew[k] - r) <= 2e-3 + 2e-6 * np.abs(r)), k
+    env.close()

@@ -208,3 +208,31 @@ def test_autoreset_same_step_and_truncation():
     for t in range(20):
         obs, r, term, trunc = v.step(np.full((1, 4), hov))
         assert trunc[0] == (t == 19) and not term[0]
+
+
+def test_vecpid_matches_scalar_heuristic_closed_loop():
+    """VecPid + VecOracle(float64) == PidHeuristic + TaskOracle lane by lane, bit for bit."""
+    from oracle.refcpu import PidGains, PidHeuristic
+    from oracle.refvec import VecPid
+    n, T = 5, 160
+    for gains in (PidGains(), PidGains(rate_kp=0.002, rate_kd=0.002, pos_kp=0.0002, pos_ki=0.0, pos_kd=0.0,
+                                       descent_kp=0.004, descent_kd=0.012),
+                  PidGains(rate_ki=0.05, pos_ki=0.3)):
+        vec = VecOracle("lander3d", n, store_mode="float64", seed=11)
+        obs = vec.reset()
+        forces = vec.force[:3].astype(np.float64).T.copy()
+        pid = VecPid(n, gains)
+        scal = []
+        for i in range(n):
+            env = TaskOracle("lander3d")
+            o = env.reset(force_xyz=forces[i])
+            scal.append((env, PidHeuristic(gains), o))
+        for t in range(T):
+            a = pid.action(obs)
+            obs, r, term, _ = vec.step(a)
+            for i, (env, pol, o) in enumerate(scal):
+                ai = pol.action(o).astype(np.float32)
+                assert np.array_equal(ai, a[i]), (t, i)
+                o2, ri, di, _, _ = env.step(ai.astype(np.float64))
+                assert np.array_equal(o2, obs[i]) and ri == r[i] and di == term[i], (t, i)
+                scal[i] = (env, pol, o2)
