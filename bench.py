@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--gather", action="store_true", help="also time with the RCCL obs all-gather")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--pid", type=int, default=100,
+                   help="also time cs_rollout_pid (closed loop, on-device PID heuristic) with this many "
+                        "steps per launch (0 = skip)")
     p.add_argument("--many", type=int, default=100,
                    help="also time cs_step_many with this many steps per launch (0 = skip)")
     return p.parse_args()
@@ -240,6 +243,32 @@ def main():
             "note": "cs_step_many: bit-identical to K single-step launches "
                     "(tests/test_gpu_parity.py::test_step_many_is_bit_identical_to_single_steps); "
                     "open-loop actions only, so it is reported beside, not as, the headline value"}
+
+    if a.pid > 0 and a.task == "lander3d":
+        # closed loop: K steps per launch with the on-device PID heuristic choosing every action
+        k = a.pid
+        reps = max(1, a.steps // k)
+        env.configure_pid()
+        env.reset()
+
+        class Roll:
+            def run(self, count):
+                for _ in range(count // k):
+                    env.rollout_pid(k)
+        m = Roll()
+        m.run(2 * k)
+        wm, evm = timed(m, reps * k)
+        per_step = evm / (reps * k)
+        od = env.obs_dim
+        bytes_step = 4 * od + 4 + 2 + (200.0 + 256.0) / k   # obs, reward, flags out; env + controller state once per launch
+        extra["rollout_pid"] = {
+            "steps_per_launch": k, "value": total_envs * reps * k / wm, "unit": "env-steps/s",
+            "us_per_step": per_step * 1e6,
+            "algorithmic_bytes_per_env_step": bytes_step,
+            "achieved_GBps": bytes_step * n / per_step / 1e9,
+            "note": "cs_rollout_pid: closed loop, upstream's PID landing heuristic evaluated on device "
+                    "(tests/test_gpu_parity.py::test_rollout_pid_policy_is_bit_exact); episodes under "
+                    "upstream's gains end by tilt after ~130 steps and auto-reset"}
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
