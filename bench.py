@@ -106,13 +106,22 @@ class Stepper:
             done += 1
 
 
-def cpu_baseline(task, law, seconds):
-    """Scalar NumPy port of the reference (one env per object, same NumPy call structure),
-    one core, bounded sample; plus the vectorised NumPy oracle as an extra row."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _scalar_port(args):
+    """`seconds` of the scalar NumPy port on one core -> (steps, elapsed)."""
+    task, law, seconds, seed = args
     import numpy as np
     from oracle.refcpu import TaskOracle
-    from oracle.refvec import VecOracle
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     o = TaskOracle(task)
     o.reset(rng=rng)
     steps = 0
@@ -131,7 +140,30 @@ def cpu_baseline(task, law, seconds):
                 o.reset(rng=rng)
         dt = time.perf_counter() - t0
         if dt >= seconds:
-            break
+            return steps, dt
+
+
+def cpu_baseline(task, law, seconds):
+    """Scalar NumPy port of the reference (one env per object, same NumPy call structure):
+    one core, bounded sample; the same on every host core at once (one process per core, each
+    stepping its own env); plus the vectorised NumPy oracle as an extra row.  Runs BEFORE the
+    process touches the GPU, so that forking the workers is safe."""
+    import numpy as np
+    from oracle.refvec import VecOracle
+    rng = np.random.default_rng(0)
+    steps, dt = _scalar_port((task, law, seconds, 0))
+    procs = os.cpu_count() or 1
+    all_cores = None
+    if procs > 1:
+        import multiprocessing as mp
+        per = max(2.0, seconds / 4)
+        try:
+            with mp.get_context("fork").Pool(procs) as pool:
+                res = pool.map(_scalar_port, [(task, law, per, 100 + i) for i in range(procs)])
+            all_cores = {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env-steps/s",
+                         "cores": procs, "sample": "%d processes x %.1f s, one env each" % (procs, per)}
+        except Exception as e:      # a baseline, never a reason to lose the GPU measurement
+            all_cores = {"error": repr(e)}
     scalar = steps / dt
     nv = 65536
     v = VecOracle(task, nv, store_mode="float32", autoreset=1, seed=1)
@@ -147,6 +179,7 @@ def cpu_baseline(task, law, seconds):
             "sample": "oracle/refcpu.py TaskOracle (scalar NumPy, reference call structure), %s, "
                       "'%s' actions, %d steps in %.1f s on 1 of %d host cores"
                       % (task, law, steps, dt, os.cpu_count()),
+            "all_cores": all_cores, "cpu_model": _cpu_model(),
             "vectorised_numpy": {"value": vec, "unit": "env-steps/s", "cores": 1,
                                  "sample": "oracle/refvec.py VecOracle, %d envs x %d steps" % (nv, k)}}
 
@@ -163,6 +196,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.task, a.actions, a.cpu_seconds)      # before any HIP call (forks workers)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
     device = torch.device("cuda", local)
@@ -299,8 +335,8 @@ def main():
                      "algorithmic_bytes_per_launch": ALGO_BYTES[a.task] * n},
     }
     out.update(extra)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.task, a.actions, a.cpu_seconds)
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out), flush=True)
     env.close()

@@ -1,0 +1,153 @@
+// A plain C++ host driving libcopterstep.so through include/copterstep.h only: no Python, no
+// torch.  Run by tests/test_gpu_parity.py::test_c_host_known_answers on the GPU box; built by
+// __graft_entry__.build().  Known answers come from the reference: reset observation
+// (0,0,0,0,-10,0,0,0,0,0); constant thrust 1.625e-2 (lander.py:21) gives netz = 0.363923869 m/s^2,
+// so without a perturbation dz after the first step is netz * dt; a free-falling copter (motors 0)
+// accelerates at G, reaches the ground after ~143 steps and the episode ends as CRASHED one step
+// later (status is sampled before the physics, task.py:81).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "copterstep.h"
+
+#define OK(call)                                                                  \
+  do {                                                                            \
+    int rc_ = (call);                                                             \
+    if (rc_ != 0) {                                                               \
+      std::fprintf(stderr, "FAIL %s -> %d: %s\n", #call, rc_, cs_last_error());   \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+#define HIP(call)                                                                 \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      std::fprintf(stderr, "FAIL %s: %s\n", #call, hipGetErrorString(e_));        \
+      return 2;                                                                   \
+    }                                                                             \
+  } while (0)
+#define CHECK(cond)                                                               \
+  do {                                                                            \
+    if (!(cond)) {                                                                \
+      std::fprintf(stderr, "CHECK failed line %d: %s\n", __LINE__, #cond);        \
+      return 3;                                                                   \
+    }                                                                             \
+  } while (0)
+
+int main() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    std::fprintf(stderr, "no HIP device\n");
+    return 77;
+  }
+  const int64_t n = 1000;  // ragged: not a multiple of the 64-env tile
+  cs_config cfg;
+  OK(cs_config_init(&cfg, CS_TASK_LANDER3D));
+  cfg.num_envs = n;
+  cfg.autoreset = CS_AUTORESET_DISABLED;
+  cs_ctx* ctx = nullptr;
+  OK(cs_create(&cfg, &ctx));
+  int32_t od = 0;
+  OK(cs_obs_dim(ctx, &od));
+  CHECK(od == 10);
+
+  float *act, *obs, *rew, *force;
+  uint8_t *term, *trunc;
+  HIP(hipMalloc((void**)&act, n * 4 * sizeof(float)));
+  HIP(hipMalloc((void**)&obs, n * od * sizeof(float)));
+  HIP(hipMalloc((void**)&rew, n * sizeof(float)));
+  HIP(hipMalloc((void**)&force, 3 * n * sizeof(float)));
+  HIP(hipMalloc((void**)&term, n));
+  HIP(hipMalloc((void**)&trunc, n));
+  HIP(hipMemset(force, 0, 3 * n * sizeof(float)));  // no reset perturbation
+  hipStream_t stream;
+  HIP(hipStreamCreate(&stream));
+
+  std::vector<float> h_obs(n * od), h_rew(n), h_act(n * 4);
+  std::vector<uint8_t> h_term(n);
+  auto fetch = [&]() -> int {
+    HIP(hipMemcpyAsync(h_obs.data(), obs, h_obs.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP(hipMemcpyAsync(h_rew.data(), rew, h_rew.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP(hipMemcpyAsync(h_term.data(), term, n, hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    return 0;
+  };
+
+  // ---- reset: observation of the fresh state ----
+  OK(cs_reset(ctx, nullptr, force, obs, stream));
+  if (fetch()) return 2;
+  for (int64_t i = 0; i < n; ++i)
+    for (int k = 0; k < od; ++k) CHECK(h_obs[i * od + k] == (k == 4 ? -10.0f : 0.0f));
+
+  // ---- constant thrust: first integrated step ----
+  for (auto& v : h_act) v = 1.625e-2f;
+  HIP(hipMemcpyAsync(act, h_act.data(), h_act.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  OK(cs_step(ctx, act, obs, rew, term, trunc, stream));
+  if (fetch()) return 2;
+  const double dt = 1.0 / cfg.frames_per_second;
+  // 1.625e-2 is rounded to float32 at the action boundary: netz scales with its square
+  auto net_accel = [&](double m) {
+    const double w = m * cfg.maxrpm * 3.14159265358979323846 / 30.0;
+    return cfg.G - cfg.B * 4.0 * w * w / cfg.M;
+  };
+  CHECK(std::fabs(net_accel(1.625e-2) - 0.363923869) < 5e-9);  // the reference's figure (float64 action)
+  const double netz = net_accel((double)1.625e-2f);
+  for (int64_t i = 0; i < n; ++i) {
+    CHECK(h_obs[i * od + 4] == -10.0f);                                    // z: Euler uses the old dz
+    CHECK(std::fabs(h_obs[i * od + 5] - netz * dt) <= 1e-6 * netz * dt);   // dz
+    CHECK(h_term[i] == 0);
+    // shaping difference: -25 * (sqrt(100 + dz^2) - 10)
+    const double dz = netz * dt, want = -25.0 * (std::sqrt(100.0 + dz * dz) - 10.0);
+    CHECK(std::fabs(h_rew[i] - want) < 1e-6);
+  }
+
+  // ---- free fall to the ground: crash, reported done one step later ----
+  OK(cs_reset(ctx, nullptr, force, obs, stream));
+  for (auto& v : h_act) v = 0.0f;
+  HIP(hipMemcpyAsync(act, h_act.data(), h_act.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+  int done_at = -1;
+  for (int t = 1; t <= 200 && done_at < 0; ++t) {
+    OK(cs_step(ctx, act, obs, rew, term, trunc, stream));
+    if (fetch()) return 2;
+    for (int64_t i = 1; i < n; ++i) CHECK(h_term[i] == h_term[0]);  // identical envs stay identical
+    if (h_term[0]) done_at = t;
+  }
+  // z_k = -10 + G dt^2 k(k-1)/2 first exceeds 0 at k = 144 integrating calls -> contact seen by call
+  // 145 (CRASHED, frozen), reported by the step after it
+  CHECK(done_at == 146);
+  std::vector<uint8_t> status(n);
+  std::vector<int32_t> steps(n);
+  OK(cs_get_state(ctx, nullptr, status.data(), steps.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                  stream));
+  for (int64_t i = 0; i < n; ++i) CHECK(status[i] == CS_STATUS_CRASHED && steps[i] == done_at + 1);
+
+  // ---- K steps in one launch == what the single steps did ----
+  OK(cs_reset(ctx, nullptr, force, obs, stream));
+  const int K = 8;
+  float *act_k, *obs_k;
+  HIP(hipMalloc((void**)&act_k, (size_t)K * n * 4 * sizeof(float)));
+  HIP(hipMalloc((void**)&obs_k, (size_t)K * n * od * sizeof(float)));
+  HIP(hipMemsetAsync(act_k, 0, (size_t)K * n * 4 * sizeof(float), stream));
+  OK(cs_step_many(ctx, K, act_k, obs_k, nullptr, nullptr, nullptr, stream));
+  std::vector<float> last(n * od);
+  HIP(hipMemcpyAsync(last.data(), obs_k + (size_t)(K - 1) * n * od, last.size() * sizeof(float),
+                     hipMemcpyDeviceToHost, stream));
+  HIP(hipStreamSynchronize(stream));
+  const double dz8 = cfg.G * dt * K, z8 = -10.0 + cfg.G * dt * dt * K * (K - 1) / 2.0;
+  for (int64_t i = 0; i < n; ++i) {
+    CHECK(std::fabs(last[i * od + 5] - dz8) < 1e-6 && std::fabs(last[i * od + 4] - z8) < 1e-5);
+  }
+
+  // ---- errors come back as codes + messages, never as exceptions or aborts ----
+  CHECK(cs_step(ctx, nullptr, obs, rew, term, trunc, stream) != 0);
+  CHECK(cs_last_error()[0] != '\0');
+  CHECK(cs_rollout_pid(ctx, 4, nullptr, obs_k, nullptr, nullptr, nullptr, stream) != 0);  // not configured
+
+  OK(cs_destroy(ctx));
+  std::printf("abi_host: OK (%lld envs, done at step %d)\n", (long long)n, done_at);
+  return 0;
+}

@@ -92,3 +92,19 @@ def test_spaces_and_registry():
     assert b.shape == (4,) and b.dtype == np.float32 and b.contains(b.sample())
     assert b.high[0] == 1 and not b.contains(np.full(4, 2, np.float32))
     assert set(gym_copter_amd._REGISTRY) == {"Lander-v0", "Lander3D-v0", "Hover3D-v0"}
+
+
+def test_c_host_builds_and_reports_missing_device():
+    """The plain C++ host of the ABI links against the library; without a GPU it says so (exit 77)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "abi_host")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gym_copter_amd", "csrc"), "host"],
+                              stdout=subprocess.DEVNULL)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    try:
+        import torch
+        gpu = torch.cuda.is_available()
+    except Exception:
+        gpu = False
+    assert p.returncode == (0 if gpu else 77), (p.returncode, p.stderr)

@@ -669,3 +669,15 @@ def test_rollout_pid_matches_full_oracle(gains):
         assert scaled_err(obs[k], seen) <= 2e-6, (k, scaled_err(obs[k], seen))
         assert np.all(np.abs(rew[k] - r) <= 2e-3 + 2e-6 * np.abs(r)), k
     env.close()
+
+
+def test_c_host_known_answers():
+    """tests/host/abi_host.cpp: a plain C++ program (no Python, no torch) drives the C ABI --
+    reset observation, the reference's constant-thrust known answer, free fall to a crash, K steps
+    in one launch, error returns."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "host", "abi_host")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert "abi_host: OK" in p.stdout
