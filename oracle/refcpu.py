@@ -159,16 +159,35 @@ class RigidBody:
         self.ticks += 1
 
 
+# task -> (reward kind, first observed state slot, observation size, motor fan-out).
+# 3D: lander.py:39-44 / attic hover3d.py:32-37.  1D / 2D: the _get_state sub-selection and
+# _get_motors fan-out of attic/gym_copter/envs/lander1d.py:43-48, lander2d.py:43-50,
+# hover1d.py:44-50, hover2d.py:44-50 plugged into the live _Task hooks (task.py:94, :133).
+TASKS = {
+    "lander3d": ("lander", 0, 10, (0, 1, 2, 3)),
+    "hover3d": ("hover", 0, 12, (0, 1, 2, 3)),
+    "lander2d": ("lander", 2, 6, (0, 1, 1, 0)),     # obs (y,dy,z,dz,phi,dphi), motors [m0,m1,m1,m0]
+    "lander1d": ("lander", 4, 2, (0, 0, 0, 0)),     # obs (z,dz),               motors [m0,m0,m0,m0]
+    "hover2d": ("hover", 2, 6, (0, 1, 1, 0)),
+    "hover1d": ("hover", 4, 2, (0, 0, 0, 0)),
+}
+
+
+def task_action_dim(task):
+    return max(TASKS[task][3]) + 1
+
+
 class TaskOracle:
-    """Single-environment Lander3D / Hover3D task around one RigidBody."""
+    """Single-environment Lander / Hover task (3D, or a 2D / 1D variant) around one RigidBody."""
 
     def __init__(self, task="lander3d", tp=TaskParams(), vp=DJI_PHANTOM, substeps=1,
                  action_dtype_passthrough=False):
-        assert task in ("lander3d", "hover3d")
+        assert task in TASKS
         self.task, self.tp, self.vp = task, tp, vp
+        self.kind, self.obs_first, self.obs_dim, self.fan = TASKS[task]
+        self.act_dim = task_action_dim(task)
         self.substeps = substeps
         self.passthrough = action_dtype_passthrough
-        self.obs_dim = 10 if task == "lander3d" else 12
         self.max_angle = np.radians(tp.max_angle)
         self.body = None
 
@@ -214,11 +233,13 @@ class TaskOracle:
                 action = np.asarray(action, dtype=np.float64)
             motors = np.clip(action, 0, 1)
             if not initializing:
+                if self.act_dim != 4:
+                    motors = [motors[j] for j in self.fan]        # _get_motors
                 for _ in range(self.substeps):
                     b.set_motors(motors)
         x = b.x
         self.done = False
-        if self.task == "lander3d":
+        if self.kind == "lander":
             reward = self._lander_reward(status0, x)
         else:
             reward = 1
@@ -233,7 +254,7 @@ class TaskOracle:
         if self.steps == tp.max_steps:
             self.done = True
         self.steps += 1
-        obs = np.array(x[:self.obs_dim], dtype=np.float32)
+        obs = np.array(x[self.obs_first:self.obs_first + self.obs_dim], dtype=np.float32)
         return obs, reward, self.done, False, {}
 
 

@@ -27,7 +27,7 @@ Reference lines followed (paths relative to the upstream checkout):
 import numpy as np
 
 from .refcpu import (AIRBORNE, CRASHED, DJI_PHANTOM, G, LANDED, LANDING_ANGLE,
-                     LANDING_VEL_X, LANDING_VEL_Y, LEVELING, TaskParams)
+                     LANDING_VEL_X, LANDING_VEL_Y, LEVELING, TASKS, TaskParams, task_action_dim)
 
 AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
 
@@ -105,8 +105,11 @@ class VecOracle:
     def __init__(self, task="lander3d", num_envs=1, tp=TaskParams(), vp=DJI_PHANTOM,
                  substeps=1, store_mode="float64", autoreset=AUTORESET_DISABLED,
                  seed=0, env_id_base=0, time_limit_truncates=False):
-        assert task in ("lander3d", "hover3d")
+        assert task in TASKS
         self.task, self.n, self.tp, self.vp = task, int(num_envs), tp, vp
+        self.kind, self.obs_first, self.obs_dim, fan = TASKS[task]
+        self.fan = np.array(fan)
+        self.act_dim = task_action_dim(task)
         self.substeps = int(substeps)
         word, xdtype, self.rounding = STORE_MODES[store_mode]
         self.T = np.dtype(word)
@@ -114,7 +117,6 @@ class VecOracle:
         self.seed = int(seed)
         self.env_ids = np.arange(env_id_base, env_id_base + self.n, dtype=np.uint64)
         self.time_limit_truncates = bool(time_limit_truncates)
-        self.obs_dim = 10 if task == "lander3d" else 12
         self.dt = 1. / (tp.frames_per_second * self.substeps)
         self.max_angle = np.radians(tp.max_angle)
         self.episode = np.zeros(self.n, dtype=np.uint32)   # episodes started (Philox counter word)
@@ -217,7 +219,7 @@ class VecOracle:
         self.pending[m] = True
         self.done_pending[m] = False
         xs = self.x[:, m].astype(np.float64)
-        if self.task == "lander3d":
+        if self.kind == "lander":
             self.prev_shaping[m] = self._shaping(xs).astype(self.T)
         else:
             self.prev_shaping[m] = np.nan
@@ -236,7 +238,8 @@ class VecOracle:
     def observe(self):
         # float32 observation = round-to-nearest-even of the stored value, in every mode
         with np.errstate(over="ignore"):
-            return np.ascontiguousarray(self.x[:self.obs_dim].T.astype(np.float32))
+            return np.ascontiguousarray(
+                self.x[self.obs_first:self.obs_first + self.obs_dim].T.astype(np.float32))
 
     # ------------------------------------------------------------------ reward
     def _shaping(self, x):
@@ -268,7 +271,7 @@ class VecOracle:
     # ------------------------------------------------------------------ step
     def step(self, actions):
         tp, n = self.tp, self.n
-        actions = np.asarray(actions, dtype=np.float64).reshape(n, 4)
+        actions = np.asarray(actions, dtype=np.float64).reshape(n, self.act_dim)[:, self.fan]   # _get_motors
         obs = np.empty((n, self.obs_dim), dtype=np.float32)
         reward = np.zeros(n)
         term = np.zeros(n, dtype=bool)
@@ -289,7 +292,7 @@ class VecOracle:
         # task logic on the *stored* (rounded) state, float64 arithmetic
         x = self.x.astype(np.float64)
         done = np.zeros(n, dtype=bool)
-        if self.task == "lander3d":
+        if self.kind == "lander":
             sh = self._shaping(x)
             prev = self.prev_shaping.astype(np.float64)
             r = np.where(np.isnan(prev), 0.0, sh - prev)

@@ -18,12 +18,13 @@ def pytest_configure(config):
 class Cases:
     """Read-only view of one golden .npz: cases[name][field]."""
 
-    def __init__(self, path):
-        z = np.load(path)
+    def __init__(self, *paths):
         self._d = {}
-        for k in z.files:
-            c, f = k.split("/", 1)
-            self._d.setdefault(c, {})[f] = z[k]
+        for path in paths:
+            z = np.load(path)
+            for k in z.files:
+                c, f = k.split("/", 1)
+                self._d.setdefault(c, {})[f] = z[k]
 
     def names(self):
         return sorted(self._d)
@@ -35,10 +36,11 @@ class Cases:
 _cache = {}
 
 
-def load_cases(fname):
-    if fname not in _cache:
-        _cache[fname] = Cases(os.path.join(GOLDEN, fname))
-    return _cache[fname]
+def load_cases(*fnames):
+    """Cases of one golden file, or of several merged (case names are unique across files)."""
+    if fnames not in _cache:
+        _cache[fnames] = Cases(*[os.path.join(GOLDEN, f) for f in fnames])
+    return _cache[fnames]
 
 
 @pytest.fixture(scope="session")

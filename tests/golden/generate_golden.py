@@ -231,7 +231,7 @@ def run_env(env, actions, seed, altitude=None, extra_after_done=25, action_dtype
             break
     n = len(rec["reward"])
     return dict(
-        task=np.array("hover3d" if len(obs0) == 12 else "lander3d"),
+        task=np.array(getattr(env, "TASK_NAME", "hover3d" if len(obs0) == 12 else "lander3d")),
         seed=np.int64(seed), altitude=np.float64(env.initial_altitude),
         force=force[:3], actions=actions[:n].astype(np.float64),
         action_is_f32=np.bool_(action_dtype == np.float32),
@@ -305,6 +305,59 @@ def e_series(_Task, Lander, vp):
     return cases
 
 
+def v_series(_Task, Lander, vp):
+    """1D / 2D task variants on the LIVE _Task / Lander: the two hooks of the retired variant
+    classes -- _get_motors fan-out and _get_state sub-selection
+    (attic/gym_copter/envs/lander1d.py:43-48, lander2d.py:43-50, hover1d.py:44-50,
+    hover2d.py:44-50; those files themselves import names that no longer exist) -- plugged into
+    the reference's current step()/reset()/reward code."""
+    rng = np.random.default_rng(4242)
+    hov = hover_motor(vp)
+    KEYS = {"1d": ('z', 'dz'), "2d": ('y', 'dy', 'z', 'dz', 'phi', 'dphi')}
+    FAN = {"1d": lambda m: [m[0], m[0], m[0], m[0]], "2d": lambda m: [m[0], m[1], m[1], m[0]]}
+
+    def variant(kind, dim):
+        keys, fan, nact = KEYS[dim], FAN[dim], {"1d": 1, "2d": 2}[dim]
+
+        class V(Lander):
+            TASK_NAME = kind + dim
+
+            def __init__(self):
+                _Task.__init__(self, len(keys), nact)
+                self.viewer = None
+
+            def _get_state(self, state):
+                return [state[k] for k in keys]
+
+            def _get_motors(self, motors):
+                return fan(motors)
+
+            if kind == "hover":
+                def _get_reward(self, status, state, d, x, y):     # attic hover.py:18-21
+                    return 1
+        return V()
+
+    T = 1100
+    cases = {}
+    for dim, nact in (("1d", 1), ("2d", 2)):
+        ones = np.ones((T, nact))
+        for kind in ("lander", "hover"):
+            tag = "V_%s%s" % (kind, dim)
+            cases[tag + "_const"] = run_env(variant(kind, dim), f32r(1.625e-2) * ones, seed=30)
+            cases[tag + "_uniform"] = run_env(variant(kind, dim), f32r(rng.uniform(-1, 1, (T, nact))), seed=31)
+            cases[tag + "_noisy_hover"] = run_env(
+                variant(kind, dim), f32r(hov * (1 + 0.01 * rng.standard_normal((T, nact)))), seed=32)
+            cases[tag + "_soft_landing"] = run_env(variant(kind, dim), f32r(1.6e-2) * ones, seed=33,
+                                                   altitude=0.05)
+        # 2D only: differential thrust rolls the copter to the tilt limit / out of bounds
+        if dim == "2d":
+            a = f32r(hov * np.array([0.99, 1.01])) * ones
+            a[40:] = f32r(hov)
+            cases["V_lander2d_oob"] = run_env(variant("lander", dim), a, seed=34)
+            cases["V_hover2d_roll"] = run_env(variant("hover", dim), np.array([0., 1.]) * ones, seed=35)
+    return cases
+
+
 def save(name, cases):
     flat = {}
     for cname, c in cases.items():
@@ -321,6 +374,7 @@ def main():
     save("dynamics_traces.npz", d_series(Dynamics, vp))
     save("env_traces.npz", e_series(_Task, Lander, vp))
     save("pid_traces.npz", p_series(Lander, load_mars_pid()))
+    save("variant_traces.npz", v_series(_Task, Lander, vp))
     # known-answer constants observed from the reference (used as spot checks)
     meta = dict(numpy_version=np.array(np.__version__), hover_motor=np.float64(hover_motor(vp)))
     np.savez(os.path.join(OUT, "meta.npz"), **meta)

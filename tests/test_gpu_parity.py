@@ -13,7 +13,7 @@ from gpu_util import (MODE_TOL, assert_state_close, assert_step_close, have_gpu,
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 
-ENV = load_cases("env_traces.npz")
+ENV = load_cases("env_traces.npz", "variant_traces.npz")   # 3D tasks + 1D / 2D variants
 DYN = load_cases("dynamics_traces.npz")
 import os
 HOVER = float(np.load(os.path.join(os.path.dirname(__file__), "golden", "meta.npz"))["hover_motor"])
@@ -41,7 +41,7 @@ def test_golden_env_traces(key, mode):
     cs = _env_groups()[key]
     n = len(cs)
     T = max(len(ENV[c]["reward"]) for c in cs)
-    acts = np.zeros((T, n, 4), dtype=np.float32)
+    acts = np.zeros((T, n, ENV[cs[0]]["actions"].shape[1]), dtype=np.float32)
     forces = np.zeros((3, n), dtype=np.float32)
     for i, c in enumerate(cs):
         a = ENV[c]["actions"]

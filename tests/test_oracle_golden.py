@@ -8,7 +8,7 @@ from oracle.refcpu import (AIRBORNE, CRASHED, DJI_PHANTOM, LANDED, RigidBody, Ta
                            TaskParams)
 
 DYN = load_cases("dynamics_traces.npz")
-ENV = load_cases("env_traces.npz")
+ENV = load_cases("env_traces.npz", "variant_traces.npz")   # 3D tasks + 1D / 2D variants
 
 
 @pytest.mark.parametrize("name", DYN.names())

@@ -10,7 +10,7 @@ from oracle.refcpu import AIRBORNE, DJI_PHANTOM, LANDED, TaskOracle, TaskParams
 from oracle.refvec import VecOracle, draw_forces, philox2x32_10
 
 DYN = load_cases("dynamics_traces.npz")
-ENV = load_cases("env_traces.npz")
+ENV = load_cases("env_traces.npz", "variant_traces.npz")   # 3D tasks + 1D / 2D variants
 
 
 def test_philox_known_answers():
@@ -58,7 +58,7 @@ def test_vec_env_traces_bit_exact_in_batch(key):
     cs = _env_groups()[key]
     n = len(cs)
     T = max(len(ENV[c]["reward"]) for c in cs)
-    acts = np.zeros((T, n, 4))
+    acts = np.zeros((T, n, ENV[cs[0]]["actions"].shape[1]))
     forces = np.zeros((3, n))
     for i, c in enumerate(cs):
         a = ENV[c]["actions"]
