@@ -16,6 +16,10 @@ _REGISTRY = {
     "Lander-v0": dict(task="lander3d", max_steps=1000),
     "Lander3D-v0": dict(task="lander3d", max_steps=1000),
     "Hover3D-v0": dict(task="hover3d", max_steps=1000),
+    "Lander2D-v0": dict(task="lander2d", max_steps=1000),
+    "Lander1D-v0": dict(task="lander1d", max_steps=1000),
+    "Hover2D-v0": dict(task="hover2d", max_steps=1000),
+    "Hover1D-v0": dict(task="hover1d", max_steps=1000),
 }
 
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COPTERSTEP_LIB", os.path.join(_HERE, "libcopterstep.so"))
 
 ABI_VERSION = 1
-TASK_LANDER3D, TASK_HOVER3D = 0, 1
+TASK_LANDER3D, TASK_HOVER3D, TASK_LANDER2D, TASK_LANDER1D, TASK_HOVER2D, TASK_HOVER1D = range(6)
 STATE_F32G, STATE_F32_RN, STATE_F64 = 0, 1, 2
 AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
 STATUS_CRASHED, STATUS_LANDED, STATUS_LEVELING, STATUS_AIRBORNE = 0, 1, 2, 3
@@ -73,6 +73,7 @@ SYMBOLS = {
     "cs_destroy": (C.c_int, [_P]),
     "cs_num_envs": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "cs_obs_dim": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "cs_action_dim": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "cs_seed": (C.c_int, [_P, C.c_uint64]),
     "cs_set_altitude": (C.c_int, [_P, C.c_double]),
     "cs_reset": (C.c_int, [_P, _P, _P, _P, _P]),

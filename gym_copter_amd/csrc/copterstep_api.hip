@@ -78,7 +78,7 @@ cs::DevConst make_const(const cs_ctx* ctx) {
   c.dz_pen = g.dz_penalty;
   c.target_r2 = g.target_radius * g.target_radius;
   c.bonus = g.inside_radius_bonus;
-  if (g.task == CS_TASK_LANDER3D) {
+  if (cs::task_is_lander(g.task)) {
     const double z = stored_word(g, c.z0);
     c.reset_shaping = stored_word(g, -(g.xyz_penalty_factor * std::sqrt(z * z) +
                                        g.yaw_penalty_factor * std::sqrt(0.0)));
@@ -115,7 +115,7 @@ const char* cs_last_error(void) { return g_err.c_str(); }
 
 int cs_config_init(cs_config* cfg, int task) {
   if (cfg == nullptr) return fail(CS_ERR_ARG, "cs_config_init: null cfg");
-  if (task != CS_TASK_LANDER3D && task != CS_TASK_HOVER3D)
+  if (task < 0 || task >= CS_TASK_COUNT)
     return fail(CS_ERR_ARG, "cs_config_init: unknown task");
   std::memset(cfg, 0, sizeof *cfg);
   cfg->struct_size = (uint32_t)sizeof(cs_config);
@@ -168,7 +168,7 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   *out = nullptr;
   if (cfg->struct_size != sizeof(cs_config) || cfg->abi_version != CS_ABI_VERSION)
     return fail(CS_ERR_ABI, "cs_create: cs_config size/version mismatch (use cs_config_init)");
-  if (cfg->task != CS_TASK_LANDER3D && cfg->task != CS_TASK_HOVER3D)
+  if (cfg->task < 0 || cfg->task >= CS_TASK_COUNT)
     return fail(CS_ERR_ARG, "cs_create: unknown task");
   if (cfg->state_mode < CS_STATE_F32G || cfg->state_mode > CS_STATE_F64)
     return fail(CS_ERR_ARG, "cs_create: unknown state_mode");
@@ -246,7 +246,13 @@ int cs_num_envs(const cs_ctx* ctx, int64_t* out) {
 
 int cs_obs_dim(const cs_ctx* ctx, int32_t* out) {
   if (check_ctx(ctx) || out == nullptr) return fail(CS_ERR_ARG, "cs_obs_dim: null argument");
-  *out = ctx->cfg.task == CS_TASK_LANDER3D ? 10 : 12;
+  *out = cs::task_obs_dim(ctx->cfg.task);
+  return CS_OK;
+}
+
+int cs_action_dim(const cs_ctx* ctx, int32_t* out) {
+  if (check_ctx(ctx) || out == nullptr) return fail(CS_ERR_ARG, "cs_action_dim: null argument");
+  *out = cs::task_act_dim(ctx->cfg.task);
   return CS_OK;
 }
 
@@ -404,6 +410,8 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
                    void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_rollout_pid: call cs_pid_configure first");
+  if (cs::task_act_dim(ctx->cfg.task) != 4)
+    return fail(CS_ERR_ARG, "cs_rollout_pid: the heuristic flies the 3D tasks only");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_pid: num_steps must be >= 1");
   const cs::DevConst c = make_const(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,

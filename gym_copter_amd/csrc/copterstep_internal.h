@@ -115,6 +115,21 @@ inline void trig_constants(double (&t)[16]) {
   for (int i = 0; i < 16; ++i) t[i] = v[i];
 }
 
+// Compile-time traits of the tasks (include/copterstep.h: CS_TASK_*).
+constexpr bool task_is_lander(int t) {
+  return t == CS_TASK_LANDER3D || t == CS_TASK_LANDER2D || t == CS_TASK_LANDER1D;
+}
+constexpr int task_act_dim(int t) {
+  return (t == CS_TASK_LANDER3D || t == CS_TASK_HOVER3D) ? 4
+         : (t == CS_TASK_LANDER2D || t == CS_TASK_HOVER2D) ? 2 : 1;
+}
+constexpr int task_obs_dim(int t) {
+  return t == CS_TASK_LANDER3D ? 10 : t == CS_TASK_HOVER3D ? 12 : task_act_dim(t) == 2 ? 6 : 2;
+}
+constexpr int task_obs_first(int t) {  // first observed state slot: x | y | z
+  return task_act_dim(t) == 4 ? 0 : task_act_dim(t) == 2 ? 2 : 4;
+}
+
 // Gains of the on-device PID landing heuristic (attic/mars/lander3d.py:32-36), float64.
 struct PidConst {
   double rate_kp, rate_ki, rate_kd, rate_windup, rate_big;  // rate_big in rad/s

@@ -511,6 +511,23 @@ struct StepOpts {  // uniform switches (compiled out in LEAN builds)
   bool stats, trunc, done_list, same_step;
 };
 
+// One action row -> the four motor demands: _get_motors (lander.py:95-97 for the 3D tasks; the
+// fan-outs of attic lander2d.py:48-50 / lander1d.py:46-48 for the variants).  Coalesced
+// 16 / 8 / 4 bytes per lane.
+template <int TASK>
+__device__ __forceinline__ float4 load_action(const float* base, uint32_t env) {
+  constexpr int A = task_act_dim(TASK);
+  if constexpr (A == 4) {
+    return *at32<const float4>(base, env << 4);
+  } else if constexpr (A == 2) {
+    const float2 a = *at32<const float2>(base, env << 3);
+    return make_float4(a.x, a.y, a.y, a.x);
+  } else {
+    const float a = *at32<const float>(base, env << 2);
+    return make_float4(a, a, a, a);
+  }
+}
+
 // _Task.step() (task.py:77-137) for one register-resident env: Dynamics.setMotors x
 // substeps -> stored-word rounding -> reward / termination -> optional done list and
 // final_obs -> masked auto-reset (task.py:145-197).  Shared by the one-step and the
@@ -523,6 +540,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const StepOpts& o, En
                                         int lane, bool valid, const TileIO<MODE>& tile,
                                         StepOut<OBS>& out) {
   using T = typename ModeOf<MODE>::T;
+  constexpr int FIRST = task_obs_first(TASK);
   const bool resetting = e.reset_pending;  // only ever set under NEXT_STEP auto-reset
   double reward = 0.0;
   bool term = false, trunc = false;
@@ -543,13 +561,14 @@ __device__ __forceinline__ void advance(const DevConst& c, const StepOpts& o, En
     e.xs[k] = w.word;
     e.gs[k >> 2] |= w.guard << (8 * (k & 3));
     e.x[k] = w.value;
-    if (k < OBS) out.row[k] = (float)w.value;  // float32 observation: round-to-nearest of the stored value
+    // float32 observation: round-to-nearest of the stored value (slots FIRST .. FIRST+OBS-1)
+    if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w.value;
   }
 
   // ---- reward / termination (task.py:104-130, lander.py:46-74) ----
   if (!resetting) {
     bool done = false;
-    if constexpr (TASK == CS_TASK_LANDER3D) {
+    if constexpr (task_is_lander(TASK)) {
       const double sh = lander_shaping(c, e.x);
       reward = (e.prev_sh != e.prev_sh) ? 0.0 : sh - e.prev_sh;  // NaN == None
       e.prev_sh = (double)(T)sh;
@@ -625,7 +644,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const StepOpts& o, En
     }
     e.gs[0] = e.gs[1] = e.gs[2] = 0;
 #pragma unroll
-    for (int k = 0; k < OBS; ++k) out.row[k] = (float)e.xs[k];
+    for (int k = 0; k < OBS; ++k) out.row[k] = (float)e.xs[FIRST + k];
     e.fs = c.status0;
     e.pend = true;
     e.steps = 1;
@@ -669,7 +688,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
   const bool opt_stats = !LEAN && c.stats;
   const bool opt_trunc = !LEAN && c.tl_trunc;
   const bool opt_done_list = !LEAN && io.done_count_dev != nullptr;
-  constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
+  constexpr int OBS = task_obs_dim(TASK);
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
   const uint32_t n = s.n;
@@ -685,9 +704,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
   uint32_t g[3];
   uint32_t meta;
   tile.load_state(raw, g, meta);
-  const float4 act = *at32<const float4>(io.actions_dev, (valid ? i : 0u) << 4);
+  const float4 act = load_action<TASK>(io.actions_dev, valid ? i : 0u);
   double prev_sh = 0.0;
-  if constexpr (TASK == CS_TASK_LANDER3D) prev_sh = (double)tile.load_prev();
+  if constexpr (task_is_lander(TASK)) prev_sh = (double)tile.load_prev();
   float ep_ret = 0.f;
   if (opt_stats) ep_ret = tile.load_ret();
 
@@ -725,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
   CS_STAMP(5);
   // ---- stores: 4 x 16 B (state, guards + meta) + prev_shaping ----
   tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
-  if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)e.prev_sh);
+  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (opt_stats) tile.store_ret(e.ep_ret);
   if (valid) {
     if (io.reward_dev) *at32<float>(io.reward_dev, i << 2) = (float)out.reward;
@@ -828,7 +847,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
-  constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
+  constexpr int OBS = task_obs_dim(TASK);
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
   const uint32_t n = s.n;
@@ -850,7 +869,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
   e.fe_dirty = false;
   e.prev_sh = 0.0;
-  if constexpr (TASK == CS_TASK_LANDER3D) e.prev_sh = (double)tile.load_prev();
+  if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
   const bool opt_stats = !LEAN && c.stats;
   e.ep_ret = opt_stats ? tile.load_ret() : 0.f;
   e.fe = tile.load_fe();
@@ -873,7 +892,8 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   io.terminated_dev = io.truncated_dev = nullptr;
   io.done_count_dev = io.done_ids_dev = io.done_length_dev = nullptr;
 
-  const uint32_t ia = (valid ? i : 0u) << 4;
+  constexpr int ACT = task_act_dim(TASK);
+  const uint32_t ia = valid ? i : 0u;
   float4 act = make_float4(0.f, 0.f, 0.f, 0.f);
   PidCtl ctl[4];
   float seen[OBS];  // the observation the policy acts on: what the previous step returned
@@ -888,18 +908,19 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
 #pragma unroll
     for (int j = 0; j < OBS; ++j) seen[j] = (float)e.x[j];
   } else {
-    act = *at32<const float4>(actions_dev, ia);
+    act = load_action<TASK>(actions_dev, ia);
   }
   for (int k = 0; k < num_steps; ++k) {
     // rows of step k (64-bit uniform offsets: K * N can exceed 32 bits)
     const size_t row = (size_t)k * n;
     float4 act_next = act;
     if constexpr (POLICY) {
+      static_assert(!POLICY || OBS >= 10, "the PID heuristic reads the 3D observation");
       act = pid_policy<OBS>(pc, ctl, seen);
-      if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia) = act;
+      if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
     } else {
       const int kn = (k + 1 < num_steps) ? k + 1 : k;
-      act_next = *at32<const float4>(actions_dev + (size_t)kn * n * 4, ia);  // prefetch
+      act_next = load_action<TASK>(actions_dev + (size_t)kn * n * ACT, ia);  // prefetch
     }
     StepOut<OBS> out;
     advance<TASK, MODE, OBS, false>(c, o, e, act, io, i, lane, valid, tile, out);
@@ -922,7 +943,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
 
   if (e.fe_dirty) tile.store_fe(e.fe);
   tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
-  if constexpr (TASK == CS_TASK_LANDER3D) tile.store_prev((T)e.prev_sh);
+  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (opt_stats) tile.store_ret(e.ep_ret);
   if constexpr (POLICY) {
 #pragma unroll
@@ -983,7 +1004,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
                                                        double* __restrict__ pid_state,
                                                        const uint32_t pid_stride) {
   using T = typename ModeOf<MODE>::T;
-  constexpr int OBS = (TASK == CS_TASK_LANDER3D) ? 10 : 12;
+  constexpr int OBS = task_obs_dim(TASK);
   const uint32_t n = s.n;
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
@@ -1017,8 +1038,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     uint32_t meta;
     tile.load_state(raw, g, meta);
 #pragma unroll
-    for (int k = 0; k < OBS; ++k)
-      obs[(size_t)i * OBS + k] = (float)decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
+    for (int k = 0; k < OBS; ++k) {
+      constexpr int FIRST = task_obs_first(TASK);
+      obs[(size_t)i * OBS + k] =
+          (float)decode_word<MODE>(raw[FIRST + k], g[(FIRST + k) >> 2], FIRST + k, c.guard_mask);
+    }
   }
 }
 
@@ -1026,68 +1050,97 @@ inline int grid_for(uint32_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
 
-hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
-                       const cs_step_io& io, hipStream_t stream) {
+// (task, mode) -> template instantiation
+#define CS_CASE3(FN, TASK, ...)                                         \
+  case TASK * 3 + CS_STATE_F32G:                                        \
+    return FN<TASK, CS_STATE_F32G>(__VA_ARGS__);                        \
+  case TASK * 3 + CS_STATE_F32_RN:                                      \
+    return FN<TASK, CS_STATE_F32_RN>(__VA_ARGS__);                      \
+  case TASK * 3 + CS_STATE_F64:                                         \
+    return FN<TASK, CS_STATE_F64>(__VA_ARGS__);
+#define CS_DISPATCH(FN, ...)                      \
+  switch (task * 3 + mode) {                      \
+    CS_CASE3(FN, CS_TASK_LANDER3D, __VA_ARGS__)   \
+    CS_CASE3(FN, CS_TASK_HOVER3D, __VA_ARGS__)    \
+    CS_CASE3(FN, CS_TASK_LANDER2D, __VA_ARGS__)   \
+    CS_CASE3(FN, CS_TASK_LANDER1D, __VA_ARGS__)   \
+    CS_CASE3(FN, CS_TASK_HOVER2D, __VA_ARGS__)    \
+    CS_CASE3(FN, CS_TASK_HOVER1D, __VA_ARGS__)    \
+    default:                                      \
+      return hipErrorInvalidValue;                \
+  }
+static_assert(CS_STATE_F32G == 0 && CS_STATE_F32_RN == 1 && CS_STATE_F64 == 2, "dispatch index");
+
+namespace {
+
+template <int TASK, int MODE>
+hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
   const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc &&
                     io.done_count_dev == nullptr && io.final_obs_dev == nullptr;
-#define CS_LAUNCH(TASK, MODE)                                                               \
-  if (task == TASK && mode == MODE) {                                                       \
-    if (lean)                                                                               \
-      hipLaunchKernelGGL((step_kernel<TASK, MODE, true>), grid, block, 0, stream, s.tiles, s.n,      \
-                         io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,             \
-                         io.truncated_dev, c, s, io);  \
-    else                                                                                    \
-      hipLaunchKernelGGL((step_kernel<TASK, MODE, false>), grid, block, 0, stream, s.tiles, s.n,     \
-                         io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,             \
-                         io.truncated_dev, c, s, io); \
-    return hipGetLastError();                                                               \
+  if (lean)
+    hipLaunchKernelGGL((step_kernel<TASK, MODE, true>), grid, block, 0, stream, s.tiles, s.n,
+                       io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,
+                       io.truncated_dev, c, s, io);
+  else
+    hipLaunchKernelGGL((step_kernel<TASK, MODE, false>), grid, block, 0, stream, s.tiles, s.n,
+                       io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,
+                       io.truncated_dev, c, s, io);
+  return hipGetLastError();
+}
+
+template <int TASK, int MODE>
+hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, float* actions,
+                       float* obs, float* reward, uint8_t* term, uint8_t* trunc,
+                       const PidConst* pid, double* pid_state, uint32_t pid_stride,
+                       hipStream_t stream) {
+  const dim3 grid(grid_for(s.n)), block(kBlock);
+  const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc;
+  const PidConst pc = pid ? *pid : PidConst{};
+#define CS_MANY(LEAN, POLICY)                                                                   \
+  hipLaunchKernelGGL((step_many_kernel<TASK, MODE, LEAN, POLICY>), grid, block, 0, stream,      \
+                     s.tiles, s.n, actions, obs, reward, term, trunc, num_steps, c, s, pc,      \
+                     pid_state, pid_stride)
+  if (pid != nullptr) {
+    if constexpr (task_act_dim(TASK) == 4) {  // the heuristic reads the 3D observation
+      if (lean)
+        CS_MANY(true, true);
+      else
+        CS_MANY(false, true);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  } else if (lean) {
+    CS_MANY(true, false);
+  } else {
+    CS_MANY(false, false);
   }
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F64)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_RN)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F64)
-#undef CS_LAUNCH
-  return hipErrorInvalidValue;
+#undef CS_MANY
+  return hipGetLastError();
+}
+
+template <int TASK, int MODE>
+hipError_t reset_t(const DevConst& c, const DevState& s, const uint8_t* mask, const float* force_xyz,
+                   float* obs, double* pid_state, uint32_t pid_stride, hipStream_t stream) {
+  const dim3 grid(grid_for(s.n)), block(kBlock);
+  hipLaunchKernelGGL((reset_kernel<TASK, MODE>), grid, block, 0, stream, c, s, mask, force_xyz, obs,
+                     pid_state, pid_stride);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
+                       const cs_step_io& io, hipStream_t stream) {
+  CS_DISPATCH(step_t, c, s, io, stream)
 }
 
 hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
                             float* actions, float* obs, float* reward, uint8_t* term,
                             uint8_t* trunc, const PidConst* pid, double* pid_state,
                             uint32_t pid_stride, hipStream_t stream) {
-  const dim3 grid(grid_for(s.n)), block(kBlock);
-  const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc;
-  const PidConst pc = pid ? *pid : PidConst{};
-#define CS_ARGS s.tiles, s.n, actions, obs, reward, term, trunc, num_steps, c, s, pc, pid_state, pid_stride
-#define CS_LAUNCH(TASK, MODE)                                                                       \
-  if (task == TASK && mode == MODE) {                                                               \
-    if (pid != nullptr) {                                                                           \
-      if (lean)                                                                                     \
-        hipLaunchKernelGGL((step_many_kernel<TASK, MODE, true, true>), grid, block, 0, stream,      \
-                           CS_ARGS);                                                                \
-      else                                                                                          \
-        hipLaunchKernelGGL((step_many_kernel<TASK, MODE, false, true>), grid, block, 0, stream,     \
-                           CS_ARGS);                                                                \
-    } else if (lean) {                                                                              \
-      hipLaunchKernelGGL((step_many_kernel<TASK, MODE, true, false>), grid, block, 0, stream,       \
-                         CS_ARGS);                                                                  \
-    } else {                                                                                        \
-      hipLaunchKernelGGL((step_many_kernel<TASK, MODE, false, false>), grid, block, 0, stream,      \
-                         CS_ARGS);                                                                  \
-    }                                                                                               \
-    return hipGetLastError();                                                                       \
-  }
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F64)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_RN)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F64)
-#undef CS_LAUNCH
-#undef CS_ARGS
-  return hipErrorInvalidValue;
+  CS_DISPATCH(step_many_t, c, s, num_steps, actions, obs, reward, term, trunc, pid, pid_state,
+              pid_stride, stream)
 }
 
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,
@@ -1108,21 +1161,7 @@ hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, con
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,
                         const uint8_t* mask, const float* force_xyz, float* obs,
                         double* pid_state, uint32_t pid_stride, hipStream_t stream) {
-  const dim3 grid(grid_for(s.n)), block(kBlock);
-#define CS_LAUNCH(TASK, MODE)                                                          \
-  if (task == TASK && mode == MODE) {                                                  \
-    hipLaunchKernelGGL((reset_kernel<TASK, MODE>), grid, block, 0, stream, c, s, mask, \
-                       force_xyz, obs, pid_state, pid_stride);                         \
-    return hipGetLastError();                                                          \
-  }
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F32_RN)
-  CS_LAUNCH(CS_TASK_LANDER3D, CS_STATE_F64)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32G)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F32_RN)
-  CS_LAUNCH(CS_TASK_HOVER3D, CS_STATE_F64)
-#undef CS_LAUNCH
-  return hipErrorInvalidValue;
+  CS_DISPATCH(reset_t, c, s, mask, force_xyz, obs, pid_state, pid_stride, stream)
 }
 
 }  // namespace cs

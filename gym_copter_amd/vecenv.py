@@ -25,7 +25,15 @@ from . import _lib
 from .spaces import Box, batch_space
 
 _TASKS = {"lander3d": _lib.TASK_LANDER3D, "lander": _lib.TASK_LANDER3D,
-          "hover3d": _lib.TASK_HOVER3D, "hover": _lib.TASK_HOVER3D}
+          "hover3d": _lib.TASK_HOVER3D, "hover": _lib.TASK_HOVER3D,
+          # 2D / 1D variants (attic lander2d.py / lander1d.py / hover2d.py / hover1d.py hooks)
+          "lander2d": _lib.TASK_LANDER2D, "lander1d": _lib.TASK_LANDER1D,
+          "hover2d": _lib.TASK_HOVER2D, "hover1d": _lib.TASK_HOVER1D}
+_TASK_NAMES = {_lib.TASK_LANDER3D: "lander3d", _lib.TASK_HOVER3D: "hover3d", _lib.TASK_LANDER2D: "lander2d",
+               _lib.TASK_LANDER1D: "lander1d", _lib.TASK_HOVER2D: "hover2d", _lib.TASK_HOVER1D: "hover1d"}
+# task -> (first observed state slot, observation size, action size)
+_TASK_SHAPES = {"lander3d": (0, 10, 4), "hover3d": (0, 12, 4), "lander2d": (2, 6, 2), "hover2d": (2, 6, 2),
+                "lander1d": (4, 2, 1), "hover1d": (4, 2, 1)}
 # float32 (default) = float32 state words + 8 guard bits; see DESIGN.md "state words"
 _STATE_MODES = {"float32": _lib.STATE_F32G, "float32_guard": _lib.STATE_F32G,
                 "float32_rn": _lib.STATE_F32_RN, "float64": _lib.STATE_F64}
@@ -90,22 +98,26 @@ class CopterVecEnv:
                 raise TypeError("unexpected keyword argument %r" % k)
             setattr(cfg, _TASK_KEYS[k], float(v))
         self.config = cfg
-        self.task = "lander3d" if cfg.task == _lib.TASK_LANDER3D else "hover3d"
+        self.task = _TASK_NAMES[cfg.task]
         self.num_envs = int(num_envs)
         self.autoreset_mode = autoreset_mode
         self.episode_stats = bool(episode_stats)
         self.device = torch.device("cuda", int(device))
-        self.obs_dim = 10 if cfg.task == _lib.TASK_LANDER3D else 12
-        self.STATE_NAMES = STATE_NAMES_12[:self.obs_dim]          # lander.py:30-31
+        first, self.obs_dim, self.action_dim = _TASK_SHAPES[self.task]
+        self.STATE_NAMES = STATE_NAMES_12[first:first + self.obs_dim]   # lander.py:30-31
         self.metadata = {"render_modes": [], "render_fps": self.FRAMES_PER_SECOND,
                          "autoreset_mode": autoreset_mode}
         self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)  # task.py:46-49
-        self.single_action_space = Box(-1, +1, (4,), np.float32)                            # task.py:52-55
+        self.single_action_space = Box(-1, +1, (self.action_dim,), np.float32)              # task.py:52-55
         self.observation_space = batch_space(self.single_observation_space, self.num_envs)
         self.action_space = batch_space(self.single_action_space, self.num_envs)
         self.closed = False
         # cs_create fails loudly when no HIP device is usable (no CPU fallback)
         _lib.check(lib.cs_create(C.byref(cfg), C.byref(self._ctx)))
+        od, ad = C.c_int32(), C.c_int32()
+        _lib.check(lib.cs_obs_dim(self._ctx, C.byref(od)))
+        _lib.check(lib.cs_action_dim(self._ctx, C.byref(ad)))
+        assert (od.value, ad.value) == (self.obs_dim, self.action_dim), "library / binding disagree on shapes"
         n = self.num_envs
         with torch.cuda.device(self.device):
             self._obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=self.device)
@@ -187,7 +199,7 @@ class CopterVecEnv:
         buffers (overwritten by the next step())."""
         self._check_open()
         torch = _torch()
-        a, was_numpy = self._dev_f32(actions, (self.num_envs, 4), "actions")
+        a, was_numpy = self._dev_f32(actions, (self.num_envs, self.action_dim), "actions")
         with torch.cuda.device(self.device):
             if self._final_obs is None and self._done is None:
                 _lib.check(self._lib.cs_step(
@@ -230,8 +242,9 @@ class CopterVecEnv:
         torch = _torch()
         if not isinstance(actions, torch.Tensor):
             actions = torch.from_numpy(np.ascontiguousarray(np.asarray(actions, dtype=np.float32)))
-        if actions.dim() != 3 or tuple(actions.shape[1:]) != (self.num_envs, 4):
-            raise ValueError("actions must have shape (K, %d, 4), got %s" % (self.num_envs, tuple(actions.shape)))
+        if actions.dim() != 3 or tuple(actions.shape[1:]) != (self.num_envs, self.action_dim):
+            raise ValueError("actions must have shape (K, %d, %d), got %s"
+                             % (self.num_envs, self.action_dim, tuple(actions.shape)))
         a = actions.to(device=self.device, dtype=torch.float32).contiguous()
         K, n = int(a.shape[0]), self.num_envs
         buf = getattr(self, "_many", None)

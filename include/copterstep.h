@@ -56,7 +56,21 @@ typedef enum cs_status {
   CS_ERR_ABI = -5       /* cs_config.struct_size / abi_version mismatch */
 } cs_status;
 
-enum { CS_TASK_LANDER3D = 0, CS_TASK_HOVER3D = 1 };
+/* 3D tasks: action [4] = the four motors; observation 10 (Lander3D: x..dtheta) or 12 (Hover3D).
+ * 2D / 1D variants: the _get_motors fan-out and _get_state sub-selection of the retired variant
+ * classes (attic/gym_copter/envs/lander2d.py:43-50, lander1d.py:43-48, hover2d.py:44-50,
+ * hover1d.py:44-50) on the same step / reward code (task.py:94, :133):
+ *   2D: action [2] -> motors (a0,a1,a1,a0), observation (y,dy,z,dz,phi,dphi)
+ *   1D: action [1] -> motors (a0,a0,a0,a0), observation (z,dz) */
+enum {
+  CS_TASK_LANDER3D = 0,
+  CS_TASK_HOVER3D = 1,
+  CS_TASK_LANDER2D = 2,
+  CS_TASK_LANDER1D = 3,
+  CS_TASK_HOVER2D = 4,
+  CS_TASK_HOVER1D = 5,
+  CS_TASK_COUNT = 6
+};
 
 /* How the 12 state words are kept in HBM.  Arithmetic is float64 in registers in
  * every mode; the mode only selects the stored word and its rounding. */
@@ -133,6 +147,7 @@ int cs_destroy(cs_ctx* ctx);
 
 int cs_num_envs(const cs_ctx* ctx, int64_t* out);
 int cs_obs_dim(const cs_ctx* ctx, int32_t* out);
+int cs_action_dim(const cs_ctx* ctx, int32_t* out); /* 4, 2 (2D variants) or 1 (1D variants) */
 int cs_seed(cs_ctx* ctx, uint64_t seed);
 int cs_set_altitude(cs_ctx* ctx, double altitude);
 /* Reset envs with mask_dev[i] != 0 (NULL = all).  force_xyz_dev: [3,N] perturbation

@@ -91,7 +91,8 @@ def test_spaces_and_registry():
     b = Box(-1, 1, (4,), np.float32)
     assert b.shape == (4,) and b.dtype == np.float32 and b.contains(b.sample())
     assert b.high[0] == 1 and not b.contains(np.full(4, 2, np.float32))
-    assert set(gym_copter_amd._REGISTRY) == {"Lander-v0", "Lander3D-v0", "Hover3D-v0"}
+    assert set(gym_copter_amd._REGISTRY) == {"Lander-v0", "Lander3D-v0", "Hover3D-v0", "Lander2D-v0",
+                                             "Lander1D-v0", "Hover2D-v0", "Hover1D-v0"}
 
 
 def test_c_host_builds_and_reports_missing_device():
