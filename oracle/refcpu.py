@@ -80,8 +80,9 @@ class TaskParams:
 class RigidBody:
     """One quad-X rigid body, forward-Euler integrated in Euler angles."""
 
-    def __init__(self, vp=DJI_PHANTOM, frames_per_second=100):
+    def __init__(self, vp=DJI_PHANTOM, frames_per_second=100, g=G):
         self.vp = vp
+        self.g = g                       # Dynamics.G (a class constant upstream, :76)
         self.dt = 1. / frames_per_second
         self.ticks = 0
         self.x = np.zeros(12)
@@ -135,7 +136,7 @@ class RigidBody:
         Omega = 0                                             # rotor-inertia term disabled upstream
 
         acc = self._thrust_ned(-U1 / p.M, self.x[PHI], self.x[THETA], self.x[PSI])
-        netz = acc[2] + G
+        netz = acc[2] + self.g
 
         if self.status == LANDED and netz < 0:
             self.status = AIRBORNE
@@ -181,9 +182,9 @@ class TaskOracle:
     """Single-environment Lander / Hover task (3D, or a 2D / 1D variant) around one RigidBody."""
 
     def __init__(self, task="lander3d", tp=TaskParams(), vp=DJI_PHANTOM, substeps=1,
-                 action_dtype_passthrough=False):
+                 action_dtype_passthrough=False, g=G):
         assert task in TASKS
-        self.task, self.tp, self.vp = task, tp, vp
+        self.task, self.tp, self.vp, self.g = task, tp, vp, g
         self.kind, self.obs_first, self.obs_dim, self.fan = TASKS[task]
         self.act_dim = task_action_dim(task)
         self.substeps = substeps
@@ -195,7 +196,7 @@ class TaskOracle:
     def reset(self, force_xyz=None, rng=None):
         tp = self.tp
         self.prev_shaping = None
-        self.body = RigidBody(self.vp, tp.frames_per_second * self.substeps)
+        self.body = RigidBody(self.vp, tp.frames_per_second * self.substeps, self.g)
         x0 = np.zeros(12)
         x0[Z] = -tp.initial_altitude
         self.body.set_state(x0)

@@ -104,9 +104,11 @@ class VecOracle:
 
     def __init__(self, task="lander3d", num_envs=1, tp=TaskParams(), vp=DJI_PHANTOM,
                  substeps=1, store_mode="float64", autoreset=AUTORESET_DISABLED,
-                 seed=0, env_id_base=0, time_limit_truncates=False):
+                 seed=0, env_id_base=0, time_limit_truncates=False, g=G):
+        # vp's fields and g may be arrays [n]: per-env vehicles / worlds (domain randomisation)
         assert task in TASKS
         self.task, self.n, self.tp, self.vp = task, int(num_envs), tp, vp
+        self.g = g
         self.kind, self.obs_first, self.obs_dim, fan = TASKS[task]
         self.fan = np.array(fan)
         self.act_dim = task_action_dim(task)
@@ -139,7 +141,8 @@ class VecOracle:
         motors [n,4] f64 (already clipped by the task, or raw in dynamics-only use).
         """
         p = self.vp
-        w = motors * p.maxrpm * np.pi / 30
+        maxrpm = np.asarray(p.maxrpm, dtype=np.float64)
+        w = motors * (maxrpm[:, None] if maxrpm.ndim else maxrpm) * np.pi / 30
         w2 = w ** 2
         w0, w1, w2_, w3 = w2[:, 0], w2[:, 1], w2[:, 2], w2[:, 3]
         U1 = p.B * (((w0 + w1) + w2_) + w3)
@@ -155,7 +158,7 @@ class VecOracle:
         ax = bz * (sph * sps + cph * cps * sth)
         ay = bz * (cph * sps * sth - cps * sph)
         az = bz * (cph * cth)
-        netz = az + G
+        netz = az + self.g
 
         st = status.copy()
         st[active & (st == LANDED) & (netz < 0)] = AIRBORNE

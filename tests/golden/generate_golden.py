@@ -358,6 +358,48 @@ def v_series(_Task, Lander, vp):
     return cases
 
 
+def w_series(Dynamics, Lander, vp):
+    """Other vehicles / worlds on the LIVE code: the reference's Lander flown with a different
+    `vehicle_params` dict (the module global that task.py:161 hands to Dynamics) and a different
+    gravity constant (Dynamics.G, dynamics/__init__.py:76).  Parameter sets: a heavier airframe,
+    a light fast one, and Mars gravity with the weak rotors of attic/mars/dynamics/ingenuity.py
+    (G = 3.721).  All values are float32-representable."""
+    task_mod = importlib.import_module("gym_copter.envs.task")
+    rng = np.random.default_rng(990)
+    worlds = {
+        "heavy": (dict(B=6.5e-3, D=2.5e-6, M=2.5, L=0.45, Ix=3.0, Iy=2.5, Iz=4.5, Jr=38e-4, maxrpm=12000), 9.80665),
+        "light": (dict(B=3.0e-3, D=1.0e-6, M=0.75, L=0.25, Ix=1.0, Iy=1.25, Iz=2.0, Jr=38e-4, maxrpm=18000), 9.80665),
+        "mars": (dict(B=2.0e-3, D=2.0e-6, M=1.8, L=0.6, Ix=2.5, Iy=2.0, Iz=3.5, Jr=38e-4, maxrpm=15000), 3.721),
+    }
+    T = 1100
+    cases = {}
+    saved_vp, saved_g = task_mod.vehicle_params, Dynamics.G
+    try:
+        for name, (v, g) in worlds.items():
+            v = {k: float(np.float32(val)) for k, val in v.items()}
+            g = float(np.float32(g))
+            task_mod.vehicle_params = v
+            Dynamics.G = g
+            hov = hover_motor(v, g)
+            extra = dict(vehicle=np.array([v[k] for k in ("B", "D", "M", "L", "Ix", "Iy", "Iz", "Jr", "maxrpm")] + [g]))
+            laws = {
+                "const": f32r(0.98 * hov) * np.ones((T, 4)),
+                "noisy_hover": f32r(hov * (1 + 0.01 * rng.standard_normal((T, 4)))),
+                "uniform": f32r(rng.uniform(-1, 1, (T, 4))),
+                "yaw_roll": f32r(hov * np.array([1.02, 1.0, 0.99, 0.99])) * np.ones((T, 4)),
+            }
+            for j, (law, acts) in enumerate(laws.items()):
+                c = run_env(Lander(), acts, seed=60 + j)
+                c.update(extra)
+                cases["W_%s_%s" % (name, law)] = c
+            c = run_env(Lander(), f32r(0.97 * hov) * np.ones((T, 4)), seed=70, altitude=0.05)
+            c.update(extra)
+            cases["W_%s_soft_landing" % name] = c
+    finally:
+        task_mod.vehicle_params, Dynamics.G = saved_vp, saved_g
+    return cases
+
+
 def save(name, cases):
     flat = {}
     for cname, c in cases.items():
@@ -375,6 +417,7 @@ def main():
     save("env_traces.npz", e_series(_Task, Lander, vp))
     save("pid_traces.npz", p_series(Lander, load_mars_pid()))
     save("variant_traces.npz", v_series(_Task, Lander, vp))
+    save("vehicle_traces.npz", w_series(Dynamics, Lander, vp))
     # known-answer constants observed from the reference (used as spot checks)
     meta = dict(numpy_version=np.array(np.__version__), hover_motor=np.float64(hover_motor(vp)))
     np.savez(os.path.join(OUT, "meta.npz"), **meta)

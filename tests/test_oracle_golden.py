@@ -93,3 +93,25 @@ def test_pid_heuristic_closed_loop_bit_exact(name):
         obs, r, done, _, _ = env.step(a)
         assert np.array_equal(obs, g["obs"][t]) and r == g["reward"][t] and done == g["done"][t], (name, t)
         assert np.array_equal(env.body.x, g["x"][t]), (name, t)
+
+
+VEH = load_cases("vehicle_traces.npz")
+
+
+def _vehicle(g):
+    from oracle.refcpu import VehicleParams
+    v = g["vehicle"]
+    return VehicleParams(*[float(t) for t in v[:9]]), float(v[9])
+
+
+@pytest.mark.parametrize("name", VEH.names())
+def test_other_vehicles_and_worlds_bit_exact(name):
+    """Episodes the reference's Lander flew with other vehicle_params dicts / gravity constants."""
+    g = VEH[name]
+    vp, grav = _vehicle(g)
+    o = TaskOracle("lander3d", TaskParams(initial_altitude=float(g["altitude"])), vp=vp, g=grav)
+    assert np.array_equal(o.reset(force_xyz=g["force"]), g["obs0"])
+    for t, a in enumerate(g["actions"]):
+        obs, r, done, _, _ = o.step(a)
+        assert np.array_equal(obs, g["obs"][t]) and r == g["reward"][t] and done == g["done"][t], (name, t)
+        assert o.body.status == g["status"][t] and np.array_equal(o.body.x, g["x"][t]), (name, t)

@@ -236,3 +236,30 @@ def test_vecpid_matches_scalar_heuristic_closed_loop():
                 o2, ri, di, _, _ = env.step(ai.astype(np.float64))
                 assert np.array_equal(o2, obs[i]) and ri == r[i] and di == term[i], (t, i)
                 scal[i] = (env, pol, o2)
+
+
+def test_vec_per_env_vehicles_bit_exact_in_batch():
+    """All golden other-vehicle / other-world episodes as ONE batch with per-env parameter arrays."""
+    from conftest import load_cases
+    from oracle.refcpu import VehicleParams
+    VEH = load_cases("vehicle_traces.npz")
+    for alt in (10.0, 0.05):
+        cs = [c for c in VEH.names() if float(VEH[c]["altitude"]) == alt]
+        n = len(cs)
+        veh = np.stack([VEH[c]["vehicle"] for c in cs], axis=1)          # [10, n]
+        vp = VehicleParams(*[veh[j].copy() for j in range(9)])
+        T = max(len(VEH[c]["reward"]) for c in cs)
+        acts = np.zeros((T, n, 4))
+        forces = np.zeros((3, n))
+        for i, c in enumerate(cs):
+            acts[:len(VEH[c]["actions"]), i] = VEH[c]["actions"]
+            forces[:, i] = VEH[c]["force"]
+        o = VecOracle("lander3d", n, TaskParams(initial_altitude=alt), vp=vp, g=veh[9].copy())
+        o.reset(forces=forces)
+        for t in range(T):
+            obs, r, term, _ = o.step(acts[t])
+            for i, c in enumerate(cs):
+                g = VEH[c]
+                if t < len(g["reward"]):
+                    assert np.array_equal(obs[i], g["obs"][t]) and r[i] == g["reward"][t], (c, t)
+                    assert term[i] == g["done"][t] and np.array_equal(o.x[:, i], g["x"][t]), (c, t)
