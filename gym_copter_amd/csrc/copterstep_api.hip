@@ -20,6 +20,7 @@ struct cs_ctx {
   cs::PidConst pid{};
   double* pid_state = nullptr;
   uint32_t pid_stride = 0;
+  double* veh = nullptr;  // per-env coefficient columns (cs_set_vehicle_params), owned
 };
 
 namespace {
@@ -234,6 +235,7 @@ int cs_destroy(cs_ctx* ctx) {
   (void)hipSetDevice(ctx->cfg.device);
   if (ctx->st.tiles) (void)hipFree(ctx->st.tiles);
   if (ctx->pid_state) (void)hipFree(ctx->pid_state);
+  if (ctx->veh) (void)hipFree(ctx->veh);
   delete ctx;
   return CS_OK;
 }
@@ -319,6 +321,40 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
                                       terminated_dev, truncated_dev, nullptr, nullptr, 0,
                                       (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_step_many: kernel launch");
+  return CS_OK;
+}
+
+int cs_set_vehicle_params(cs_ctx* ctx, const double* params_host) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  CS_HIP(hipSetDevice(ctx->cfg.device));
+  CS_HIP(hipDeviceSynchronize());
+  if (params_host == nullptr) {  // back to the uniform vehicle of cs_config
+    ctx->st.veh = nullptr;
+    ctx->st.veh_stride = 0;
+    return CS_OK;
+  }
+  const size_t n = (size_t)ctx->cfg.num_envs;
+  const uint32_t stride = ctx->st.ntiles * 64u;  // padded like the tiles: no bounds checks on device
+  const double* P = params_host;
+  auto at = [&](int row, size_t i) { return P[(size_t)row * n + i]; };
+  std::vector<double> cols((size_t)9 * stride, 0.0);
+  const double pi = 3.14159265358979323846;
+  for (size_t i = 0; i < n; ++i) {
+    const double B = at(0, i), D = at(1, i), M = at(2, i), L = at(3, i), Ix = at(4, i), Iy = at(5, i),
+                 Iz = at(6, i), maxrpm = at(8, i), G = at(9, i);
+    if (!(M > 0.0) || !(Ix > 0.0) || !(Iy > 0.0) || !(Iz > 0.0) || !std::isfinite(B * D * L * maxrpm * G))
+      return fail(CS_ERR_ARG, "cs_set_vehicle_params: env " + std::to_string(i) +
+                                  ": M, Ix, Iy, Iz must be positive and every value finite");
+    // the same folding as make_const()
+    const double ws = maxrpm * pi / 30.0, ws2 = ws * ws;
+    const double v[9] = {-(B * ws2) / M,  (L * B * ws2) / Ix, (L * B * ws2) / Iy, (D * ws2) / Iz, G,
+                         (Iy - Iz) / Ix, (Iz - Ix) / Iy,     (Ix - Iy) / Iz,     2.0 / M};
+    for (int j = 0; j < 9; ++j) cols[(size_t)j * stride + i] = v[j];
+  }
+  if (ctx->veh == nullptr) CS_HIP(hipMalloc((void**)&ctx->veh, cols.size() * sizeof(double)));
+  CS_HIP(hipMemcpy(ctx->veh, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice));
+  ctx->st.veh = ctx->veh;
+  ctx->st.veh_stride = stride;
   return CS_OK;
 }
 

@@ -141,6 +141,10 @@ struct DevState {
   char* tiles;      // ntiles * tile_bytes
   uint32_t n;       // envs
   uint32_t ntiles;  // allocated tiles: a multiple of 4 that covers the whole launch grid
+  // per-env vehicle / world coefficients (cs_set_vehicle_params): [9][veh_stride] float64 rows
+  // k_thrust, k_roll, k_pitch, k_yaw, G, c_dphi, c_dthe, c_dpsi, two_inv_M; nullptr = uniform
+  const double* veh;
+  uint32_t veh_stride;
 #ifdef CS_STAMPS
   unsigned long long* stamps;  // diagnostic build: [ntiles][8] shader-clock stamps
 #endif

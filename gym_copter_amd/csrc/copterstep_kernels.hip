@@ -335,6 +335,26 @@ __device__ __forceinline__ double sqrt_f64(double a) {
 // ---------------------------------------------------------------------------------
 // physics
 // ---------------------------------------------------------------------------------
+// The coefficients the rigid-body model needs from the vehicle and the world, with every
+// uniform factor folded in on the host (see DevConst).  Uniform for the batch (scalar
+// registers) or, with cs_set_vehicle_params, one set per env (vector registers).
+struct Coef {
+  double k_thrust, k_roll, k_pitch, k_yaw, G, c_dphi, c_dthe, c_dpsi, two_inv_M;
+};
+constexpr int kCoefRows = 9;
+
+__device__ __forceinline__ Coef uniform_coef(const DevConst& c) {
+  return Coef{c.k_thrust, c.k_roll, c.k_pitch, c.k_yaw, c.G, c.c_dphi, c.c_dthe, c.c_dpsi, c.two_inv_M};
+}
+
+// per-env coefficient columns: [kCoefRows][stride] float64, coalesced 8 B per lane
+__device__ __forceinline__ Coef load_coef(const double* veh, uint32_t stride, uint32_t i) {
+  double v[kCoefRows];
+#pragma unroll
+  for (int j = 0; j < kCoefRows; ++j) v[j] = veh[(size_t)j * stride + i];
+  return Coef{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
+}
+
 struct Wrench {  // per-env, constant across substeps
   double bz;     // -U1 / M          body-Z acceleration
   double aphi;   // U2 / Ix
@@ -345,7 +365,7 @@ struct Wrench {  // per-env, constant across substeps
 // dynamics/__init__.py:120-132 + _u2/_u3/_u4 (:231-247).  The squares of the motor
 // values are exact in float64 (24-bit inputs); the uniform factors (maxrpm*pi/30)^2,
 // B, L*B, D and the 1/M, 1/I divisions are folded into one host-side constant each.
-__device__ __forceinline__ Wrench motor_model(const DevConst& c, float a0, float a1, float a2,
+__device__ __forceinline__ Wrench motor_model(const Coef& c, float a0, float a1, float a2,
                                               float a3) {
   const double m0 = (double)a0, m1 = (double)a1, m2 = (double)a2, m3 = (double)a3;
   const double q0 = m0 * m0, q1 = m1 * m1, q2 = m2 * m2, q3 = m3 * m3;
@@ -365,8 +385,9 @@ enum { kCallOther = 0, kCallIntegrated = 1, kCallFroze = 2 };
 // (px,py,pz) = 2*force/M, the pending reset perturbation in its doubled form (upstream
 // adds it inside the derivative, :263-271, and again at :183), zero when none is
 // pending.  Returns what the call did.
-__device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, double (&x)[12],
-                                            int& fs, double px, double py, double pz) {
+__device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, const Wrench& w,
+                                            double (&x)[12], int& fs, double px, double py,
+                                            double pz) {
   double sph, cph, sth, cth, sps, cps;
   // roll and pitch of a live env are inside +-pi/4 (the task ends the episode beyond,
   // task.py:116): when that holds for the whole wavefront the reduction is the identity
@@ -381,7 +402,7 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, 
   sincos_f64(c, x[10], sps, cps);
   const double ax = w.bz * fma(cph * cps, sth, sph * sps);
   const double ay = w.bz * fma(cph * sps, sth, -(cps * sph));
-  const double netz = fma(w.bz, cph * cth, c.G);
+  const double netz = fma(w.bz, cph * cth, q.G);
 
   if (fs == CS_STATUS_LANDED && netz < 0.0) fs = CS_STATUS_AIRBORNE;
   const bool leveling = fs == CS_STATUS_LEVELING;
@@ -394,9 +415,9 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, 
 
   const double dt = integ ? c.dt : 0.0;
   const double dphi = x[7], dthe = x[9], dpsi = x[11];
-  const double d7 = fma(dpsi * dthe, c.c_dphi, w.aphi);
-  const double d9 = -fma(dpsi * dphi, c.c_dthe, w.athe);
-  const double d11 = fma(dthe * dphi, c.c_dpsi, w.apsi);
+  const double d7 = fma(dpsi * dthe, q.c_dphi, w.aphi);
+  const double d9 = -fma(dpsi * dphi, q.c_dthe, w.athe);
+  const double d11 = fma(dthe * dphi, q.c_dpsi, w.apsi);
   x[0] = fma(dt, x[1], x[0]);
   x[2] = fma(dt, x[3], x[2]);
   x[4] = fma(dt, x[5], x[4]);
@@ -419,15 +440,15 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Wrench& w, 
 // f[] in newtons) can only enter the FIRST call: a call that freezes on ground contact
 // keeps it, but the status it leaves (CRASHED / LEVELING) makes the next call drop it.
 template <class T>
-__device__ __forceinline__ void physics_substeps(const DevConst& c, const Wrench& w,
+__device__ __forceinline__ void physics_substeps(const DevConst& c, const Coef& q, const Wrench& w,
                                                  double (&x)[12], int& fs, bool& pend,
                                                  const Vec4<T>& f) {
-  double px = pend ? (double)f.v[0] * c.two_inv_M : 0.0;
-  double py = pend ? (double)f.v[1] * c.two_inv_M : 0.0;
-  double pz = pend ? (double)f.v[2] * c.two_inv_M : 0.0;
+  double px = pend ? (double)f.v[0] * q.two_inv_M : 0.0;
+  double py = pend ? (double)f.v[1] * q.two_inv_M : 0.0;
+  double pz = pend ? (double)f.v[2] * q.two_inv_M : 0.0;
 #pragma clang loop unroll(disable)
   for (int sub = 0; sub < c.nsub; ++sub) {
-    const int what = physics_call(c, w, x, fs, px, py, pz);
+    const int what = physics_call(c, q, w, x, fs, px, py, pz);
     // a call that froze keeps the perturbation (upstream's early return); it is inert
     // there (dt = 0) and the next call, which cannot integrate either, drops it
     const bool keep = pend && what == kCallFroze;
@@ -535,8 +556,8 @@ __device__ __forceinline__ float4 load_action(const float* base, uint32_t env) {
 // after this call, so a reset writes the FE group from inside its branch and does not keep
 // the register copies (x, fe) up to date.
 template <int TASK, int MODE, int OBS, bool ONE_STEP>
-__device__ __forceinline__ void advance(const DevConst& c, const StepOpts& o, Env<MODE>& e,
-                                        const float4 act, const cs_step_io& io, uint32_t i,
+__device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const StepOpts& o,
+                                        Env<MODE>& e, const float4 act, const cs_step_io& io, uint32_t i,
                                         int lane, bool valid, const TileIO<MODE>& tile,
                                         StepOut<OBS>& out) {
   using T = typename ModeOf<MODE>::T;
@@ -550,8 +571,8 @@ __device__ __forceinline__ void advance(const DevConst& c, const StepOpts& o, En
   const int status0 = e.fs;
   if (!resetting && status0 != CS_STATUS_LANDED) {
     // np.clip(action, 0, 1), task.py:91
-    const Wrench w = motor_model(c, clip01(act.x), clip01(act.y), clip01(act.z), clip01(act.w));
-    physics_substeps(c, w, e.x, e.fs, e.pend, e.fe);
+    const Wrench w = motor_model(q, clip01(act.x), clip01(act.y), clip01(act.z), clip01(act.w));
+    physics_substeps(c, q, w, e.x, e.fs, e.pend, e.fe);
   }
 
   // ---- round to the stored word; everything below sees exactly what is stored ----
@@ -738,8 +759,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
 #endif
   CS_STAMP(1);
 
+  // vehicle / world coefficients: uniform, or this env's own (full-featured build only)
+  Coef q = uniform_coef(c);
+  if constexpr (!LEAN) {
+    if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
+  }
   StepOut<OBS> out;
-  advance<TASK, MODE, OBS, true>(c, o, e, act, io, i, lane, valid, tile, out);
+  advance<TASK, MODE, OBS, true>(c, q, o, e, act, io, i, lane, valid, tile, out);
 
   CS_STAMP(5);
   // ---- stores: 4 x 16 B (state, guards + meta) + prev_shaping ----
@@ -894,6 +920,10 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
 
   constexpr int ACT = task_act_dim(TASK);
   const uint32_t ia = valid ? i : 0u;
+  Coef q = uniform_coef(c);
+  if constexpr (!LEAN) {
+    if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
+  }
   float4 act = make_float4(0.f, 0.f, 0.f, 0.f);
   PidCtl ctl[4];
   float seen[OBS];  // the observation the policy acts on: what the previous step returned
@@ -923,7 +953,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       act_next = load_action<TASK>(actions_dev + (size_t)kn * n * ACT, ia);  // prefetch
     }
     StepOut<OBS> out;
-    advance<TASK, MODE, OBS, false>(c, o, e, act, io, i, lane, valid, tile, out);
+    advance<TASK, MODE, OBS, false>(c, q, o, e, act, io, i, lane, valid, tile, out);
     if constexpr (POLICY) {
 #pragma unroll
       for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
@@ -978,8 +1008,9 @@ __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, co
   bool pend = (meta & kMetaPerturbPending) != 0;
   Vec4<T> fe = {{(T)0, (T)0, (T)0, (T)0}};
   if (pend) fe = tile.load_fe();
-  const Wrench w = motor_model(c, mv.x, mv.y, mv.z, mv.w);
-  physics_substeps(c, w, x, fs, pend, fe);
+  const Coef q = s.veh != nullptr ? load_coef(s.veh, s.veh_stride, i) : uniform_coef(c);
+  const Wrench w = motor_model(q, mv.x, mv.y, mv.z, mv.w);
+  physics_substeps(c, q, w, x, fs, pend, fe);
   T xs[12];
   uint32_t gs[3] = {0, 0, 0};
 #pragma unroll
@@ -1077,7 +1108,7 @@ template <int TASK, int MODE>
 hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
   const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc &&
-                    io.done_count_dev == nullptr && io.final_obs_dev == nullptr;
+                    io.done_count_dev == nullptr && io.final_obs_dev == nullptr && s.veh == nullptr;
   if (lean)
     hipLaunchKernelGGL((step_kernel<TASK, MODE, true>), grid, block, 0, stream, s.tiles, s.n,
                        io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,
@@ -1095,7 +1126,7 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
                        const PidConst* pid, double* pid_state, uint32_t pid_stride,
                        hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
-  const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc;
+  const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc && s.veh == nullptr;
   const PidConst pc = pid ? *pid : PidConst{};
 #define CS_MANY(LEAN, POLICY)                                                                   \
   hipLaunchKernelGGL((step_many_kernel<TASK, MODE, LEAN, POLICY>), grid, block, 0, stream,      \

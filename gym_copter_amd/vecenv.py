@@ -261,6 +261,35 @@ class CopterVecEnv:
         self._keep = a
         return buf[0], buf[1], buf[2].view(torch.bool), buf[3].view(torch.bool)
 
+    # -- per-env vehicles / worlds (domain randomisation) --------------------------------
+    VEHICLE_ROWS = _VEHICLE_KEYS + ("G",)
+
+    def set_vehicle_params(self, params=None, **columns):
+        """Give every env its own vehicle and gravity: `params` is [10, N] (rows B, D, M, L, Ix,
+        Iy, Iz, Jr, maxrpm, G -- the reference's `vehicle_params` keys, dji_phantom.py:9-26, plus
+        Dynamics.G), or pass columns by name (scalars or [N]); unnamed ones keep this env's
+        configured values.  set_vehicle_params(None) returns to the uniform vehicle."""
+        self._check_open()
+        torch = _torch()
+        if params is None and not columns:
+            with torch.cuda.device(self.device):
+                _lib.check(self._lib.cs_set_vehicle_params(self._ctx, None))
+            return None
+        n = self.num_envs
+        if params is None:
+            base = [getattr(self.config, k) for k in self.VEHICLE_ROWS]
+            table = np.repeat(np.asarray(base, dtype=np.float64)[:, None], n, axis=1)
+            for k, v in columns.items():
+                if k not in self.VEHICLE_ROWS:
+                    raise TypeError("unknown vehicle parameter %r (have %s)" % (k, self.VEHICLE_ROWS))
+                table[self.VEHICLE_ROWS.index(k)] = np.asarray(v, dtype=np.float64)
+        else:
+            table = np.asarray(params, dtype=np.float64).reshape(len(self.VEHICLE_ROWS), n)
+        table = np.ascontiguousarray(table)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_set_vehicle_params(self._ctx, table.ctypes.data_as(C.c_void_p)))
+        return table
+
     # -- closed-loop rollouts under the on-device PID landing heuristic ----------------
     def configure_pid(self, **gains):
         """Install the PID landing heuristic (attic/mars/lander3d.py:32-36, :64-87 with the

@@ -202,6 +202,16 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
                    float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
                    void* stream);
 
+/* Per-env vehicles and worlds (domain randomisation).  params_host: [CS_VEHICLE_ROWS, N] float64,
+ * rows B, D, M, L, Ix, Iy, Iz, Jr, maxrpm -- the keys of the `vehicle_params` dict that
+ * task.py:161 hands to Dynamics (dji_phantom.py:9-26; attic/mars/dynamics/ingenuity.py:46-75 for
+ * another set) -- and G, the gravity constant (dynamics/__init__.py:76).  NULL returns to the
+ * uniform values of cs_config.  Jr is accepted for completeness: upstream multiplies it by
+ * Omega = 0 (:135).  Synchronous (first call allocates); call outside stream capture.  Steps then
+ * read 72 more bytes per env. */
+enum { CS_VEHICLE_ROWS = 10 };
+int cs_set_vehicle_params(cs_ctx* ctx, const double* params_host);
+
 /* Physics only: `substeps` x Dynamics.setMotors(motors[i]) on every env, raw motor
  * values (no clipping, no task logic). */
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream);

@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 
 from conftest import load_cases
-from gpu_util import (MODE_TOL, assert_state_close, assert_step_close, have_gpu, make_pair,
-                      scaled_err, step_both, to_np)
+from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu,
+                      make_pair, scaled_err, step_both, to_np)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 
@@ -732,3 +732,96 @@ def test_variant_rollout_pid_is_refused():
     with pytest.raises(Exception, match="3D tasks only"):
         env.rollout_pid(4)
     env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# per-env vehicles / worlds (cs_set_vehicle_params)
+# ---------------------------------------------------------------------------------------
+VEH = load_cases("vehicle_traces.npz")
+
+
+@pytest.mark.parametrize("mode", ["float32", "float64"])
+def test_golden_other_vehicles_as_one_batch(mode):
+    """The reference's Lander flown with other vehicle_params dicts / gravity (heavy, light, Mars):
+    all episodes as ONE device batch, every env with its own parameter column."""
+    import torch
+    for alt in (10.0, 0.05):
+        cs = [c for c in VEH.names() if float(VEH[c]["altitude"]) == alt]
+        n = len(cs)
+        T = max(len(VEH[c]["reward"]) for c in cs)
+        acts = np.zeros((T, n, 4), dtype=np.float32)
+        forces = np.zeros((3, n), dtype=np.float32)
+        for i, c in enumerate(cs):
+            acts[:len(VEH[c]["actions"]), i] = VEH[c]["actions"]
+            forces[:, i] = VEH[c]["force"]
+        env, _ = make_pair("lander3d", n, mode, initial_altitude=alt)
+        env.set_vehicle_params(np.stack([VEH[c]["vehicle"] for c in cs], axis=1))
+        env.reset(options={"forces": forces})
+        tol = 1e-9 if mode == "float64" else BAR
+        for t in range(T):
+            obs, r, term, _, _ = env.step(torch.from_numpy(acts[t]).to(env.device))
+            obs, r, term = to_np(obs), to_np(r), to_np(term)
+            for i, c in enumerate(cs):
+                g = VEH[c]
+                if t >= len(g["reward"]) or t > int(g["first_done"]) + 5:
+                    continue
+                assert scaled_err(obs[i], g["obs"][t]) <= tol, (c, t, scaled_err(obs[i], g["obs"][t]))
+                assert bool(term[i]) == bool(g["done"][t]), (c, t)
+                sh = abs(g["prev_shaping"][t]) if np.isfinite(g["prev_shaping"][t]) else 0.0
+                r_tol = 5e-5 + 1e-5 * abs(g["reward"][t]) + (0 if mode == "float64" else 6e-7 * sh)
+                assert abs(float(r[i]) - g["reward"][t]) <= r_tol, (c, t)
+        env.close()
+
+
+@pytest.mark.parametrize("task,mode,autoreset", [("lander3d", "float32", "next_step"),
+                                                 ("hover3d", "float64", "same_step"),
+                                                 ("lander2d", "float32_rn", "disabled")])
+def test_randomised_vehicles_match_oracle(task, mode, autoreset):
+    """Domain randomisation: every env of a ragged batch gets its own vehicle (+-30 % around the DJI
+    Phantom) and gravity (Mars .. 1.2 g); single steps, cs_step_many and cs_set_motors against the
+    oracle run with the same per-env parameter arrays."""
+    import torch
+    from oracle.refcpu import DJI_PHANTOM, VehicleParams
+    rng = np.random.default_rng(31)
+    n, K = 2777, 25
+    base = np.array([getattr(DJI_PHANTOM, k) for k in ("B", "D", "M", "L", "Ix", "Iy", "Iz", "Jr", "maxrpm")] + [9.80665])
+    table = base[:, None] * rng.uniform(0.7, 1.3, (10, n))
+    table[9] = rng.uniform(3.7, 11.8, n)
+    env, _ = make_pair(task, n, mode, autoreset=autoreset, seed=13, episode_stats=True)
+    many, _ = make_pair(task, n, mode, autoreset=autoreset, seed=13, episode_stats=True)
+    orc = VecOracle(task, n, substeps=1, store_mode=mode, autoreset=AUTORESET[autoreset], seed=13,
+                    vp=VehicleParams(*[table[j].copy() for j in range(9)]), g=table[9].copy())
+    for e in (env, many):
+        e.set_vehicle_params(table)
+    assert np.array_equal(to_np(env.reset()[0]), orc.reset())
+    many.reset()
+    A = env.action_dim
+    hover = np.sqrt(table[2] * table[9] / (4 * table[0])) / (table[8] * np.pi / 30)      # per-env hover motor value
+    tol = max(MODE_TOL[mode], 2e-6)
+    for chunk in range(3):
+        law = rng.uniform(-1, 1, (K, n, A)) if chunk == 0 else hover[None, :, None] * (1 + 0.05 * rng.standard_normal((K, n, A)))
+        acts = law.astype(np.float32)
+        obs_m, rew_m, term_m, trunc_m = many.step_many(torch.from_numpy(acts).to(many.device))
+        for k in range(K):
+            got, want, _ = step_both(env, orc, acts[k])
+            assert_step_close(got, want, tol, r_abs=2e-3, r_rel=2e-6, ctx=(task, mode, chunk, k))
+            assert np.array_equal(to_np(obs_m[k]), got[0]) and np.array_equal(to_np(rew_m[k]), got[1])
+            assert np.array_equal(to_np(term_m[k]), got[2])
+        assert_state_close(env, orc, tol)
+    # dynamics-only entry point with per-env parameters
+    m = rng.uniform(0, 0.05, (n, 4)).astype(np.float32)
+    env.set_motors(torch.from_numpy(m).to(env.device))
+    orc.set_motors(m.astype(np.float64))
+    assert_state_close(env, orc, tol)
+    # back to the uniform vehicle: same as a fresh env
+    env.set_vehicle_params(None)
+    fresh, _ = make_pair(task, n, mode, autoreset=autoreset, seed=99)
+    f = rng.uniform(-30, 30, (3, n)).astype(np.float32)     # (the Philox draw depends on the episode count)
+    env.reset(options={"forces": f})
+    fresh.reset(options={"forces": f})
+    a = rng.uniform(-1, 1, (n, A)).astype(np.float32)
+    r1 = env.step(torch.from_numpy(a).to(env.device))
+    r2 = fresh.step(torch.from_numpy(a).to(env.device))
+    assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
+    for e in (env, many, fresh):
+        e.close()
