@@ -254,6 +254,16 @@ def main():
         w2, _ = timed(st2, a.steps)
         extra["value_with_allgather"] = total_envs * a.steps / w2
         extra["ms_per_step_with_allgather"] = w2 / a.steps * 1e3
+        # everything a global learner needs (obs, reward, both flags) in ONE all-gather: the kernel
+        # writes its outputs straight into the packed per-rank buffer
+        from gym_copter_amd.sharded import PackedOutputs
+        pk = PackedOutputs(n, env.obs_dim, world, device)
+        env.bind_outputs(pk.obs, pk.reward, pk.term, pk.trunc)
+        st3 = Stepper(torch, env, actions, False, chunk, post=pk.all_gather)
+        st3.run(min(a.warmup, 50))
+        w3, _ = timed(st3, a.steps)
+        extra["value_with_packed_allgather"] = total_envs * a.steps / w3
+        extra["ms_per_step_with_packed_allgather"] = w3 / a.steps * 1e3
 
     if a.many > 0:
         # K steps per launch (env state stays in registers): same envs, same resident action ring

@@ -127,6 +127,19 @@ class CopterVecEnv:
             self._final_obs = None
             self._done = None
 
+    def bind_outputs(self, obs, reward, terminated, truncated):
+        """Make step()/reset() write into caller-provided device tensors (same shapes and dtypes
+        as the defaults; truncated/terminated as uint8) -- e.g. slices of one packed buffer that a
+        single collective then ships (gym_copter_amd.sharded)."""
+        torch = _torch()
+        n = self.num_envs
+        want = ((obs, (n, self.obs_dim), torch.float32), (reward, (n,), torch.float32),
+                (terminated, (n,), torch.uint8), (truncated, (n,), torch.uint8))
+        for t, shape, dt in want:
+            if tuple(t.shape) != shape or t.dtype != dt or t.device != self.device or not t.is_contiguous():
+                raise ValueError("bind_outputs: need contiguous %s %s on %s" % (dt, shape, self.device))
+        self._obs, self._reward, self._term, self._trunc = obs, reward, terminated, truncated
+
     # -- plumbing ------------------------------------------------------------------
     @property
     def unwrapped(self):

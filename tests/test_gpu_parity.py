@@ -825,3 +825,31 @@ def test_randomised_vehicles_match_oracle(task, mode, autoreset):
     assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])
     for e in (env, many, fresh):
         e.close()
+
+
+# ---------------------------------------------------------------------------------------
+# sharded env on one GPU (world size 1): the packed-output path the multi-GPU gather uses
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gather", ["none", "obs", "all"])
+def test_sharded_env_single_rank_matches_plain_env(gather):
+    """ShardedCopterVecEnv without a process group (world 1).  With gather='all' the step kernel
+    writes observations, rewards and flags straight into one packed buffer (what a multi-GPU run
+    ships with ONE all-gather): results must equal the plain env's, bit for bit."""
+    import torch
+    from gym_copter_amd.sharded import ShardedCopterVecEnv
+    rng = np.random.default_rng(41)
+    n = 4097
+    sh = ShardedCopterVecEnv("lander3d", n, gather=gather, device=0, seed=6, autoreset_mode="next_step")
+    plain, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=6)
+    if gather == "all":
+        assert sh.local._obs.data_ptr() == sh._packed.obs.data_ptr()       # zero-copy binding
+    o1, _ = sh.reset()
+    o2, _ = plain.reset()
+    assert torch.equal(o1, o2)
+    for t in range(30):
+        a = torch.from_numpy(rng.uniform(-1, 1, (n, 4)).astype(np.float32)).to(plain.device)
+        r1, r2 = sh.step(a), plain.step(a)
+        for u, v in zip(r1[:4], r2[:4]):
+            assert u.shape == v.shape and u.dtype == v.dtype and torch.equal(u, v), t
+    sh.close()
+    plain.close()
