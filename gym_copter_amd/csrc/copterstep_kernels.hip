@@ -786,6 +786,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
   CS_STAMP(7);
 }
 
+// Pin a uniform value into vector registers (opaque to the optimiser).
+__device__ __forceinline__ double in_vgpr(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // ---------------------------------------------------------------------------------
 // On-device PID landing heuristic (the retired upstream controllers,
 // attic/mars/pidcontrollers/__init__.py:12-146, wired as attic/mars/lander3d.py:64-87).
@@ -867,9 +873,39 @@ template <int TASK, int MODE, bool LEAN, bool POLICY>
 __global__ __launch_bounds__(kBlock) void step_many_kernel(
     char* const tiles, const uint32_t n_envs, float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
-    const int num_steps, const DevConst c, const DevState s_rest, const PidConst pc,
+    const int num_steps, const DevConst c_arg, const DevState s_rest, const PidConst pc_arg,
     double* const pid_state, const uint32_t pid_stride) {
   using T = typename ModeOf<MODE>::T;
+  // The loop body needs more uniform values than there are scalar registers (the kernel
+  // argument block alone is > 100 dwords); what the compiler cannot keep it parks in VGPR lanes
+  // and fetches back with v_readlane in every iteration.  Vector registers are plentiful at
+  // this occupancy, so the constants used deep inside the step (sin/cos coefficients,
+  // controller gains, reward constants) are made vector-resident up front instead.
+  DevConst c = c_arg;
+  PidConst pc = pc_arg;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) c.trig[j] = in_vgpr(c.trig[j]);
+  c.xyz_pen = in_vgpr(c.xyz_pen);
+  c.yaw_pen = in_vgpr(c.yaw_pen);
+  c.dz_max = in_vgpr(c.dz_max);
+  c.dz_pen = in_vgpr(c.dz_pen);
+  c.target_r2 = in_vgpr(c.target_r2);
+  c.bonus = in_vgpr(c.bonus);
+  c.oob_penalty = in_vgpr(c.oob_penalty);
+  if constexpr (POLICY) {
+    pc.rate_kp = in_vgpr(pc.rate_kp);
+    pc.rate_ki = in_vgpr(pc.rate_ki);
+    pc.rate_kd = in_vgpr(pc.rate_kd);
+    pc.rate_windup = in_vgpr(pc.rate_windup);
+    pc.rate_big = in_vgpr(pc.rate_big);
+    pc.pos_kp = in_vgpr(pc.pos_kp);
+    pc.pos_ki = in_vgpr(pc.pos_ki);
+    pc.pos_kd = in_vgpr(pc.pos_kd);
+    pc.pos_target = in_vgpr(pc.pos_target);
+    pc.pos_windup = in_vgpr(pc.pos_windup);
+    pc.descent_kp = in_vgpr(pc.descent_kp);
+    pc.descent_kd = in_vgpr(pc.descent_kd);
+  }
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
