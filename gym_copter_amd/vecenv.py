@@ -440,6 +440,19 @@ class CopterVecEnv:
         _lib.check(self._lib.cs_set_state(self._ctx, *ptrs, self._stream()))
 
 
+    def set_perturbation(self, force_xyz):
+        """Dynamics.perturb() (dynamics/__init__.py:227-229) for the batch: install a pending
+        force [3,N] in newtons that the next integrating physics call consumes (applied twice in
+        that call, as upstream does)."""
+        st = self.get_state()
+        if hasattr(force_xyz, "detach"):
+            force_xyz = force_xyz.detach().cpu().numpy()
+        f = np.asarray(force_xyz, dtype=np.float64).reshape(3, self.num_envs)
+        self.set_state(force=f, flags=st["flags"] | np.uint8(1))
+
+    perturb = set_perturbation
+
+
 def _to_numpy(v):
     if isinstance(v, dict):
         return {k: _to_numpy(x) for k, x in v.items()}

@@ -853,3 +853,29 @@ def test_sharded_env_single_rank_matches_plain_env(gather):
             assert u.shape == v.shape and u.dtype == v.dtype and torch.equal(u, v), t
     sh.close()
     plain.close()
+
+
+def test_set_perturbation_mid_flight():
+    """Dynamics.perturb() for the batch: a force installed between steps enters the next
+    integrating call (twice, as upstream applies it) and is then gone."""
+    rng = np.random.default_rng(5)
+    n = 777
+    env, orc = make_pair("lander3d", n, "float32", seed=2)
+    env.reset()
+    orc.reset()
+    a = (HOVER * (1 + 0.01 * rng.standard_normal((n, 4)))).astype(np.float32)
+    for t in range(3):
+        got, want, _ = step_both(env, orc, a)
+    f = rng.uniform(-50, 50, (3, n)).astype(np.float32).astype(np.float64)
+    env.set_perturbation(f)
+    orc.force[:] = f.astype(orc.T)
+    orc.pending[:] = True
+    dx_before = env.get_state()["x"][1].copy()
+    got, want, _ = step_both(env, orc, a)
+    assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6)
+    kick = env.get_state()["x"][1] - dx_before
+    assert np.allclose(kick, 2 * f[0] / 1.380 * 0.01, rtol=0, atol=2e-3)     # 2 F/M dt on top of the thrust term
+    got, want, _ = step_both(env, orc, a)
+    assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6)
+    assert_state_close(env, orc, 2e-6)
+    env.close()
