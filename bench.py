@@ -152,6 +152,9 @@ def cpu_baseline(task, law, seconds):
     from oracle.refvec import VecOracle
     rng = np.random.default_rng(0)
     steps, dt = _scalar_port((task, law, seconds, 0))
+    # the 1-core row for both action laws of the headline workloads
+    other = "const" if law != "const" else "uniform"
+    o_steps, o_dt = _scalar_port((task, other, max(2.0, seconds / 4), 1))
     procs = os.cpu_count() or 1
     all_cores = None
     if procs > 1:
@@ -179,6 +182,8 @@ def cpu_baseline(task, law, seconds):
             "sample": "oracle/refcpu.py TaskOracle (scalar NumPy, reference call structure), %s, "
                       "'%s' actions, %d steps in %.1f s on 1 of %d host cores"
                       % (task, law, steps, dt, os.cpu_count()),
+            "one_core_other_law": {"actions": other, "value": o_steps / o_dt, "unit": "env-steps/s",
+                                   "sample": "%d steps in %.1f s" % (o_steps, o_dt)},
             "all_cores": all_cores, "cpu_model": _cpu_model(),
             "vectorised_numpy": {"value": vec, "unit": "env-steps/s", "cores": 1,
                                  "sample": "oracle/refvec.py VecOracle, %d envs x %d steps" % (nv, k)}}
@@ -315,6 +320,28 @@ def main():
             "note": "cs_rollout_pid: closed loop, upstream's PID landing heuristic evaluated on device "
                     "(tests/test_gpu_parity.py::test_rollout_pid_policy_is_bit_exact); episodes under "
                     "upstream's gains end by tilt after ~130 steps and auto-reset"}
+
+    if a.pid > 0:
+        # random policy on device: the headline's action law with no action tensor, K steps per launch
+        k = a.pid
+        reps = max(1, a.steps // k)
+        env.reset()
+
+        class RollR:
+            def run(self, count):
+                for _ in range(count // k):
+                    env.rollout_random(k)
+        m = RollR()
+        m.run(2 * k)
+        wm, evm = timed(m, reps * k)
+        per_step = evm / (reps * k)
+        bytes_step = 4 * env.obs_dim + 4 + 2 + 200.0 / k
+        extra["rollout_random"] = {
+            "steps_per_launch": k, "value": total_envs * reps * k / wm, "unit": "env-steps/s",
+            "us_per_step": per_step * 1e6, "algorithmic_bytes_per_env_step": bytes_step,
+            "achieved_GBps": bytes_step * n / per_step / 1e9,
+            "note": "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
+                    "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)"}
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -87,6 +87,7 @@ SYMBOLS = {
     "cs_pid_get_state": (C.c_int, [_P, _P, _P]),
     "cs_pid_set_state": (C.c_int, [_P, _P, _P]),
     "cs_rollout_pid": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "cs_rollout_random": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_get_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
     "cs_set_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
 }

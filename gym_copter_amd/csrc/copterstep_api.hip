@@ -318,8 +318,8 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
   const cs::DevConst c = make_const(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       const_cast<float*>(actions_dev), obs_dev, reward_dev,
-                                      terminated_dev, truncated_dev, nullptr, nullptr, 0,
-                                      (hipStream_t)stream);
+                                      terminated_dev, truncated_dev, cs::CS_POLICY_NONE, nullptr,
+                                      nullptr, 0, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_step_many: kernel launch");
   return CS_OK;
 }
@@ -452,9 +452,23 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
   const cs::DevConst c = make_const(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,
-                                      truncated_dev, &ctx->pid, ctx->pid_state, ctx->pid_stride,
-                                      (hipStream_t)stream);
+                                      truncated_dev, cs::CS_POLICY_PID, &ctx->pid, ctx->pid_state,
+                                      ctx->pid_stride, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_rollout_pid: kernel launch");
+  return CS_OK;
+}
+
+int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
+                      float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
+                      void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_random: num_steps must be >= 1");
+  const cs::DevConst c = make_const(ctx);
+  hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
+                                      actions_out_dev, obs_dev, reward_dev, terminated_dev,
+                                      truncated_dev, cs::CS_POLICY_RANDOM, nullptr, nullptr, 0,
+                                      (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_rollout_random: kernel launch");
   return CS_OK;
 }
 

@@ -152,11 +152,13 @@ struct DevState {
 
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                        const cs_step_io& io, hipStream_t stream);
-// pid == nullptr: open loop, `actions` is the [K,N,4] input.  Otherwise closed loop under the
-// on-device PID heuristic: `actions` is an optional [K,N,4] output, `pid_state` is required.
+// policy 0: open loop, `actions` is the [K,N,A] input.  1: closed loop under the on-device PID
+// heuristic (`pid`, `pid_state` required).  2: on-device U[-1,1) random policy.  For 1 and 2
+// `actions` is an optional [K,N,A] output.
+enum { CS_POLICY_NONE = 0, CS_POLICY_PID = 1, CS_POLICY_RANDOM = 2 };
 hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
                             float* actions, float* obs, float* reward, uint8_t* term,
-                            uint8_t* trunc, const PidConst* pid, double* pid_state,
+                            uint8_t* trunc, int policy, const PidConst* pid, double* pid_state,
                             uint32_t pid_stride, hipStream_t stream);
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,
                              hipStream_t stream);

@@ -211,6 +211,19 @@ __device__ __forceinline__ void draw_force(const DevConst& c, uint32_t i, uint32
   }
 }
 
+// On-device random policy: action ~ U[-1, 1)^4 on a 2^-15 grid (exact in float32), keyed by
+// (seed, global env id, episode number, step counter of the episode) -- again a pure function
+// of the env's own stored state, so it does not depend on batch size, sharding or how the steps
+// are grouped into launches.  counter = (global env id, episode), key = (seed_lo ^ seed_hi ^
+// 0x5DEECE66) + steps; the 64 output bits give four 16-bit uniforms.
+__device__ __forceinline__ float4 draw_action(const DevConst& c, uint32_t i, uint32_t episode,
+                                              uint32_t steps) {
+  uint32_t r0, r1;
+  philox2x32_10(c.id_lo + i, episode, (c.seed_lo ^ c.seed_hi ^ 0x5DEECE66u) + steps, r0, r1);
+  auto u = [](uint32_t bits) { return (float)bits * 0x1.0p-15f - 1.0f; };  // exact
+  return make_float4(u(r0 >> 16), u(r0 & 0xFFFFu), u(r1 >> 16), u(r1 & 0xFFFFu));
+}
+
 // ---------------------------------------------------------------------------------
 // stored-word codec.  encode(): float64 register -> stored word (+ guard byte), and
 // the float64 value the stored representation decodes to (what the next step and
@@ -869,7 +882,9 @@ __device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[4]
 // applied to the previous observation row (`actions_dev` is then an optional OUTPUT [K,N,4]);
 // the controller state lives in `pid_state` ([16][pid_stride] float64) between launches and is
 // zeroed whenever its env starts a new episode.
-template <int TASK, int MODE, bool LEAN, bool POLICY>
+enum { kPolicyNone = 0, kPolicyPid = 1, kPolicyRandom = 2 };
+
+template <int TASK, int MODE, bool LEAN, int POLICY>
 __global__ __launch_bounds__(kBlock) void step_many_kernel(
     char* const tiles, const uint32_t n_envs, float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
@@ -892,7 +907,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   c.target_r2 = in_vgpr(c.target_r2);
   c.bonus = in_vgpr(c.bonus);
   c.oob_penalty = in_vgpr(c.oob_penalty);
-  if constexpr (POLICY) {
+  if constexpr (POLICY == kPolicyPid) {
     pc.rate_kp = in_vgpr(pc.rate_kp);
     pc.rate_ki = in_vgpr(pc.rate_ki);
     pc.rate_kd = in_vgpr(pc.rate_kd);
@@ -963,7 +978,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   float4 act = make_float4(0.f, 0.f, 0.f, 0.f);
   PidCtl ctl[4];
   float seen[OBS];  // the observation the policy acts on: what the previous step returned
-  if constexpr (POLICY) {
+  if constexpr (POLICY == kPolicyPid) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       ctl[j].err_i = pid_state[(size_t)(4 * j + 0) * pid_stride + i];
@@ -973,24 +988,38 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     }
 #pragma unroll
     for (int j = 0; j < OBS; ++j) seen[j] = (float)e.x[j];
-  } else {
+  } else if constexpr (POLICY == kPolicyNone) {
     act = load_action<TASK>(actions_dev, ia);
   }
   for (int k = 0; k < num_steps; ++k) {
     // rows of step k (64-bit uniform offsets: K * N can exceed 32 bits)
     const size_t row = (size_t)k * n;
     float4 act_next = act;
-    if constexpr (POLICY) {
-      static_assert(!POLICY || OBS >= 10, "the PID heuristic reads the 3D observation");
+    if constexpr (POLICY == kPolicyPid) {
+      static_assert(OBS >= 10, "the PID heuristic reads the 3D observation");
       act = pid_policy<OBS>(pc, ctl, seen);
       if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
+    } else if constexpr (POLICY == kPolicyRandom) {
+      const float4 a = draw_action(c, i, TileIO<MODE>::episode_of(e.fe), (uint32_t)e.steps);
+      // the task's own action row (1, 2 or 4 values), then its motor fan-out
+      if constexpr (ACT == 4) {
+        act = a;
+        if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = a;
+      } else if constexpr (ACT == 2) {
+        act = make_float4(a.x, a.y, a.y, a.x);
+        if (actions_dev != nullptr && valid)
+          *at32<float2>(actions_dev + row * 2, ia << 3) = make_float2(a.x, a.y);
+      } else {
+        act = make_float4(a.x, a.x, a.x, a.x);
+        if (actions_dev != nullptr && valid) *at32<float>(actions_dev + row, ia << 2) = a.x;
+      }
     } else {
       const int kn = (k + 1 < num_steps) ? k + 1 : k;
       act_next = load_action<TASK>(actions_dev + (size_t)kn * n * ACT, ia);  // prefetch
     }
     StepOut<OBS> out;
     advance<TASK, MODE, OBS, false>(c, q, o, e, act, io, i, lane, valid, tile, out);
-    if constexpr (POLICY) {
+    if constexpr (POLICY == kPolicyPid) {
 #pragma unroll
       for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
       if (out.did_reset) {
@@ -1011,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
   if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (opt_stats) tile.store_ret(e.ep_ret);
-  if constexpr (POLICY) {
+  if constexpr (POLICY == kPolicyPid) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       pid_state[(size_t)(4 * j + 0) * pid_stride + i] = ctl[j].err_i;
@@ -1159,7 +1188,7 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, hi
 template <int TASK, int MODE>
 hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, float* actions,
                        float* obs, float* reward, uint8_t* term, uint8_t* trunc,
-                       const PidConst* pid, double* pid_state, uint32_t pid_stride,
+                       int policy, const PidConst* pid, double* pid_state, uint32_t pid_stride,
                        hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
   const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc && s.veh == nullptr;
@@ -1168,19 +1197,25 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
   hipLaunchKernelGGL((step_many_kernel<TASK, MODE, LEAN, POLICY>), grid, block, 0, stream,      \
                      s.tiles, s.n, actions, obs, reward, term, trunc, num_steps, c, s, pc,      \
                      pid_state, pid_stride)
-  if (pid != nullptr) {
+  if (policy == kPolicyPid) {
     if constexpr (task_act_dim(TASK) == 4) {  // the heuristic reads the 3D observation
+      if (pid == nullptr || pid_state == nullptr) return hipErrorInvalidValue;
       if (lean)
-        CS_MANY(true, true);
+        CS_MANY(true, kPolicyPid);
       else
-        CS_MANY(false, true);
+        CS_MANY(false, kPolicyPid);
     } else {
       return hipErrorInvalidValue;
     }
+  } else if (policy == kPolicyRandom) {
+    if (lean)
+      CS_MANY(true, kPolicyRandom);
+    else
+      CS_MANY(false, kPolicyRandom);
   } else if (lean) {
-    CS_MANY(true, false);
+    CS_MANY(true, kPolicyNone);
   } else {
-    CS_MANY(false, false);
+    CS_MANY(false, kPolicyNone);
   }
 #undef CS_MANY
   return hipGetLastError();
@@ -1204,10 +1239,10 @@ hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
 
 hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
                             float* actions, float* obs, float* reward, uint8_t* term,
-                            uint8_t* trunc, const PidConst* pid, double* pid_state,
+                            uint8_t* trunc, int policy, const PidConst* pid, double* pid_state,
                             uint32_t pid_stride, hipStream_t stream) {
-  CS_DISPATCH(step_many_t, c, s, num_steps, actions, obs, reward, term, trunc, pid, pid_state,
-              pid_stride, stream)
+  CS_DISPATCH(step_many_t, c, s, num_steps, actions, obs, reward, term, trunc, policy, pid,
+              pid_state, pid_stride, stream)
 }
 
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,

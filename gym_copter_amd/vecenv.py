@@ -322,14 +322,23 @@ class CopterVecEnv:
         self._pid = True
         return {k: getattr(g, k) for k, _ in g._fields_[2:]}
 
+    def rollout_random(self, num_steps, return_actions=False):
+        """K steps in ONE kernel launch under the on-device random policy (actions ~ U[-1,1)
+        drawn in the kernel from Philox keyed by seed, global env id, episode and step): the
+        `action_space.sample()` loop with no action tensor.  Returns like rollout_pid."""
+        return self._rollout(self._lib.cs_rollout_random, num_steps, return_actions)
+
     def rollout_pid(self, num_steps, return_actions=False):
         """K closed-loop steps in ONE kernel launch: every step's action is the PID heuristic of
         the observation the previous step returned.  -> (obs [K,N,obs_dim], reward [K,N],
         terminated [K,N], truncated [K,N]) and, with return_actions, the float32 actions [K,N,4]
         appended."""
-        self._check_open()
         if not getattr(self, "_pid", False):
             self.configure_pid()
+        return self._rollout(self._lib.cs_rollout_pid, num_steps, return_actions)
+
+    def _rollout(self, entry, num_steps, return_actions):
+        self._check_open()
         torch = _torch()
         K, n = int(num_steps), self.num_envs
         buf = getattr(self, "_roll", None)
@@ -338,12 +347,12 @@ class CopterVecEnv:
                    torch.empty((K, n), dtype=torch.float32, device=self.device),
                    torch.empty((K, n), dtype=torch.uint8, device=self.device),
                    torch.empty((K, n), dtype=torch.uint8, device=self.device),
-                   torch.empty((K, n, 4), dtype=torch.float32, device=self.device))
+                   torch.empty((K, n, self.action_dim), dtype=torch.float32, device=self.device))
             self._roll = buf
         p = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.cs_rollout_pid(self._ctx, K, p(buf[4]) if return_actions else None,
-                                                p(buf[0]), p(buf[1]), p(buf[2]), p(buf[3]), self._stream()))
+            _lib.check(entry(self._ctx, K, p(buf[4]) if return_actions else None,
+                             p(buf[0]), p(buf[1]), p(buf[2]), p(buf[3]), self._stream()))
         out = (buf[0], buf[1], buf[2].view(torch.bool), buf[3].view(torch.bool))
         return out + (buf[4],) if return_actions else out
 

@@ -202,6 +202,16 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
                    float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
                    void* stream);
 
+/* K steps in ONE launch under an on-device random policy -- the "random actions" workload
+ * (lander.py --random / `env.action_space.sample()` loops) with no action tensor at all:
+ * action ~ U[-1,1)^A on a 2^-15 grid from Philox2x32-10 with counter = (global env id, episode
+ * number), key = (lo32(seed) ^ hi32(seed) ^ 0x5DEECE66) + step counter of the episode; four
+ * 16-bit uniforms per draw, the task's A of them used.  Outputs as cs_rollout_pid
+ * (actions_out_dev [K,N,A], nullable). */
+int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
+                      float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
+                      void* stream);
+
 /* Per-env vehicles and worlds (domain randomisation).  params_host: [CS_VEHICLE_ROWS, N] float64,
  * rows B, D, M, L, Ix, Iy, Iz, Jr, maxrpm -- the keys of the `vehicle_params` dict that
  * task.py:161 hands to Dynamics (dji_phantom.py:9-26; attic/mars/dynamics/ingenuity.py:46-75 for

@@ -76,6 +76,24 @@ def draw_forces(seed, env_ids, episode, magnitude):
     return out
 
 
+def draw_actions(seed, env_ids, episode, steps, act_dim=4):
+    """On-device random policy, shared (by specification) with the K-step kernel:
+    counter = (global env id, episode number), key = (lo32(seed) ^ hi32(seed) ^ 0x5DEECE66) +
+    step counter of the episode; the 64 output bits give four 16-bit uniforms
+    a = bits * 2^-15 - 1 in [-1, 1), exact in float32; the first `act_dim` are the action.
+    Returns [n, act_dim] float32."""
+    env_ids = np.asarray(env_ids, dtype=np.uint64)
+    episode = np.broadcast_to(np.asarray(episode, dtype=np.uint32), env_ids.shape)
+    steps = np.broadcast_to(np.asarray(steps).astype(np.uint32), env_ids.shape)
+    seed = int(seed) & ((1 << 64) - 1)
+    with np.errstate(over="ignore"):
+        key = (np.uint32(((seed & 0xFFFFFFFF) ^ (seed >> 32) ^ 0x5DEECE66) & 0xFFFFFFFF) + steps).astype(np.uint32)
+    r0, r1 = philox2x32_10(env_ids.astype(np.uint32), episode, key)
+    bits = np.stack([r0 >> np.uint32(16), r0 & np.uint32(0xFFFF), r1 >> np.uint32(16), r1 & np.uint32(0xFFFF)], axis=1)
+    a = bits.astype(np.float32) * np.float32(2.0 ** -15) - np.float32(1.0)
+    return np.ascontiguousarray(a[:, :act_dim])
+
+
 # ---------------------------------------------------------------------------
 # Stored-word rounding shared (by specification) with the device kernels.
 # ---------------------------------------------------------------------------

@@ -12,6 +12,8 @@ for law in uniform near_hover; do
     run --task lander3d --envs $n --actions $law --steps $k --warmup 100 --ring 8
   done
 done
+run --task lander3d --envs 65536 --actions const --steps 2000 --warmup 100                    # constant thrust (lander.py:21)
+run --task lander3d --envs 262144 --actions const --steps 2000 --warmup 100
 run --task hover3d --envs 262144 --actions uniform --steps 1000 --warmup 100 --ring 8        # BASELINE config 3
 run --task hover3d --envs 262144 --actions near_hover --steps 1000 --warmup 100 --ring 8
 run --task lander3d --envs 65536 --actions near_hover --substeps 10 --steps 1000 --warmup 100   # BASELINE config 5

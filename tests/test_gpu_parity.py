@@ -879,3 +879,50 @@ def test_set_perturbation_mid_flight():
     assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6)
     assert_state_close(env, orc, 2e-6)
     env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# rollouts under the on-device random policy (cs_rollout_random)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task,mode,autoreset", [("lander3d", "float32", "next_step"),
+                                                 ("hover3d", "float64", "same_step"),
+                                                 ("lander2d", "float32_rn", "next_step"),
+                                                 ("hover1d", "float32", "disabled")])
+def test_rollout_random_is_bit_exact(task, mode, autoreset):
+    """The kernel's action draw against the oracle's draw_actions (same specification), bit for
+    bit, and the rollout against a twin device env stepped one cs_step at a time with those
+    actions; then the whole thing against the CPU oracle.  Launch grouping must not matter: the
+    same steps as 3 launches of 20 and as 60 launches of 1 give identical results."""
+    import torch
+    from oracle.refvec import draw_actions
+    n, K = 2111, 20
+    roll, orc = make_pair(task, n, mode, autoreset=autoreset, seed=77, env_id_base=5000, episode_stats=True)
+    twin, _ = make_pair(task, n, mode, autoreset=autoreset, seed=77, env_id_base=5000, episode_stats=True)
+    ones, _ = make_pair(task, n, mode, autoreset=autoreset, seed=77, env_id_base=5000, episode_stats=True)
+    for e in (roll, twin, ones):
+        e.reset()
+    orc.reset()
+    ids = np.arange(5000, 5000 + n)
+    tol = max(MODE_TOL[mode], 2e-6)
+    for chunk in range(3):
+        obs_k, rew_k, term_k, trunc_k, act_k = roll.rollout_random(K, return_actions=True)
+        for k in range(K):
+            st = twin.get_state()
+            a = draw_actions(77, ids, st["episode"], st["steps"], twin.action_dim)
+            assert np.array_equal(a, to_np(act_k[k])), (chunk, k)
+            assert np.array_equal(a, draw_actions(77, ids, orc.episode, orc.steps, orc.act_dim)), (chunk, k)
+            o, r, t, tr, _ = twin.step(torch.from_numpy(a).to(twin.device))
+            assert torch.equal(obs_k[k], o) and torch.equal(rew_k[k], r), (chunk, k)
+            assert torch.equal(term_k[k], t) and torch.equal(trunc_k[k], tr), (chunk, k)
+            want = orc.step(a.astype(np.float64))
+            assert_step_close((to_np(o), to_np(r), to_np(t), to_np(tr)), want, tol, r_abs=2e-3, r_rel=2e-6,
+                              ctx=(task, mode, chunk, k))
+            o1 = ones.rollout_random(1)
+            assert torch.equal(o1[0][0], o) and torch.equal(o1[1][0], r), (chunk, k)
+        sr, st, so = roll.get_state(), twin.get_state(), ones.get_state()
+        for key in sr:
+            assert np.array_equal(sr[key], st[key], equal_nan=True), (chunk, key)
+            assert np.array_equal(sr[key], so[key], equal_nan=True), (chunk, key)
+        assert_state_close(roll, orc, tol)
+    for e in (roll, twin, ones):
+        e.close()

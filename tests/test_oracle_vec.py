@@ -263,3 +263,24 @@ def test_vec_per_env_vehicles_bit_exact_in_batch():
                 if t < len(g["reward"]):
                     assert np.array_equal(obs[i], g["obs"][t]) and r[i] == g["reward"][t], (c, t)
                     assert term[i] == g["done"][t] and np.array_equal(o.x[:, i], g["x"][t]), (c, t)
+
+
+KNOWN_ACTION = [-0.31329345703125, 0.641265869140625, 0.04437255859375, 0.8636474609375]
+
+
+def test_draw_actions_spec():
+    """The on-device random policy's draw: on the 2^-15 grid in [-1, 1), a pure function of (seed,
+    env id, episode, step), distinct from the reset-force stream, roughly uniform."""
+    from oracle.refvec import draw_actions
+    ids = np.arange(1000, 1000 + 4096, dtype=np.uint64)
+    a = draw_actions(7, ids, 3, 11)
+    assert a.shape == (4096, 4) and a.dtype == np.float32
+    assert a.min() >= -1 and a.max() < 1 and np.array_equal(a * 32768, np.round(a * 32768))
+    assert np.array_equal(a[100:200], draw_actions(7, ids[100:200], 3, 11))           # position invariant
+    assert not np.array_equal(a, draw_actions(7, ids, 3, 12)) and not np.array_equal(a, draw_actions(7, ids, 4, 11))
+    assert not np.array_equal(a, draw_actions(8, ids, 3, 11))
+    assert np.array_equal(draw_actions(7, ids, 3, 11, act_dim=2), a[:, :2])
+    assert abs(a.mean()) < 0.02 and abs(a.std() - 1 / np.sqrt(3)) < 0.01
+    # known answer (first env, seed 1234, episode 1, step 1), pinned when the spec was written
+    k = draw_actions(1234, [0], 1, 1)[0]
+    assert np.array_equal(k, np.float32(KNOWN_ACTION)), k.tolist()
