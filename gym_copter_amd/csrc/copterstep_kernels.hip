@@ -64,6 +64,27 @@ __device__ __forceinline__ U* at32(P* base, uint32_t byte_off) {
   return reinterpret_cast<U*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(base)) + byte_off);
 }
 
+// Streaming accesses (non-temporal hint).  The per-step outputs (observation rows, reward,
+// flags) pass through once: stored as streams they do not displace the env state, which the
+// same XCD re-reads every step (workgroup -> XCD assignment is the same in every launch), from
+// that XCD's L2 -- measured -5 % time from 131 072 to 1 M envs.  Action rows are loaded as
+// streams only for batches whose state fits the L2s (kNtActionMaxEnvs): there it keeps a long
+// ring of action tensors from evicting the state (-5 % at 65 536 envs with a 64-deep ring); for
+// larger batches a non-temporal load is slower than a plain one (+2..7 %).  tools/ab.sh.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define CS_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+constexpr uint32_t kNtActionMaxEnvs = 98304;
+
+template <bool STREAM, class V>
+__device__ __forceinline__ V load_maybe_stream(const V* p) {
+  if constexpr (STREAM) {
+    return __builtin_nontemporal_load(p);
+  } else {
+    return *p;
+  }
+}
+
 template <class T>
 struct alignas(4 * sizeof(T)) Vec4 {
   T v[4];
@@ -510,7 +531,11 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
 #pragma unroll
     for (int k = 0; k < (kVec + kWave - 1) / kWave; ++k) {
       const int v = k * kWave + lane;
-      if (v < kVec) *at32<float4>(out, base + (uint32_t)k * 1024u) = src[v];
+      if (v < kVec) {
+        const float4 r = src[v];
+        const f32x4 rv = {r.x, r.y, r.z, r.w};
+        CS_NT_STORE(rv, at32<f32x4>(out, base + (uint32_t)k * 1024u));
+      }
     }
   } else if (valid) {  // ragged last wavefront: plain row stores
     float* dst = out + (size_t)(env0 + lane) * OBS;
@@ -552,16 +577,17 @@ struct StepOpts {  // uniform switches (compiled out in LEAN builds)
 // One action row -> the four motor demands: _get_motors (lander.py:95-97 for the 3D tasks; the
 // fan-outs of attic lander2d.py:48-50 / lander1d.py:46-48 for the variants).  Coalesced
 // 16 / 8 / 4 bytes per lane.
-template <int TASK>
+template <int TASK, bool STREAM = false>
 __device__ __forceinline__ float4 load_action(const float* base, uint32_t env) {
   constexpr int A = task_act_dim(TASK);
   if constexpr (A == 4) {
-    return *at32<const float4>(base, env << 4);
+    const f32x4 a = load_maybe_stream<STREAM>(at32<const f32x4>(base, env << 4));
+    return make_float4(a.x, a.y, a.z, a.w);
   } else if constexpr (A == 2) {
-    const float2 a = *at32<const float2>(base, env << 3);
+    const f32x2 a = load_maybe_stream<STREAM>(at32<const f32x2>(base, env << 3));
     return make_float4(a.x, a.y, a.y, a.x);
   } else {
-    const float a = *at32<const float>(base, env << 2);
+    const float a = load_maybe_stream<STREAM>(at32<const float>(base, env << 2));
     return make_float4(a, a, a, a);
   }
 }
@@ -719,11 +745,13 @@ struct TileIn {
 };
 
 // ---- loads: 4 x 16 B (state, guards + meta) + prev_shaping + the action row ----
-template <int TASK, int MODE>
+template <int TASK, int MODE, bool STREAM_ACT>
 __device__ __forceinline__ void load_tile(const TileIO<MODE>& tile, const float* actions_dev,
-                                          uint32_t i, bool valid, bool opt_stats, TileIn<MODE>& in) {
+                                          uint32_t i, uint32_t n_envs, bool opt_stats,
+                                          TileIn<MODE>& in) {
+  const bool valid = i < n_envs;
   tile.load_state(in.raw, in.g, in.meta);
-  in.act = load_action<TASK>(actions_dev, valid ? i : 0u);
+  in.act = load_action<TASK, STREAM_ACT>(actions_dev, valid ? i : 0u);
   in.prev_sh = 0.0;
   if constexpr (task_is_lander(TASK)) in.prev_sh = (double)tile.load_prev();
   in.ep_ret = 0.f;
@@ -778,9 +806,9 @@ __device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, c
   if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (valid) {
-    if (io.reward_dev) *at32<float>(io.reward_dev, i << 2) = (float)out.reward;
-    if (io.terminated_dev) *at32<uint8_t>(io.terminated_dev, i) = out.term ? 1 : 0;
-    if (io.truncated_dev) *at32<uint8_t>(io.truncated_dev, i) = out.trunc ? 1 : 0;
+    if (io.reward_dev) CS_NT_STORE((float)out.reward, at32<float>(io.reward_dev, i << 2));
+    if (io.terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(io.terminated_dev, i));
+    if (io.truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(io.truncated_dev, i));
   }
   write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, n, valid, out.row);
   CS_STAMP(6);
@@ -788,7 +816,7 @@ __device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, c
 
 // One wavefront = one tile = one workgroup.  (Giving each wavefront two tiles with both tiles'
 // loads issued up front was measured: +22 % time at 262 144 envs, neutral from 524 288 envs up.)
-template <int TASK, int MODE, bool LEAN>
+template <int TASK, int MODE, bool LEAN, bool STREAM_ACT>
 __global__ __launch_bounds__(kBlock) void step_kernel(
     // leading scalar arguments: preloaded into SGPRs with the wave (kernarg preload), so the
     // first loads do not wait for an s_load of the argument block
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
   const TileIO<MODE> tile(s, i);
   CS_STAMP(0);
   TileIn<MODE> in;
-  load_tile<TASK, MODE>(tile, io.actions_dev, i, i < s.n, o.stats, in);
+  load_tile<TASK, MODE, STREAM_ACT>(tile, io.actions_dev, i, s.n, o.stats, in);
   run_tile<TASK, MODE, LEAN>(c, s, io, o, in, i, lane, tile, lds_wave);
 #ifdef CS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1055,9 +1083,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       }
     }
     if (valid) {
-      if (reward_dev) *at32<float>(reward_dev + row, i << 2) = (float)out.reward;
-      if (terminated_dev) *at32<uint8_t>(terminated_dev + row, i) = out.term ? 1 : 0;
-      if (truncated_dev) *at32<uint8_t>(truncated_dev + row, i) = out.trunc ? 1 : 0;
+      if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
+      if (terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(terminated_dev + row, i));
+      if (truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(truncated_dev + row, i));
     }
     write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds_wave, lane, env0, n, valid, out.row);
     act = act_next;
@@ -1201,14 +1229,17 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, hi
   const dim3 grid(grid_for(s.n)), block(kBlock);
   const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc &&
                     io.done_count_dev == nullptr && io.final_obs_dev == nullptr && s.veh == nullptr;
-  if (lean)
-    hipLaunchKernelGGL((step_kernel<TASK, MODE, true>), grid, block, 0, stream, s.tiles, s.n,
-                       io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,
-                       io.truncated_dev, c, s, io);
+#define CS_STEP(LEAN, STREAM_ACT)                                                                \
+  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT>), grid, block, 0, stream, s.tiles, \
+                     s.n, io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,           \
+                     io.truncated_dev, c, s, io)
+  if (!lean)
+    CS_STEP(false, false);
+  else if (s.n <= kNtActionMaxEnvs)  // the state fits the L2s: keep the action stream out of them
+    CS_STEP(true, true);
   else
-    hipLaunchKernelGGL((step_kernel<TASK, MODE, false>), grid, block, 0, stream, s.tiles, s.n,
-                       io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,
-                       io.truncated_dev, c, s, io);
+    CS_STEP(true, false);
+#undef CS_STEP
   return hipGetLastError();
 }
 
