@@ -1,0 +1,90 @@
+// Plain C++ host: time cs_step() through the C ABI without Python -- eager launches and
+// hipGraph replay of a captured chunk (every entry point only enqueues on the given stream, so
+// a chunk of steps is capturable as is).  Usage: abi_bench [num_envs] [steps]
+// Prints one line per mode; used for the numbers in INTEGRATION.md, not by the test-suite.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "copterstep.h"
+
+#define OK(call)                                                                \
+  do {                                                                          \
+    int rc_ = (call);                                                           \
+    if (rc_ != 0) {                                                             \
+      std::fprintf(stderr, "FAIL %s -> %d: %s\n", #call, rc_, cs_last_error()); \
+      return 1;                                                                 \
+    }                                                                           \
+  } while (0)
+#define HIP(call)                                                          \
+  do {                                                                     \
+    hipError_t e_ = (call);                                                \
+    if (e_ != hipSuccess) {                                                \
+      std::fprintf(stderr, "FAIL %s: %s\n", #call, hipGetErrorString(e_)); \
+      return 2;                                                            \
+    }                                                                      \
+  } while (0)
+
+int main(int argc, char** argv) {
+  const int64_t n = argc > 1 ? std::atoll(argv[1]) : 65536;
+  const int steps = argc > 2 ? std::atoi(argv[2]) : 2000;
+  const int ring = 8, chunk = 100;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    std::fprintf(stderr, "no HIP device\n");
+    return 77;
+  }
+  cs_config cfg;
+  OK(cs_config_init(&cfg, CS_TASK_LANDER3D));
+  cfg.num_envs = n;
+  cfg.autoreset = CS_AUTORESET_NEXT_STEP;
+  cfg.seed = 1234;
+  cs_ctx* ctx = nullptr;
+  OK(cs_create(&cfg, &ctx));
+  float *act, *obs, *rew;
+  uint8_t *term, *trunc;
+  HIP(hipMalloc((void**)&act, (size_t)ring * n * 4 * sizeof(float)));
+  HIP(hipMalloc((void**)&obs, n * 10 * sizeof(float)));
+  HIP(hipMalloc((void**)&rew, n * sizeof(float)));
+  HIP(hipMalloc((void**)&term, n));
+  HIP(hipMalloc((void**)&trunc, n));
+  std::vector<float> h((size_t)ring * n * 4);
+  uint32_t lcg = 12345u;
+  for (auto& v : h) {
+    lcg = lcg * 1664525u + 1013904223u;
+    v = (float)(lcg >> 8) * (2.0f / 16777216.0f) - 1.0f;  // U[-1,1)
+  }
+  HIP(hipMemcpy(act, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  hipStream_t stream;
+  HIP(hipStreamCreate(&stream));
+  OK(cs_reset(ctx, nullptr, nullptr, obs, stream));
+  auto step = [&](int j) { return cs_step(ctx, act + (size_t)(j % ring) * n * 4, obs, rew, term, trunc, stream); };
+  for (int j = 0; j < 200; ++j) OK(step(j));
+  HIP(hipStreamSynchronize(stream));
+
+  auto t0 = std::chrono::steady_clock::now();
+  for (int j = 0; j < steps; ++j) OK(step(j));
+  HIP(hipStreamSynchronize(stream));
+  double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps;
+  std::printf("eager      %8lld envs  %8.3f us/step  %8.2f G env-steps/s\n", (long long)n, us, n / us * 1e-3);
+
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeGlobal));
+  for (int j = 0; j < chunk; ++j) OK(step(j));
+  HIP(hipStreamEndCapture(stream, &graph));
+  HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  HIP(hipGraphLaunch(exec, stream));
+  HIP(hipStreamSynchronize(stream));
+  const int reps = steps / chunk > 0 ? steps / chunk : 1;
+  t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < reps; ++r) HIP(hipGraphLaunch(exec, stream));
+  HIP(hipStreamSynchronize(stream));
+  us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (reps * chunk);
+  std::printf("hipGraph   %8lld envs  %8.3f us/step  %8.2f G env-steps/s\n", (long long)n, us, n / us * 1e-3);
+  OK(cs_destroy(ctx));
+  return 0;
+}
