@@ -126,6 +126,7 @@ class CopterVecEnv:
             self._trunc = torch.empty(n, dtype=torch.uint8, device=self.device)
             self._final_obs = None
             self._done = None
+        self._cache_outputs()
 
     def bind_outputs(self, obs, reward, terminated, truncated):
         """Make step()/reset() write into caller-provided device tensors (same shapes and dtypes
@@ -139,6 +140,18 @@ class CopterVecEnv:
             if tuple(t.shape) != shape or t.dtype != dt or t.device != self.device or not t.is_contiguous():
                 raise ValueError("bind_outputs: need contiguous %s %s on %s" % (dt, shape, self.device))
         self._obs, self._reward, self._term, self._trunc = obs, reward, terminated, truncated
+        self._cache_outputs()
+
+    def _cache_outputs(self):
+        """The output buffers are persistent: their device pointers and the bool views of the flag
+        buffers are computed once, not per step (the eager step path is host-bound)."""
+        torch = _torch()
+        self._out_ptrs = tuple(C.c_void_p(t.data_ptr())
+                               for t in (self._obs, self._reward, self._term, self._trunc))
+        self._term_b, self._trunc_b = self._term.view(torch.bool), self._trunc.view(torch.bool)
+        self._dev_index = self.device.index
+        # raw current-stream query (no Stream object); falls back to the public API
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
     # -- plumbing ------------------------------------------------------------------
     @property
@@ -146,6 +159,8 @@ class CopterVecEnv:
         return self
 
     def _stream(self):
+        if self._raw_stream is not None:
+            return C.c_void_p(self._raw_stream(self._dev_index))
         return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
     def _dev_f32(self, a, shape, name):
@@ -213,6 +228,17 @@ class CopterVecEnv:
         self._check_open()
         torch = _torch()
         a, was_numpy = self._dev_f32(actions, (self.num_envs, self.action_dim), "actions")
+        if self._final_obs is None and self._done is None and torch.cuda.current_device() == self._dev_index:
+            # fast path: resident actions, default outputs, the env's device already current
+            po, pr, pt, pu = self._out_ptrs
+            rc = self._lib.cs_step(self._ctx, C.c_void_p(a.data_ptr()), po, pr, pt, pu, self._stream())
+            if rc != 0:
+                _lib.check(rc)
+            self._keep = a
+            if was_numpy:
+                return (self._obs.cpu().numpy(), self._reward.cpu().numpy(), self._term_b.cpu().numpy(),
+                        self._trunc_b.cpu().numpy(), {})
+            return self._obs, self._reward, self._term_b, self._trunc_b, {}
         with torch.cuda.device(self.device):
             if self._final_obs is None and self._done is None:
                 _lib.check(self._lib.cs_step(
@@ -241,7 +267,7 @@ class CopterVecEnv:
             infos["final_obs"] = self._final_obs
         if self._done is not None:
             infos["episode"] = self._done
-        term, trunc = self._term.view(torch.bool), self._trunc.view(torch.bool)
+        term, trunc = self._term_b, self._trunc_b
         if was_numpy:
             return (self._obs.cpu().numpy(), self._reward.cpu().numpy(), term.cpu().numpy(),
                     trunc.cpu().numpy(), {k: _to_numpy(v) for k, v in infos.items()})
