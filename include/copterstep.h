@@ -22,6 +22,11 @@
  *   cs_get_state             Dynamics.getState / getStatus      dynamics/__init__.py:199-207,223-225
  *   cs_set_state             Dynamics.setState / perturb        dynamics/__init__.py:210-217,227-229
  *   cs_set_altitude          _Task.set_altitude                 envs/task.py:67-69
+ *   cs_obs_dim/cs_action_dim observation_space / action_space   envs/task.py:46-55 (attic variants: lander2d.py:43-50 ...)
+ *   cs_set_vehicle_params    the vehicle_params dict + G        vehicles/dji_phantom.py:9-26, dynamics/__init__.py:76, envs/task.py:161
+ *   cs_pid_* / cs_rollout_pid  the PID landing heuristic loop   attic/mars/pidcontrollers/__init__.py:12-146,
+ *                                                               attic/mars/lander3d.py:32-36,64-87
+ *   cs_rollout_random        the `--random` action loop         lander.py:40-65 (action = MOTORVAL*randn / action_space.sample())
  *
  * Conventions
  *   - Every function returns CS_OK (0) or a negative cs_status; cs_last_error() then
@@ -29,10 +34,12 @@
  *   - A context owns all of its device allocations (freed by cs_destroy) and belongs to
  *     ONE HIP device.  Pointers named *_dev are device pointers owned by the caller;
  *     pointers named *_host are host pointers.
- *   - cs_reset / cs_step / cs_step_ex / cs_set_motors only ENQUEUE work on `stream`
- *     (a hipStream_t, NULL = the null stream) and return; the caller synchronises.
- *     They may be captured into a hipGraph: they allocate nothing and never
- *     synchronise.  cs_get_state / cs_set_state synchronise `stream`.
+ *   - cs_reset / cs_step / cs_step_ex / cs_step_many / cs_rollout_* / cs_set_motors only
+ *     ENQUEUE work on `stream` (a hipStream_t, NULL = the null stream) and return; the
+ *     caller synchronises.  They may be captured into a hipGraph: they allocate nothing
+ *     and never synchronise.  cs_get_state / cs_set_state / cs_pid_get_state /
+ *     cs_pid_set_state synchronise `stream`; cs_pid_configure and cs_set_vehicle_params
+ *     allocate and synchronise the device (call them outside capture).
  *   - A context is not thread-safe; distinct contexts may be driven from distinct threads.
  *   - There is no CPU fallback: without a HIP device cs_create fails with CS_ERR_DEVICE.
  */
