@@ -257,7 +257,8 @@ def test_vec_per_env_vehicles_bit_exact_in_batch():
         o = VecOracle("lander3d", n, TaskParams(initial_altitude=alt), vp=vp, g=veh[9].copy())
         o.reset(forces=forces)
         for t in range(T):
-            obs, r, term, _ = o.step(acts[t])
+            with np.errstate(all="ignore"):      # short episodes keep free-running (and diverge) past their end
+                obs, r, term, _ = o.step(acts[t])
             for i, c in enumerate(cs):
                 g = VEH[c]
                 if t < len(g["reward"]):
