@@ -926,3 +926,50 @@ def test_rollout_random_is_bit_exact(task, mode, autoreset):
         assert_state_close(roll, orc, tol)
     for e in (roll, twin, ones):
         e.close()
+
+
+def test_full_size_all_stepping_paths_agree():
+    """BASELINE size (65 536 envs), 500 steps with reset churn: the random-policy rollout, the open-loop
+    K-step kernel and single steps -- eager and replayed from a hipGraph -- fed the same actions produce
+    bit-identical observations, rewards, flags and final states; the recorded actions are the oracle's
+    draw."""
+    import torch
+    from oracle.refvec import draw_actions
+    n, K, chunks = 65536, 50, 10
+    mk = lambda: make_pair("lander3d", n, "float32", autoreset="next_step", seed=2024)[0]
+    roll, many, single, graphed = mk(), mk(), mk(), mk()
+    for e in (roll, many, single, graphed):
+        e.reset()
+    ids = np.arange(n)
+    static_act = torch.zeros((n, 4), device=graphed.device)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        graphed.step(static_act)                       # warm-up outside capture (this step is re-done below)
+    torch.cuda.current_stream().wait_stream(s)
+    graphed.reset()
+    graphed.set_state(**{k: v for k, v in single.get_state().items()})   # identical starting point
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        g_out = graphed.step(static_act)
+    for c in range(chunks):
+        st = roll.get_state()
+        obs_r, rew_r, term_r, trunc_r, act = roll.rollout_random(K, return_actions=True)
+        assert np.array_equal(to_np(act[0]), draw_actions(2024, ids, st["episode"], st["steps"]))
+        obs_m, rew_m, term_m, trunc_m = many.step_many(act)
+        assert torch.equal(obs_r, obs_m) and torch.equal(rew_r, rew_m)
+        assert torch.equal(term_r, term_m) and torch.equal(trunc_r, trunc_m)
+        for k in range(K):
+            o, r, t, tr, _ = single.step(act[k])
+            assert torch.equal(o, obs_r[k]) and torch.equal(r, rew_r[k]) and torch.equal(t, term_r[k]), (c, k)
+            static_act.copy_(act[k])
+            g.replay()
+            assert torch.equal(g_out[0], o) and torch.equal(g_out[1], r) and torch.equal(g_out[2], t), (c, k)
+    assert int(term_r.sum()) > 0
+    ref = roll.get_state()
+    for e in (many, single, graphed):
+        st = e.get_state()
+        for key in ref:
+            assert np.array_equal(ref[key], st[key], equal_nan=True), key
+    for e in (roll, many, single, graphed):
+        e.close()
