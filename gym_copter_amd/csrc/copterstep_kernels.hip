@@ -452,7 +452,12 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, co
     sincos_f64(c, x[6], sph, cph);
     sincos_f64(c, x[8], sth, cth);
   }
-  sincos_f64(c, x[10], sps, cps);
+  // yaw is unbounded, but the yaw torque of this airframe is weak (D << B): it usually qualifies too
+  if (__all(fabs(x[10]) < 0.785)) {
+    sincos_kernel(c.trig, x[10], sps, cps);
+  } else {
+    sincos_f64(c, x[10], sps, cps);
+  }
   const double ax = w.bz * fma(cph * cps, sth, sph * sps);
   const double ay = w.bz * fma(cph * sps, sth, -(cps * sph));
   const double netz = fma(w.bz, cph * cth, q.G);
