@@ -3,6 +3,7 @@ every symbol include/copterstep.h declares, the ctypes mirror of cs_config match
 header's defaults, and the product path fails loudly (no CPU fallback) without a device."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -109,3 +110,16 @@ def test_c_host_builds_and_reports_missing_device():
     except Exception:
         gpu = False
     assert p.returncode == (0 if gpu else 77), (p.returncode, p.stderr)
+
+
+def test_bench_cpu_baseline_leg_runs_on_cpu():
+    """bench.py's cpu_baseline leg (the oracle timed on the host cores: 1 core for both action laws,
+    all cores, vectorised) is self-contained CPU code; a bounded sample here."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    out = bench.cpu_baseline("lander3d", "uniform", 0.5)
+    assert out["kind"] == "port" and out["cores"] == 1 and out["unit"] == "env-steps/s"
+    assert out["value"] > 1000 and out["one_core_other_law"]["actions"] == "const"
+    assert out["all_cores"]["cores"] == (os.cpu_count() or 1) and out["all_cores"]["value"] > out["value"] * 0.5
+    assert out["vectorised_numpy"]["value"] > out["value"]
