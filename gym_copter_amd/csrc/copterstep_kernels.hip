@@ -320,6 +320,36 @@ __device__ __forceinline__ Stored<MODE> encode_word(double v) {
   return o;
 }
 
+// The two halves of encode_word(), for code that keeps an env in registers over several steps:
+// round_stored() = the value the stored representation would decode to (all that the next
+// step needs); split_stored() = the word + guard byte of such a value, needed only when the
+// env finally goes back to HBM.
+template <int MODE>
+__device__ __forceinline__ double round_stored(double v) {
+  if constexpr (MODE == CS_STATE_F64) {
+    return v;
+  } else if constexpr (MODE == CS_STATE_F32_RN) {
+    return (double)(float)v;
+  } else {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v) + (1ULL << 20);
+    return __longlong_as_double((long long)(b & ~0x1FFFFFULL));
+  }
+}
+
+template <int MODE>
+__device__ __forceinline__ void split_stored(double value, typename ModeOf<MODE>::T& word,
+                                             uint32_t& guard) {
+  using T = typename ModeOf<MODE>::T;
+  if constexpr (MODE == CS_STATE_F32G) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(value);
+    guard = (uint32_t)(b >> 21) & 0xFFu;
+    word = (float)__longlong_as_double((long long)(b & ~0x1FFFFFFFULL));
+  } else {
+    guard = 0;
+    word = (T)value;
+  }
+}
+
 // np.clip(a, 0, 1) incl. its NaN passthrough (v_med3_f32 alone would turn NaN into 0)
 __device__ __forceinline__ float clip01(float a) {
   const float m = __builtin_amdgcn_fmed3f(a, 0.f, 1.f);
@@ -646,12 +676,18 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
   // ---- round to the stored word; everything below sees exactly what is stored ----
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
-    const Stored<MODE> w = encode_word<MODE>(e.x[k]);
-    e.xs[k] = w.word;
-    e.gs[k >> 2] |= w.guard << (8 * (k & 3));
-    e.x[k] = w.value;
+    if constexpr (ONE_STEP) {
+      const Stored<MODE> w = encode_word<MODE>(e.x[k]);
+      e.xs[k] = w.word;
+      e.gs[k >> 2] |= w.guard << (8 * (k & 3));
+      e.x[k] = w.value;
+    } else {
+      // the env stays in registers: only the decoded value is needed now, the words are split
+      // off when it is stored (step_many_kernel's epilogue)
+      e.x[k] = round_stored<MODE>(e.x[k]);
+    }
     // float32 observation: round-to-nearest of the stored value (slots FIRST .. FIRST+OBS-1)
-    if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w.value;
+    if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)e.x[k];
   }
 
   // ---- reward / termination (task.py:104-130, lander.py:46-74) ----
@@ -728,12 +764,15 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-      e.xs[k] = (k == 4) ? (T)c.z0 : (T)0;
-      if constexpr (!ONE_STEP) e.x[k] = (double)e.xs[k];
+      const T w0 = (k == 4) ? (T)c.z0 : (T)0;
+      if constexpr (ONE_STEP) {
+        e.xs[k] = w0;
+      } else {
+        e.x[k] = (double)w0;
+      }
+      if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
     }
     e.gs[0] = e.gs[1] = e.gs[2] = 0;
-#pragma unroll
-    for (int k = 0; k < OBS; ++k) out.row[k] = (float)e.xs[FIRST + k];
     e.fs = c.status0;
     e.pend = true;
     e.steps = 1;
@@ -1036,11 +1075,6 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   o.same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
 #pragma unroll
   for (int k = 0; k < 12; ++k) e.x[k] = decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
-  e.gs[0] = g[0];
-  e.gs[1] = g[1];
-  e.gs[2] = g[2];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) e.xs[k] = raw[k];
 
   cs_step_io io;  // no optional outputs in the K-step form
   io.actions_dev = nullptr;
@@ -1116,6 +1150,13 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   }
 
   if (e.fe_dirty) tile.store_fe(e.fe);
+  e.gs[0] = e.gs[1] = e.gs[2] = 0;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {  // words + guard bytes of the (already rounded) values
+    uint32_t guard;
+    split_stored<MODE>(e.x[k], e.xs[k], guard);
+    e.gs[k >> 2] |= guard << (8 * (k & 3));
+  }
   tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
   if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (opt_stats) tile.store_ret(e.ep_ret);
