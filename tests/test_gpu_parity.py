@@ -973,3 +973,47 @@ def test_full_size_all_stepping_paths_agree():
             assert np.array_equal(ref[key], st[key], equal_nan=True), key
     for e in (roll, many, single, graphed):
         e.close()
+
+
+def test_rollouts_are_graph_capturable():
+    """cs_rollout_random / cs_rollout_pid / cs_step_many only enqueue work: captured into a hipGraph
+    and replayed they advance the envs exactly as eager launches do."""
+    import torch
+    n, K = 5000, 16
+    mk = lambda: make_pair("lander3d", n, "float32", autoreset="next_step", seed=9)[0]
+    eager, graphed = mk(), mk()
+    for e in (eager, graphed):
+        e.configure_pid()
+        e.reset()
+    acts = torch.rand((K, n, 4), device=eager.device) * 2 - 1
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                      # warm-up (allocates the rollout buffers), then rewind
+        graphed.rollout_random(K)
+        graphed.rollout_pid(K)
+        graphed.step_many(acts)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graphed.reset()
+    graphed.set_state(**eager.get_state())
+    graphed.pid_set_state(eager.pid_get_state())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        r1 = graphed.rollout_random(K)
+        o_rand = r1[0].clone()
+        r2 = graphed.rollout_pid(K)
+        o_pid = r2[0].clone()
+        r3 = graphed.step_many(acts)
+        o_many = r3[0].clone()
+    for rep in range(3):
+        g.replay()
+        e1 = eager.rollout_random(K)[0].clone()
+        e2 = eager.rollout_pid(K)[0].clone()
+        e3 = eager.step_many(acts)[0].clone()
+        assert torch.equal(o_rand, e1) and torch.equal(o_pid, e2) and torch.equal(o_many, e3), rep
+    se, sg = eager.get_state(), graphed.get_state()
+    for key in se:
+        assert np.array_equal(se[key], sg[key], equal_nan=True), key
+    assert np.array_equal(eager.pid_get_state(), graphed.pid_get_state())
+    eager.close()
+    graphed.close()
