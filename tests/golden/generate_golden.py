@@ -22,9 +22,20 @@ needs modules that no longer exist upstream), so its fixture is produced by a
 subclass of the *imported live* _Task whose two overrides restate
 hover.py:18-21 (reward == 1) and hover3d.py:32-37 (12-component observation).
 
-Inputs are made float32-representable (actions, perturbation forces) so that
-the fp32 device path can be fed bit-identical inputs; the reference still
-computes everything in float64.
+Further series, all flown on the imported live classes:
+  * P (pid_traces.npz): closed loop under the reference's own PID controller
+    classes, loaded from attic/mars/pidcontrollers by file path and wired as
+    attic/mars/lander3d.py:64-87 does;
+  * V (variant_traces.npz): the 1D / 2D variants -- subclasses of the live Lander
+    whose _get_motors / _get_state hooks restate attic lander1d.py:43-48,
+    lander2d.py:43-50, hover1d.py:44-50, hover2d.py:44-50;
+  * W (vehicle_traces.npz): the live Lander with other `vehicle_params` dicts and
+    gravity constants (the module global of envs/task.py and Dynamics.G are
+    swapped for the duration of the run).
+
+Inputs are made float32-representable (actions, perturbation forces, vehicle
+parameters) so that the fp32 device path can be fed bit-identical inputs; the
+reference still computes everything in float64.
 
 Usage:  python tests/golden/generate_golden.py   (rewrites tests/golden/*.npz)
 """
