@@ -40,10 +40,12 @@ for rep in range(10):
     torch.cuda.synchronize()
     lib.cs_debug_read_stamps(env._ctx, buf.ctypes.data_as(C.c_void_p), None)
     b = buf[:N // 64].astype(np.int64)
-    res.append(np.diff(b, axis=1))
+    # slots in use: 0 kernel entry, 1 loads landed, 5 step body done, 6 stores issued, 7 stores acknowledged
+    res.append(np.stack([b[:, 1] - b[:, 0], b[:, 5] - b[:, 1], b[:, 6] - b[:, 5], b[:, 7] - b[:, 6],
+                         b[:, 7] - b[:, 0]], axis=1))
 d = np.median(np.stack(res), axis=0)
-names = ["loads issued -> landed", "decode + step body", "(unused)", "(unused)", "(unused)",
-         "stores issued", "stores acknowledged"]
+names = ["loads issued -> landed", "decode + step body", "stores issued (+ LDS transpose)", "stores acknowledged",
+         "whole wavefront"]
 print("N", N, law, "- shader-clock cycles per phase, median over wavefronts and 10 steps")
-for k in range(7):
-    print("%-28s %8.0f" % (names[k], np.median(d[:, k])))
+for k in range(5):
+    print("%-32s %8.0f" % (names[k], np.median(d[:, k])))
