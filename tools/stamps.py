@@ -3,6 +3,7 @@
 
   make -C gym_copter_amd/csrc stamps          # -> gym_copter_amd/csrc/build/libcopterstep_stamps.so
   python tools/stamps.py [num_envs] [uniform|near_hover]
+  STAMPS_THRASH_MB=512 python tools/stamps.py ...   # a 512 MB read-modify-write before every step (cold caches)
 
 The stamp build (-DCS_STAMPS) records s_memtime at phase boundaries of every wavefront into a
 side buffer; it serialises the phases, so read the SHARES, not the total.  Never the product."""
@@ -35,7 +36,10 @@ nt = (N + 255) // 256 * 4
 buf = np.zeros((nt, 8), dtype=np.uint64)
 lib.cs_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
 res = []
+thrash = torch.empty(int(os.environ.get("STAMPS_THRASH_MB", "0")) << 20, dtype=torch.uint8, device=dev)
 for rep in range(10):
+    if thrash.numel():
+        thrash.add_(1)          # STAMPS_THRASH_MB=512: push everything out of the L2s and the Infinity Cache first
     env.step(acts[rep % 8])
     torch.cuda.synchronize()
     lib.cs_debug_read_stamps(env._ctx, buf.ctypes.data_as(C.c_void_p), None)
