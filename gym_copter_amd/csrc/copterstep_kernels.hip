@@ -839,6 +839,10 @@ __device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, c
   e.fs = (int)((in.meta >> kMetaStatusShift) & 3u);
   e.pend = (in.meta & kMetaPerturbPending) != 0;
   e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && (in.meta & kMetaResetPending) != 0;
+#ifdef CS_STAMPS
+  asm volatile("" ::"v"(e.steps));  // the meta word (first load issued) has landed
+  CS_STAMP(2);
+#endif
   e.fe_dirty = false;
   e.prev_sh = in.prev_sh;
   e.ep_ret = in.ep_ret;
@@ -854,6 +858,21 @@ __device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, c
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   CS_STAMP(1);
+#ifdef CS_STAMPS
+  {  // probes: the same 16 bytes again (translation and L1 warm), then a line of this tile not touched yet
+    uint32_t probe;
+    asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)"
+                 : "=v"(probe)
+                 : "v"(tile.b16 - kBias + TILE::L.gm)
+                 : "memory");
+    CS_STAMP(3);
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)"
+                 : "=v"(probe)
+                 : "v"(tile.bg - kBias + TILE::L.fe)
+                 : "memory");
+    CS_STAMP(4);
+  }
+#endif
 
   // vehicle / world coefficients: uniform, or this env's own (full-featured build only)
   Coef q = uniform_coef(c);
