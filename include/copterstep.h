@@ -155,6 +155,9 @@ int cs_destroy(cs_ctx* ctx);
 int cs_num_envs(const cs_ctx* ctx, int64_t* out);
 int cs_obs_dim(const cs_ctx* ctx, int32_t* out);
 int cs_action_dim(const cs_ctx* ctx, int32_t* out); /* 4, 2 (2D variants) or 1 (1D variants) */
+/* Host-side settings: they take effect for launches enqueued afterwards.  A launch already
+ * captured into a hipGraph carries the values of its capture time (the seed, the altitude and
+ * every other cs_config value travel as kernel arguments): re-capture after changing them. */
 int cs_seed(cs_ctx* ctx, uint64_t seed);
 int cs_set_altitude(cs_ctx* ctx, double altitude);
 /* Reset envs with mask_dev[i] != 0 (NULL = all).  force_xyz_dev: [3,N] perturbation
