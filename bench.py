@@ -14,7 +14,12 @@ N_gpus * envs_per_gpu * K / max-over-ranks wall time of the K timed steps, plus
   roofline     : algorithmic bytes (176 B/env-step) per launch over the
                  launch duration measured with HIP events on the launch stream, vs 8 TB/s
   cpu_baseline : the scalar NumPy port of the reference (oracle/refcpu.py), timed here on
-                 the host, 1 core, bounded sample (a reported baseline, not a target)
+                 the host, 1 core, bounded sample (a reported baseline, not a target); beside
+                 it the other action law, all host cores (one process and env each) and the
+                 vectorised NumPy oracle
+and, reported BESIDE the headline (never as `value`), the K-steps-per-launch paths on the same
+envs: step_many (open loop over the resident action ring), rollout_pid (closed loop under the
+on-device PID heuristic), rollout_random (actions drawn on device).
 Multi-GPU: the env batch is sharded by contiguous env-id range with no data-path
 collective in the timed region ("scaling": "weak"); the optional concatenated-observation
 all-gather over RCCL is timed separately and reported as value_with_allgather.
