@@ -282,6 +282,14 @@ class PidGains:
     pos_windup: float = 0.2       # _PidController default windup_max
     descent_kp: float = 1.15      # DescentPidController(Kp=1.15, Kd=1.33)
     descent_kd: float = 1.33
+    # "hover" heuristic (attic/mars/hover3d.py:65-92): a yaw-rate controller with the rate gains and
+    # the altitude-hold controller of attic/mars/hover.py:23 replace the descent law
+    heuristic: str = "lander"
+    alt_kp: float = 0.2           # AltitudeHoldPidController(Kp=0.2, Ki=3, Kd=0, target=5)
+    alt_ki: float = 3.0
+    alt_kd: float = 0.0
+    alt_target: float = 5.0
+    alt_windup: float = 0.2
 
 
 class _Pid:
@@ -319,6 +327,8 @@ class PidHeuristic:
         self.rate_theta = _Pid(g.rate_kp, g.rate_ki, g.rate_kd, g.rate_windup)
         self.pos_for_roll = _Pid(g.pos_kp, g.pos_ki, g.pos_kd, g.pos_windup)    # upstream's x_poshold_pid, fed y
         self.pos_for_pitch = _Pid(g.pos_kp, g.pos_ki, g.pos_kd, g.pos_windup)   # upstream's y_poshold_pid, fed x
+        self.rate_psi = _Pid(g.rate_kp, g.rate_ki, g.rate_kd, g.rate_windup)    # hover heuristic only
+        self.alt = _Pid(g.alt_kp, g.alt_ki, g.alt_kd, g.alt_windup)             # hover heuristic only
         self.big = np.radians(g.rate_big)
 
     def _rate(self, pid, w):
@@ -335,6 +345,13 @@ class PidHeuristic:
         x, dx, y, dy, z, dz, phi, dphi, theta, dtheta = [float(v) for v in obs[:10]]
         phi_todo = self._rate(self.rate_phi, dphi) + self._pos(self.pos_for_roll, y, dy)
         theta_todo = self._rate(self.rate_theta, -dtheta) + self._pos(self.pos_for_pitch, x, dx)
+        if self.g.heuristic == "hover":            # attic/mars/hover3d.py:65-92
+            dpsi = float(obs[11])
+            yaw_todo = self._rate(self.rate_psi, -dpsi)
+            target_velocity = (self.g.alt_target - (-z)) * 1          # AltitudeHold: NED negated
+            hover_todo = self.alt.compute(target_velocity, -dz)
+            t, r, p, yw = (hover_todo + 1) / 2, phi_todo, theta_todo, yaw_todo
+            return np.array([t - r - p - yw, t + r + p - yw, t + r - p + yw, t - r + p + yw])
         descent_todo = z * self.g.descent_kp + dz * self.g.descent_kd
         t, r, p = (descent_todo + 1) / 2, phi_todo, theta_todo
         return np.array([t - r - p, t + r + p, t + r - p, t - r + p])

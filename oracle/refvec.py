@@ -367,16 +367,17 @@ class VecOracle:
 class VecPid:
     """oracle.refcpu.PidHeuristic over a batch (same float64 operation order, lane by lane):
     attic/mars/pidcontrollers/__init__.py:12-146 + attic/mars/lander3d.py:64-87.  Controller state
-    per env: 4 controllers x (errorI, lastError, deltaError1, deltaError2).  `reset(mask)` gives
+    per env: 6 controllers x (errorI, lastError, deltaError1, deltaError2); the last two (yaw rate,
+    altitude) belong to the hover heuristic.  `reset(mask)` gives
     the masked envs fresh controllers (a new episode)."""
 
-    ROLL_RATE, PITCH_RATE, ROLL_POS, PITCH_POS = range(4)
+    ROLL_RATE, PITCH_RATE, ROLL_POS, PITCH_POS, YAW_RATE, ALTITUDE = range(6)
 
     def __init__(self, num_envs, gains=None):
         from oracle.refcpu import PidGains
         self.g = gains or PidGains()
         self.n = num_envs
-        self.state = np.zeros((4, 4, num_envs))        # [controller][errI, last, d1, d2][env]
+        self.state = np.zeros((6, 4, num_envs))        # [controller][errI, last, d1, d2][env]
         self.big = np.radians(self.g.rate_big)
 
     def reset(self, mask=None):
@@ -420,7 +421,15 @@ class VecPid:
         x, dx, y, dy, z, dz, phi, dphi, theta, dtheta = o[:10]
         r = self._rate(self.ROLL_RATE, dphi) + self._pos(self.ROLL_POS, y, dy)
         p = self._rate(self.PITCH_RATE, -dtheta) + self._pos(self.PITCH_POS, x, dx)
-        t = ((z * self.g.descent_kp + dz * self.g.descent_kd) + 1) / 2
-        a = np.stack([t - r - p, t + r + p, t + r - p, t - r + p], axis=1)
+        g = self.g
+        if g.heuristic == "hover":                 # attic/mars/hover3d.py:65-92 (needs the 12-slot observation)
+            yw = self._rate(self.YAW_RATE, -o[11])
+            hover = self._compute(self.ALTITUDE, g.alt_kp, g.alt_ki, g.alt_kd, g.alt_windup,
+                                  (g.alt_target - (-z)) * 1, -dz)
+            t = (hover + 1) / 2
+            a = np.stack([t - r - p - yw, t + r + p - yw, t + r - p + yw, t - r + p + yw], axis=1)
+        else:
+            t = ((z * g.descent_kp + dz * g.descent_kd) + 1) / 2
+            a = np.stack([t - r - p, t + r + p, t + r - p, t - r + p], axis=1)
         with np.errstate(over="ignore"):
             return a.astype(np.float32)

@@ -253,11 +253,7 @@ def run_env(env, actions, seed, altitude=None, extra_after_done=25, action_dtype
         prev_shaping=np.asarray(rec["prev_shaping"]), x=np.asarray(rec["x"]))
 
 
-def e_series(_Task, Lander, vp):
-    rng = np.random.default_rng(777)
-    hov = hover_motor(vp)
-    MOTORVAL = 1.625e-2  # reference lander.py:21
-
+def make_hover_ref(_Task):
     class HoverRef(_Task):
         # restates attic hover.py:18-21 and hover3d.py:32-37 on the live _Task
         def __init__(self):
@@ -275,6 +271,15 @@ def e_series(_Task, Lander, vp):
 
         def _get_motors(self, motors):
             return motors
+    return HoverRef
+
+
+def e_series(_Task, Lander, vp):
+    rng = np.random.default_rng(777)
+    hov = hover_motor(vp)
+    MOTORVAL = 1.625e-2  # reference lander.py:21
+
+    HoverRef = make_hover_ref(_Task)
 
     T = 1100
     ones = np.ones((T, 4))
@@ -426,7 +431,7 @@ def main():
     print("numpy", np.__version__, "reference", REF)
     save("dynamics_traces.npz", d_series(Dynamics, vp))
     save("env_traces.npz", e_series(_Task, Lander, vp))
-    save("pid_traces.npz", p_series(Lander, load_mars_pid()))
+    save("pid_traces.npz", p_series(Lander, load_mars_pid(), make_hover_ref(_Task)))
     save("variant_traces.npz", v_series(_Task, Lander, vp))
     save("vehicle_traces.npz", w_series(Dynamics, Lander, vp))
     # known-answer constants observed from the reference (used as spot checks)
@@ -503,7 +508,63 @@ def run_pid_episode(Lander, pid, seed, steps, altitude=None, gains=None):
                 descent_gains=np.array([des["Kp"], des["Kd"]], dtype=np.float64))
 
 
-def p_series(Lander, pid):
+def run_pid_hover_episode(HoverRef, pid, seed, steps, altitude=None, gains=None):
+    """The hover heuristic of attic/mars/hover3d.py:65-92 (roll / pitch / yaw rate controllers, two
+    position-hold controllers, the altitude-hold controller of attic/mars/hover.py:23) with the
+    reference's controller classes, driving the Hover3D restatement on the live _Task."""
+    gains = gains or {}
+    rate = dict(Kp=1.0, Ki=0, Kd=1)
+    rate.update(gains.get("rate", {}))
+    pos = dict(Kp=0.00001, Ki=0.1, Kd=4, target=0)
+    pos.update(gains.get("pos", {}))
+    alt = dict(Kp=0.2, Ki=3, Kd=0, target=5)
+    alt.update(gains.get("alt", {}))
+    roll_rate_pid = pid.AngularVelocityPidController(**rate)
+    pitch_rate_pid = pid.AngularVelocityPidController(**rate)
+    yaw_rate_pid = pid.AngularVelocityPidController(**rate)
+    x_poshold_pid = pid.PositionHoldPidController(**pos)
+    y_poshold_pid = pid.PositionHoldPidController(**pos)
+    altpid = pid.AltitudeHoldPidController(**alt)
+
+    env = HoverRef()
+    if altitude is not None:
+        env.set_altitude(altitude)
+    np.random.seed(seed)
+    obs, _ = env.reset()
+    d = env.dynamics
+    force = f32r(d._perturb * d.M)
+    d.perturb(force.copy())
+    rec = dict(obs=[], reward=[], done=[], action=[], x=[])
+    for t in range(steps):
+        x, dx, y, dy, z, dz, phi, dphi, theta, dtheta, _, dpsi = [float(v) for v in obs]
+        roll_rate_todo = roll_rate_pid.getDemand(dphi)
+        y_pos_todo = x_poshold_pid.getDemand(y, dy)
+        pitch_rate_todo = pitch_rate_pid.getDemand(-dtheta)
+        x_pos_todo = y_poshold_pid.getDemand(x, dx)
+        roll_todo = roll_rate_todo + y_pos_todo
+        pitch_todo = pitch_rate_todo + x_pos_todo
+        yaw_todo = yaw_rate_pid.getDemand(-dpsi)
+        hover_todo = altpid.getDemand(z, dz)
+        tt, r, p, yw = (hover_todo + 1) / 2, roll_todo, pitch_todo, yaw_todo
+        action = f32r([tt - r - p - yw, tt + r + p - yw, tt + r - p + yw, tt - r + p + yw])
+        obs, reward, done, _, _ = env.step(action)
+        rec["obs"].append(obs)
+        rec["reward"].append(float(reward))
+        rec["done"].append(bool(done))
+        rec["action"].append(action)
+        rec["x"].append(d._x.copy())
+        if done:
+            break
+    return dict(seed=np.int64(seed), altitude=np.float64(env.initial_altitude), force=force[:3],
+                heuristic=np.array("hover"),
+                obs=np.asarray(rec["obs"], dtype=np.float32), reward=np.asarray(rec["reward"]),
+                done=np.asarray(rec["done"]), action=np.asarray(rec["action"]), x=np.asarray(rec["x"]),
+                rate_gains=np.array([rate["Kp"], rate["Ki"], rate["Kd"]], dtype=np.float64),
+                pos_gains=np.array([pos["Kp"], pos["Ki"], pos["Kd"], pos["target"]], dtype=np.float64),
+                alt_gains=np.array([alt["Kp"], alt["Ki"], alt["Kd"], alt["target"]], dtype=np.float64))
+
+
+def p_series(Lander, pid, HoverRef=None):
     cases = {}
     # reference gains (tuned upstream for the retired mars dynamics: bang-bang on the live model)
     cases["P01_pid_default"] = run_pid_episode(Lander, pid, seed=20, steps=400)
@@ -513,6 +574,14 @@ def p_series(Lander, pid):
                 pos=dict(Kp=0.0002, Ki=0.0, Kd=0.0))
     cases["P03_pid_soft"] = run_pid_episode(Lander, pid, seed=22, steps=1100, gains=soft)
     cases["P04_pid_soft"] = run_pid_episode(Lander, pid, seed=23, steps=1100, gains=soft)
+    if HoverRef is not None:
+        # the hover heuristic (attic/mars/hover3d.py:65-92): upstream's gains, then gains that do hover
+        cases["H01_hover_default"] = run_pid_hover_episode(HoverRef, pid, seed=40, steps=400)
+        cases["H02_hover_default_low"] = run_pid_hover_episode(HoverRef, pid, seed=41, steps=400, altitude=3.0)
+        tuned = dict(alt=dict(Kp=0.02, Ki=5.0, Kd=0, target=5), rate=dict(Kp=0.002, Kd=0.002),
+                     pos=dict(Kp=0.0002, Ki=0.0, Kd=0.0))
+        cases["H03_hover_tuned"] = run_pid_hover_episode(HoverRef, pid, seed=42, steps=1100, gains=tuned)
+        cases["H04_hover_tuned"] = run_pid_hover_episode(HoverRef, pid, seed=43, steps=1100, gains=tuned, altitude=5.0)
     return cases
 
 

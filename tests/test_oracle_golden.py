@@ -81,11 +81,17 @@ def test_pid_heuristic_closed_loop_bit_exact(name):
     controller classes (attic/mars/pidcontrollers) flew on the reference's live Lander."""
     from oracle.refcpu import PidGains, PidHeuristic
     g = PID[name]
-    rk, pk, dk = g["rate_gains"], g["pos_gains"], g["descent_gains"]
-    gains = PidGains(rate_kp=rk[0], rate_ki=rk[1], rate_kd=rk[2], pos_kp=pk[0], pos_ki=pk[1],
-                     pos_kd=pk[2], pos_target=pk[3], descent_kp=dk[0], descent_kd=dk[1])
+    rk, pk = g["rate_gains"], g["pos_gains"]
+    kw = dict(rate_kp=rk[0], rate_ki=rk[1], rate_kd=rk[2], pos_kp=pk[0], pos_ki=pk[1], pos_kd=pk[2], pos_target=pk[3])
+    hover = "heuristic" in g and str(g["heuristic"]) == "hover"
+    if hover:
+        ak = g["alt_gains"]
+        kw.update(heuristic="hover", alt_kp=ak[0], alt_ki=ak[1], alt_kd=ak[2], alt_target=ak[3])
+    else:
+        kw.update(descent_kp=g["descent_gains"][0], descent_kd=g["descent_gains"][1])
+    gains = PidGains(**kw)
     pol = PidHeuristic(gains)
-    env = TaskOracle("lander3d", TaskParams(initial_altitude=float(g["altitude"])))
+    env = TaskOracle("hover3d" if hover else "lander3d", TaskParams(initial_altitude=float(g["altitude"])))
     obs = env.reset(force_xyz=g["force"])
     for t in range(len(g["reward"])):
         a = pol.action(obs).astype(np.float32).astype(np.float64)    # the action space is float32

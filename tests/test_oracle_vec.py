@@ -217,14 +217,18 @@ def test_vecpid_matches_scalar_heuristic_closed_loop():
     n, T = 5, 160
     for gains in (PidGains(), PidGains(rate_kp=0.002, rate_kd=0.002, pos_kp=0.0002, pos_ki=0.0, pos_kd=0.0,
                                        descent_kp=0.004, descent_kd=0.012),
-                  PidGains(rate_ki=0.05, pos_ki=0.3)):
-        vec = VecOracle("lander3d", n, store_mode="float64", seed=11)
+                  PidGains(rate_ki=0.05, pos_ki=0.3),
+                  PidGains(heuristic="hover"),
+                  PidGains(heuristic="hover", alt_kp=0.02, alt_ki=5.0, rate_kp=0.002, rate_kd=0.002, rate_ki=0.01,
+                           pos_kp=0.0002, pos_ki=0.0, pos_kd=0.0)):
+        task = "hover3d" if gains.heuristic == "hover" else "lander3d"
+        vec = VecOracle(task, n, store_mode="float64", seed=11)
         obs = vec.reset()
         forces = vec.force[:3].astype(np.float64).T.copy()
         pid = VecPid(n, gains)
         scal = []
         for i in range(n):
-            env = TaskOracle("lander3d")
+            env = TaskOracle(task)
             o = env.reset(force_xyz=forces[i])
             scal.append((env, PidHeuristic(gains), o))
         for t in range(T):
