@@ -316,7 +316,7 @@ def main():
         wm, evm = timed(m, reps * k)
         per_step = evm / (reps * k)
         od = env.obs_dim
-        bytes_step = 4 * od + 4 + 2 + (200.0 + 256.0) / k   # obs, reward, flags out; env + controller state once per launch
+        bytes_step = 4 * od + 4 + 2 + (200.0 + 384.0) / k   # obs, reward, flags out; env + controller state once per launch
         extra["rollout_pid"] = {
             "steps_per_launch": k, "value": total_envs * reps * k / wm, "unit": "env-steps/s",
             "us_per_step": per_step * 1e6,

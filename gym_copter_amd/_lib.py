@@ -60,10 +60,14 @@ class StepIO(C.Structure):
 _P = C.c_void_p
 class PidGains(C.Structure):
     """cs_pid_gains (include/copterstep.h)."""
-    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32)] + \
+    _fields_ = [("struct_size", C.c_uint32), ("heuristic", C.c_int32)] + \
                [(k, C.c_double) for k in ("rate_kp rate_ki rate_kd rate_windup rate_big_deg pos_kp pos_ki "
-                                          "pos_kd pos_target pos_windup descent_kp descent_kd").split()]
+                                          "pos_kd pos_target pos_windup descent_kp descent_kd "
+                                          "alt_kp alt_ki alt_kd alt_target alt_windup").split()]
 
+
+PID_LANDER, PID_HOVER = 0, 1
+PID_ROWS = 24          # 6 controllers x {errorI, lastError, deltaError1, deltaError2}
 
 SYMBOLS = {
     "cs_version": (C.c_int, []),

@@ -15,7 +15,7 @@ struct cs_ctx {
   cs_config cfg;
   cs::DevState st;
   cs::Layout layout;
-  // on-device PID heuristic (cs_pid_configure): gains + [16][pid_stride] float64 controller state
+  // on-device PID heuristic (cs_pid_configure): gains + [24][pid_stride] float64 controller state
   bool pid_on = false;
   cs::PidConst pid{};
   double* pid_state = nullptr;
@@ -375,6 +375,12 @@ int cs_pid_gains_init(cs_pid_gains* g) {
   g->pos_windup = 0.2;
   g->descent_kp = 1.15;
   g->descent_kd = 1.33;
+  g->heuristic = CS_PID_LANDER;
+  g->alt_kp = 0.2;  // AltitudeHoldPidController(Kp=0.2, Ki=3, Kd=0, target=5), default windup
+  g->alt_ki = 3.0;
+  g->alt_kd = 0.0;
+  g->alt_target = 5.0;
+  g->alt_windup = 0.2;
   return CS_OK;
 }
 
@@ -382,12 +388,16 @@ int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* g) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (g == nullptr || g->struct_size != sizeof(cs_pid_gains))
     return fail(CS_ERR_ARG, "cs_pid_configure: gains missing or struct_size mismatch");
+  if (g->heuristic != CS_PID_LANDER && g->heuristic != CS_PID_HOVER)
+    return fail(CS_ERR_ARG, "cs_pid_configure: unknown heuristic");
+  if (g->heuristic == CS_PID_HOVER && cs::task_obs_dim(ctx->cfg.task) < 12)
+    return fail(CS_ERR_ARG, "cs_pid_configure: the hover heuristic reads dpsi, i.e. needs the Hover3D observation");
   CS_HIP(hipSetDevice(ctx->cfg.device));
   if (ctx->pid_state == nullptr) {
     // one float64 row per controller field, padded like the tiles so that lanes past the
     // last env have somewhere harmless to read and write
     const uint32_t stride = ctx->st.ntiles * 64u;
-    const size_t bytes = (size_t)16 * stride * sizeof(double);
+    const size_t bytes = (size_t)cs::kPidRows * stride * sizeof(double);
     double* p = nullptr;
     CS_HIP(hipMalloc((void**)&p, bytes));
     hipError_t e = hipMemset(p, 0, bytes);
@@ -413,6 +423,12 @@ int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* g) {
   p.pos_windup = g->pos_windup;
   p.descent_kp = g->descent_kp;
   p.descent_kd = g->descent_kd;
+  p.alt_kp = g->alt_kp;
+  p.alt_ki = g->alt_ki;
+  p.alt_kd = g->alt_kd;
+  p.alt_target = g->alt_target;
+  p.alt_windup = g->alt_windup;
+  p.hover = g->heuristic == CS_PID_HOVER ? 1 : 0;
   ctx->pid_on = true;
   return CS_OK;
 }
@@ -423,7 +439,7 @@ int cs_pid_get_state(cs_ctx* ctx, double* state_host, void* stream) {
   if (state_host == nullptr) return fail(CS_ERR_ARG, "cs_pid_get_state: null buffer");
   const size_t n = (size_t)ctx->cfg.num_envs;
   CS_HIP(hipMemcpy2DAsync(state_host, n * sizeof(double), ctx->pid_state,
-                          (size_t)ctx->pid_stride * sizeof(double), n * sizeof(double), 16,
+                          (size_t)ctx->pid_stride * sizeof(double), n * sizeof(double), cs::kPidRows,
                           hipMemcpyDeviceToHost, (hipStream_t)stream));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
   return CS_OK;
@@ -435,7 +451,7 @@ int cs_pid_set_state(cs_ctx* ctx, const double* state_host, void* stream) {
   if (state_host == nullptr) return fail(CS_ERR_ARG, "cs_pid_set_state: null buffer");
   const size_t n = (size_t)ctx->cfg.num_envs;
   CS_HIP(hipMemcpy2DAsync(ctx->pid_state, (size_t)ctx->pid_stride * sizeof(double), state_host,
-                          n * sizeof(double), n * sizeof(double), 16, hipMemcpyHostToDevice,
+                          n * sizeof(double), n * sizeof(double), cs::kPidRows, hipMemcpyHostToDevice,
                           (hipStream_t)stream));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
   return CS_OK;

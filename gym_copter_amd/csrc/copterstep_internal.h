@@ -135,7 +135,12 @@ struct PidConst {
   double rate_kp, rate_ki, rate_kd, rate_windup, rate_big;  // rate_big in rad/s
   double pos_kp, pos_ki, pos_kd, pos_target, pos_windup;
   double descent_kp, descent_kd;
+  double alt_kp, alt_ki, alt_kd, alt_target, alt_windup;  // hover heuristic (attic/mars/hover3d.py)
+  int32_t hover;                                          // 0 = landing heuristic, 1 = hover heuristic
+  int32_t pad_;
 };
+constexpr int kPidControllers = 6;  // roll rate, pitch rate, roll position, pitch position, yaw rate, altitude
+constexpr int kPidRows = 4 * kPidControllers;
 
 struct DevState {
   char* tiles;      // ntiles * tile_bytes

@@ -993,15 +993,30 @@ __device__ __forceinline__ double pid_pos(const PidConst& p, PidCtl& s, double x
   return pid_compute(s, p.pos_kp, p.pos_ki, p.pos_kd, p.pos_windup, target_velocity, dx);
 }
 
-// heuristic + mixer (attic/mars/lander3d.py:64-87)
+// heuristic + mixer: the landing heuristic (attic/mars/lander3d.py:64-87) or, on the 12-slot
+// observation, the hover heuristic (attic/mars/hover3d.py:65-92: a yaw-rate controller and the
+// altitude-hold controller of attic/mars/hover.py:23 instead of the descent law)
 template <int OBS>
-__device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[4],
+__device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[kPidControllers],
                                              const float (&obs)[OBS]) {
 #pragma clang fp contract(off)  // the controller arithmetic is reproduced bit for bit
   const double x = obs[0], dx = obs[1], y = obs[2], dy = obs[3], z = obs[4], dz = obs[5];
   const double dphi = obs[7], dtheta = obs[9];
   const double r = pid_rate(p, ctl[0], dphi) + pid_pos(p, ctl[2], y, dy);
   const double q = pid_rate(p, ctl[1], -dtheta) + pid_pos(p, ctl[3], x, dx);
+  if constexpr (OBS >= 12) {
+    if (p.hover != 0) {
+      const double dpsi = obs[11];
+      const double yw = pid_rate(p, ctl[4], -dpsi);
+      // AltitudeHoldPidController.getDemand (pidcontrollers/__init__.py:83-92): NED negated
+      const double target_velocity = (p.alt_target - (-z)) * 1.0;
+      const double hover =
+          pid_compute(ctl[5], p.alt_kp, p.alt_ki, p.alt_kd, p.alt_windup, target_velocity, -dz);
+      const double t = (hover + 1.0) / 2.0;
+      return make_float4((float)(((t - r) - q) - yw), (float)(((t + r) + q) - yw),
+                         (float)(((t + r) - q) + yw), (float)(((t - r) + q) + yw));
+    }
+  }
   const double t = ((z * p.descent_kp + dz * p.descent_kd) + 1.0) / 2.0;
   return make_float4((float)((t - r) - q), (float)((t + r) + q), (float)((t + r) - q),
                      (float)((t - r) + q));
@@ -1017,7 +1032,7 @@ __device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[4]
 //
 // POLICY: closed loop instead -- each step's action comes from the on-device PID heuristic
 // applied to the previous observation row (`actions_dev` is then an optional OUTPUT [K,N,4]);
-// the controller state lives in `pid_state` ([16][pid_stride] float64) between launches and is
+// the controller state lives in `pid_state` ([24][pid_stride] float64) between launches and is
 // zeroed whenever its env starts a new episode.
 enum { kPolicyNone = 0, kPolicyPid = 1, kPolicyRandom = 2 };
 
@@ -1057,6 +1072,11 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     pc.pos_windup = in_vgpr(pc.pos_windup);
     pc.descent_kp = in_vgpr(pc.descent_kp);
     pc.descent_kd = in_vgpr(pc.descent_kd);
+    pc.alt_kp = in_vgpr(pc.alt_kp);
+    pc.alt_ki = in_vgpr(pc.alt_ki);
+    pc.alt_kd = in_vgpr(pc.alt_kd);
+    pc.alt_target = in_vgpr(pc.alt_target);
+    pc.alt_windup = in_vgpr(pc.alt_windup);
   }
   DevState s = s_rest;
   s.tiles = tiles;
@@ -1108,11 +1128,11 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
   }
   float4 act = make_float4(0.f, 0.f, 0.f, 0.f);
-  PidCtl ctl[4];
+  PidCtl ctl[kPidControllers];
   float seen[OBS];  // the observation the policy acts on: what the previous step returned
   if constexpr (POLICY == kPolicyPid) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kPidControllers; ++j) {
       ctl[j].err_i = pid_state[(size_t)(4 * j + 0) * pid_stride + i];
       ctl[j].last = pid_state[(size_t)(4 * j + 1) * pid_stride + i];
       ctl[j].d1 = pid_state[(size_t)(4 * j + 2) * pid_stride + i];
@@ -1156,7 +1176,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
       if (out.did_reset) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < kPidControllers; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
       }
     }
     if (valid) {
@@ -1181,7 +1201,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   if (opt_stats) tile.store_ret(e.ep_ret);
   if constexpr (POLICY == kPolicyPid) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kPidControllers; ++j) {
       pid_state[(size_t)(4 * j + 0) * pid_stride + i] = ctl[j].err_i;
       pid_state[(size_t)(4 * j + 1) * pid_stride + i] = ctl[j].last;
       pid_state[(size_t)(4 * j + 2) * pid_stride + i] = ctl[j].d1;
@@ -1247,7 +1267,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
   if (mask == nullptr || mask[i] != 0) {
     if (pid_state != nullptr) {  // a new episode flies with fresh controllers
 #pragma unroll
-      for (int j = 0; j < 16; ++j) pid_state[(size_t)j * pid_stride + i] = 0.0;
+      for (int j = 0; j < kPidRows; ++j) pid_state[(size_t)j * pid_stride + i] = 0.0;
     }
     double f[3];
     const uint32_t episode = TileIO<MODE>::episode_of(tile.load_fe());

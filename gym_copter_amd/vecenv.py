@@ -330,16 +330,21 @@ class CopterVecEnv:
         return table
 
     # -- closed-loop rollouts under the on-device PID landing heuristic ----------------
-    def configure_pid(self, **gains):
-        """Install the PID landing heuristic (attic/mars/lander3d.py:32-36, :64-87 with the
-        controllers of attic/mars/pidcontrollers).  Keywords override upstream's gains:
-        rate_kp, rate_ki, rate_kd, rate_windup, rate_big_deg, pos_kp, pos_ki, pos_kd, pos_target,
-        pos_windup, descent_kp, descent_kd.  Returns the gains in effect."""
+    def configure_pid(self, heuristic="lander", **gains):
+        """Install a PID heuristic with the controllers of attic/mars/pidcontrollers:
+        heuristic="lander" = attic/mars/lander3d.py:32-36, :64-87 (descent law); "hover" =
+        attic/mars/hover3d.py:65-92 (yaw-rate + altitude-hold controllers; Hover3D only).  Keywords
+        override upstream's gains: rate_kp, rate_ki, rate_kd, rate_windup, rate_big_deg, pos_kp,
+        pos_ki, pos_kd, pos_target, pos_windup, descent_kp, descent_kd, alt_kp, alt_ki, alt_kd,
+        alt_target, alt_windup.  Returns the gains in effect."""
         self._check_open()
         g = _lib.PidGains()
         _lib.check(self._lib.cs_pid_gains_init(C.byref(g)))
+        if heuristic not in ("lander", "hover"):
+            raise ValueError("heuristic must be 'lander' or 'hover'")
+        g.heuristic = _lib.PID_HOVER if heuristic == "hover" else _lib.PID_LANDER
         for k, v in gains.items():
-            if k in ("struct_size", "reserved") or not hasattr(g, k):
+            if k in ("struct_size", "heuristic") or not hasattr(g, k):
                 raise TypeError("unknown PID gain %r" % (k,))
             setattr(g, k, float(v))
         torch = _torch()
@@ -383,9 +388,9 @@ class CopterVecEnv:
         return out + (buf[4],) if return_actions else out
 
     def pid_get_state(self):
-        """Controller state as a host array [16, N] float64 (rows: see include/copterstep.h)."""
+        """Controller state as a host array [24, N] float64 (rows: see include/copterstep.h)."""
         self._check_open()
-        out = np.empty((16, self.num_envs), dtype=np.float64)
+        out = np.empty((_lib.PID_ROWS, self.num_envs), dtype=np.float64)
         torch = _torch()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.cs_pid_get_state(self._ctx, out.ctypes.data_as(C.c_void_p), self._stream()))
@@ -393,7 +398,7 @@ class CopterVecEnv:
 
     def pid_set_state(self, state):
         self._check_open()
-        st = np.ascontiguousarray(np.asarray(state, dtype=np.float64).reshape(16, self.num_envs))
+        st = np.ascontiguousarray(np.asarray(state, dtype=np.float64).reshape(_lib.PID_ROWS, self.num_envs))
         torch = _torch()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.cs_pid_set_state(self._ctx, st.ctypes.data_as(C.c_void_p), self._stream()))

@@ -186,23 +186,27 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
  *   attic/mars/lander3d.py:32-36, :64-87          gains, heuristic(), mixer
  * Defaults of cs_pid_gains_init() are upstream's (rate 1/0/1, windup 6, 40 deg/s;
  * position 1e-5/0.1/4, target 0, windup 0.2; descent 1.15/1.33). */
+enum { CS_PID_LANDER = 0, CS_PID_HOVER = 1 };
 typedef struct cs_pid_gains {
   uint32_t struct_size; /* sizeof(cs_pid_gains) */
-  uint32_t reserved;
+  int32_t heuristic;    /* CS_PID_LANDER: attic/mars/lander3d.py:64-87 (descent law);
+                           CS_PID_HOVER: attic/mars/hover3d.py:65-92 (yaw-rate controller + the
+                           altitude-hold controller of attic/mars/hover.py:23; Hover3D task only) */
   double rate_kp, rate_ki, rate_kd, rate_windup, rate_big_deg; /* AngularVelocityPidController */
   double pos_kp, pos_ki, pos_kd, pos_target, pos_windup;       /* PositionHoldPidController */
   double descent_kp, descent_kd;                               /* DescentPidController */
+  double alt_kp, alt_ki, alt_kd, alt_target, alt_windup;       /* AltitudeHoldPidController (0.2, 3, 0, 5) */
 } cs_pid_gains;
 
 int cs_pid_gains_init(cs_pid_gains* gains);
-/* Install gains and (first call) allocate the controller state: 16 float64 per env, zeroed =
+/* Install gains and (first call) allocate the controller state: 24 float64 per env, zeroed =
  * freshly constructed controllers.  Synchronous; call outside stream capture.  From then on
  * cs_reset() and the auto-reset inside rollouts also restart the controllers of the envs they
  * reset. */
 int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* gains);
-/* Controller state <-> HOST [16,N] float64: row 4*c+f, controller c in {roll rate, pitch rate,
- * roll position (fed y), pitch position (fed x)}, field f in {errorI, lastError, deltaError1,
- * deltaError2}.  Synchronises `stream`. */
+/* Controller state <-> HOST [24,N] float64: row 4*c+f, controller c in {roll rate, pitch rate,
+ * roll position (fed y), pitch position (fed x), yaw rate, altitude (the last two: hover heuristic
+ * only)}, field f in {errorI, lastError, deltaError1, deltaError2}.  Synchronises `stream`. */
 int cs_pid_get_state(cs_ctx* ctx, double* state_host, void* stream);
 int cs_pid_set_state(cs_ctx* ctx, const double* state_host, void* stream);
 /* K closed-loop steps in ONE launch: action_k = heuristic(observation returned by step k-1,

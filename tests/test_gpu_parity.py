@@ -565,6 +565,9 @@ def test_step_many_is_bit_identical_to_single_steps(task, mode, autoreset):
 PID = load_cases("pid_traces.npz")
 PID_GAINS = {
     "upstream": {},
+    "hover": dict(heuristic="hover"),
+    "hover_tuned": dict(heuristic="hover", alt_kp=0.02, alt_ki=5.0, rate_kp=0.002, rate_kd=0.002, rate_ki=0.01,
+                        pos_kp=0.0002, pos_ki=0.0, pos_kd=0.0),
     "soft": dict(rate_kp=0.002, rate_kd=0.002, pos_kp=0.0002, pos_ki=0.0, pos_kd=0.0,
                  descent_kp=0.004, descent_kd=0.012),
     "integral": dict(rate_ki=0.05, pos_ki=0.3, rate_big_deg=5.0),
@@ -580,8 +583,11 @@ def _oracle_gains(kw):
 @pytest.mark.parametrize("task,mode,autoreset", [("lander3d", "float32", "next_step"),
                                                  ("lander3d", "float64", "same_step"),
                                                  ("lander3d", "float32_rn", "disabled"),
-                                                 ("hover3d", "float32", "next_step")])
+                                                 ("hover3d", "float32", "next_step"),
+                                                 ("hover3d", "float64", "disabled")])
 def test_rollout_pid_policy_is_bit_exact(task, mode, autoreset, gains):
+    if PID_GAINS[gains].get("heuristic") == "hover" and task != "hover3d":
+        pytest.skip("the hover heuristic reads dpsi: Hover3D observation only")
     """The on-device controllers against the oracle's (VecPid), bit for bit: a twin device env is
     stepped one cs_step at a time with the ORACLE's actions computed from the observations the
     device returned.  Both envs share the HIP physics, so every action, every output of every step,
@@ -616,7 +622,7 @@ def test_rollout_pid_policy_is_bit_exact(task, mode, autoreset, gains):
         sr, st = roll.get_state(), twin.get_state()
         for key in sr:
             assert np.array_equal(sr[key], st[key], equal_nan=True), (chunk, key)
-        assert np.array_equal(roll.pid_get_state(), pid.state.reshape(16, n)), chunk
+        assert np.array_equal(roll.pid_get_state(), pid.state.reshape(24, n)), chunk
     if autoreset != "disabled" and gains == "upstream":
         assert resets > 0      # the bang-bang upstream gains tip the copter over within ~130 steps
     roll.close()
@@ -632,22 +638,34 @@ def test_rollout_pid_golden_traces(mode):
     cs = PID.names()
     for c in cs:
         g = PID[c]
-        rk, pk, dk = g["rate_gains"], g["pos_gains"], g["descent_gains"]
-        env, _ = make_pair("lander3d", 1, mode, initial_altitude=float(g["altitude"]))
-        env.configure_pid(rate_kp=rk[0], rate_ki=rk[1], rate_kd=rk[2], pos_kp=pk[0], pos_ki=pk[1],
-                          pos_kd=pk[2], pos_target=pk[3], descent_kp=dk[0], descent_kd=dk[1])
+        rk, pk = g["rate_gains"], g["pos_gains"]
+        kw = dict(rate_kp=rk[0], rate_ki=rk[1], rate_kd=rk[2], pos_kp=pk[0], pos_ki=pk[1], pos_kd=pk[2],
+                  pos_target=pk[3])
+        hover = "heuristic" in g and str(g["heuristic"]) == "hover"
+        if hover:
+            ak = g["alt_gains"]
+            kw.update(heuristic="hover", alt_kp=ak[0], alt_ki=ak[1], alt_kd=ak[2], alt_target=ak[3])
+        else:
+            kw.update(descent_kp=g["descent_gains"][0], descent_kd=g["descent_gains"][1])
+        env, _ = make_pair("hover3d" if hover else "lander3d", 1, mode, initial_altitude=float(g["altitude"]))
+        env.configure_pid(**kw)
         env.reset(options={"forces": g["force"][:3].astype(np.float32).reshape(3, 1)})
         T = len(g["reward"])
+        if hover and mode != "float64":
+            # the reference's altitude controller cannot hold the live vehicle (its gains were tuned for
+            # the retired mars dynamics): the loop runs away, and an unstable loop amplifies the 1e-7
+            # word rounding without bound -- float32 modes are compared over the first 300 steps
+            T = min(T, 300)
         obs, rew, term, trunc, act = (to_np(v) for v in env.rollout_pid(T, return_actions=True))
         # float32_rn (bare float32 words, not the default): the derivative terms of the bang-bang
         # upstream gains feed the word rounding back into the motors, so the closed loop is held
         # to 1e-3 there; the default guarded mode meets the north-star bar, float64 mode 1e-9
         tol = {"float64": 1e-9, "float32": BAR, "float32_rn": 1e-3}[mode]
-        assert np.array_equal(term[:, 0], g["done"].astype(bool)), c
+        assert np.array_equal(term[:, 0], g["done"][:T].astype(bool)), c
         assert not trunc.any()
-        e_obs = scaled_err(obs[:, 0], g["obs"])
-        e_act = scaled_err(act[:, 0], g["action"])
-        e_rew = float(np.max(np.abs(rew[:, 0] - g["reward"]) / np.maximum(np.abs(g["reward"]), 100.0)))
+        e_obs = scaled_err(obs[:, 0], g["obs"][:T])
+        e_act = scaled_err(act[:, 0], g["action"][:T])
+        e_rew = float(np.max(np.abs(rew[:, 0] - g["reward"][:T]) / np.maximum(np.abs(g["reward"][:T]), 100.0)))
         assert e_obs <= tol and e_act <= max(10 * tol, 1e-7) and e_rew <= max(tol, 1e-5), (c, mode, e_obs, e_act, e_rew)
         env.close()
 
