@@ -105,6 +105,7 @@ template <int MODE, bool STREAM = false>
 struct TileIO {
   using T = typename ModeOf<MODE>::T;
   static constexpr Layout L = ModeOf<MODE>::L;
+  static constexpr bool kWholeRowFe = STREAM;
   char* b16;  // lane stride 16      (GM group)
   char* bg;   // lane stride 4*word  (X0..X2, FE groups)
   char* b4;   // lane stride 4       (RET row, bare META row)
@@ -756,7 +757,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     double fr[3];
     const uint32_t episode = TileIO<MODE>::episode_of(e.fe);
     draw_force(c, i, episode, fr);
-    if constexpr (ONE_STEP) {
+    if constexpr (ONE_STEP && !TILE::kWholeRowFe) {
       tile.store_fe(TileIO<MODE>::make_fe(fr, episode + 1));
     } else {
       e.fe = TileIO<MODE>::make_fe(fr, episode + 1);
@@ -850,7 +851,13 @@ __device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, c
   // conversion of `fe` into the branch below and wait for this load right there)
   const T zero = (T)(c.nsub >> 30);
   e.fe = {{zero, zero, zero, zero}};
-  if (e.pend || e.reset_pending || o.same_step) e.fe = tile.load_fe();
+  if constexpr (TILE::kWholeRowFe) {
+    // HBM-resident batches: the FE group moves as whole 1 KiB rows whenever any lane of the
+    // wavefront needs it -- masked 16-byte writes cost read-modify-write cycles in ECC HBM
+    if (__any(e.pend || e.reset_pending || o.same_step)) e.fe = tile.load_fe();
+  } else {
+    if (e.pend || e.reset_pending || o.same_step) e.fe = tile.load_fe();
+  }
 
 #pragma unroll
   for (int k = 0; k < 12; ++k) e.x[k] = decode_word<MODE>(in.raw[k], in.g[k >> 2], k, c.guard_mask);
@@ -883,6 +890,9 @@ __device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, c
   advance<TASK, MODE, OBS, true>(c, q, o, e, in.act, io, i, lane, valid, tile, out);
 
   CS_STAMP(5);
+  if constexpr (TILE::kWholeRowFe) {
+    if (__any(e.fe_dirty)) tile.store_fe(e.fe);
+  }
   // ---- stores: 4 x 16 B (state, guards + meta) + prev_shaping ----
   tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
   if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);

@@ -1035,3 +1035,31 @@ def test_rollouts_are_graph_capturable():
     assert np.array_equal(eager.pid_get_state(), graphed.pid_get_state())
     eager.close()
     graphed.close()
+
+
+def test_streaming_instantiation_matches_k_step_kernel():
+    """From 3.5 M envs up the launcher picks the step-kernel instantiation that streams the state past
+    the caches (non-temporal loads / stores, whole-row FE traffic).  The K-step kernel never streams:
+    single steps at such a batch size must reproduce it bit for bit, through resets."""
+    import torch
+    n, K = 3670016 + 5 * 64 + 37, 8
+    mk = lambda: make_pair("lander3d", n, "float32", autoreset="next_step", seed=31)[0]
+    single, many = mk(), mk()
+    single.reset()
+    many.reset()
+    g = torch.Generator(device=single.device)
+    g.manual_seed(5)
+    resets = 0
+    for chunk in range(3):
+        acts = torch.rand((K, n, 4), generator=g, device=single.device) * 2 - 1
+        obs_m, rew_m, term_m, trunc_m = many.step_many(acts)
+        for k in range(K):
+            o, r, t, tr, _ = single.step(acts[k])
+            assert torch.equal(o, obs_m[k]) and torch.equal(r, rew_m[k]) and torch.equal(t, term_m[k]), (chunk, k)
+        resets += int(term_m.sum())
+    assert resets > n            # every env finished at least one episode on average
+    ss, sm = single.get_state(), many.get_state()
+    for key in ss:
+        assert np.array_equal(ss[key], sm[key], equal_nan=True), key
+    single.close()
+    many.close()
