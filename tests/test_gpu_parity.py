@@ -1037,13 +1037,14 @@ def test_rollouts_are_graph_capturable():
     graphed.close()
 
 
-def test_streaming_instantiation_matches_k_step_kernel():
+@pytest.mark.parametrize("mode", ["float32", "float64"])
+def test_streaming_instantiation_matches_k_step_kernel(mode):
     """From 3.5 M envs up the launcher picks the step-kernel instantiation that streams the state past
     the caches (non-temporal loads / stores, whole-row FE traffic).  The K-step kernel never streams:
     single steps at such a batch size must reproduce it bit for bit, through resets."""
     import torch
     n, K = 3670016 + 5 * 64 + 37, 8
-    mk = lambda: make_pair("lander3d", n, "float32", autoreset="next_step", seed=31)[0]
+    mk = lambda: make_pair("lander3d", n, mode, autoreset="next_step", seed=31)[0]
     single, many = mk(), mk()
     single.reset()
     many.reset()
