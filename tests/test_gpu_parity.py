@@ -826,6 +826,12 @@ def test_randomised_vehicles_match_oracle(task, mode, autoreset):
             assert np.array_equal(to_np(obs_m[k]), got[0]) and np.array_equal(to_np(rew_m[k]), got[1])
             assert np.array_equal(to_np(term_m[k]), got[2])
         assert_state_close(env, orc, tol)
+    # on-device random policy with per-env parameters: the rollout's actions replayed as single steps
+    obs_r, rew_r, term_r, trunc_r, act_r = many.rollout_random(6, return_actions=True)
+    for k in range(6):
+        got, want, _ = step_both(env, orc, to_np(act_r[k]))
+        assert np.array_equal(to_np(obs_r[k]), got[0]) and np.array_equal(to_np(rew_r[k]), got[1]), k
+        assert_step_close(got, want, tol, r_abs=2e-3, r_rel=2e-6, ctx=("rollout", k))
     # dynamics-only entry point with per-env parameters
     m = rng.uniform(0, 0.05, (n, 4)).astype(np.float32)
     env.set_motors(torch.from_numpy(m).to(env.device))
