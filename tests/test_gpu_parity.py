@@ -326,11 +326,17 @@ def test_time_limit_as_truncation():
     env.reset(options={"forces": z})
     orc.reset(forces=z)
     a = np.full((130, 4), HOVER, dtype=np.float32)
+    import torch
+    many, _ = make_pair("hover3d", 130, "float32", time_limit_truncates=True, max_steps=25)
+    many.reset(options={"forces": z})
+    obs_m, rew_m, term_m, trunc_m = many.step_many(torch.from_numpy(np.broadcast_to(a, (25, 130, 4)).copy()).to(many.device))
     for t in range(25):
         got, want, _ = step_both(env, orc, a)
         assert_step_close(got, want, 1e-7)
         assert got[3].all() == (t == 24) and not got[2].any()
+        assert np.array_equal(to_np(trunc_m[t]), got[3]) and np.array_equal(to_np(obs_m[t]), got[0])   # K-step kernel too
     env.close()
+    many.close()
 
 
 # ---------------------------------------------------------------------------------------
