@@ -1006,16 +1006,17 @@ __device__ __forceinline__ double pid_pos(const PidConst& p, PidCtl& s, double x
 // heuristic + mixer: the landing heuristic (attic/mars/lander3d.py:64-87) or, on the 12-slot
 // observation, the hover heuristic (attic/mars/hover3d.py:65-92: a yaw-rate controller and the
 // altitude-hold controller of attic/mars/hover.py:23 instead of the descent law)
-template <int OBS>
-__device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[kPidControllers],
+template <int OBS, bool HOVER, int NCTL>
+__device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[NCTL],
                                              const float (&obs)[OBS]) {
 #pragma clang fp contract(off)  // the controller arithmetic is reproduced bit for bit
   const double x = obs[0], dx = obs[1], y = obs[2], dy = obs[3], z = obs[4], dz = obs[5];
   const double dphi = obs[7], dtheta = obs[9];
   const double r = pid_rate(p, ctl[0], dphi) + pid_pos(p, ctl[2], y, dy);
   const double q = pid_rate(p, ctl[1], -dtheta) + pid_pos(p, ctl[3], x, dx);
-  if constexpr (OBS >= 12) {
-    if (p.hover != 0) {
+  if constexpr (HOVER) {
+    static_assert(OBS >= 12 && NCTL == kPidControllers, "the hover heuristic reads dpsi and has six controllers");
+    {
       const double dpsi = obs[11];
       const double yw = pid_rate(p, ctl[4], -dpsi);
       // AltitudeHoldPidController.getDemand (pidcontrollers/__init__.py:83-92): NED negated
@@ -1044,7 +1045,9 @@ __device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[kP
 // applied to the previous observation row (`actions_dev` is then an optional OUTPUT [K,N,4]);
 // the controller state lives in `pid_state` ([24][pid_stride] float64) between launches and is
 // zeroed whenever its env starts a new episode.
-enum { kPolicyNone = 0, kPolicyPid = 1, kPolicyRandom = 2 };
+// (the hover heuristic is its own instantiation: its six controllers cost 16 more VGPRs, which
+// would take the landing-heuristic kernel from four to three wavefronts per SIMD)
+enum { kPolicyNone = 0, kPolicyPid = 1, kPolicyRandom = 2, kPolicyPidHover = 3 };
 
 template <int TASK, int MODE, bool LEAN, int POLICY>
 __global__ __launch_bounds__(kBlock) void step_many_kernel(
@@ -1069,7 +1072,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   c.target_r2 = in_vgpr(c.target_r2);
   c.bonus = in_vgpr(c.bonus);
   c.oob_penalty = in_vgpr(c.oob_penalty);
-  if constexpr (POLICY == kPolicyPid) {
+  constexpr bool kPid = POLICY == kPolicyPid || POLICY == kPolicyPidHover;
+  constexpr int NCTL = POLICY == kPolicyPidHover ? kPidControllers : 4;
+  if constexpr (kPid) {
     pc.rate_kp = in_vgpr(pc.rate_kp);
     pc.rate_ki = in_vgpr(pc.rate_ki);
     pc.rate_kd = in_vgpr(pc.rate_kd);
@@ -1138,11 +1143,11 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
   }
   float4 act = make_float4(0.f, 0.f, 0.f, 0.f);
-  PidCtl ctl[kPidControllers];
+  PidCtl ctl[NCTL];
   float seen[OBS];  // the observation the policy acts on: what the previous step returned
-  if constexpr (POLICY == kPolicyPid) {
+  if constexpr (kPid) {
 #pragma unroll
-    for (int j = 0; j < kPidControllers; ++j) {
+    for (int j = 0; j < NCTL; ++j) {
       ctl[j].err_i = pid_state[(size_t)(4 * j + 0) * pid_stride + i];
       ctl[j].last = pid_state[(size_t)(4 * j + 1) * pid_stride + i];
       ctl[j].d1 = pid_state[(size_t)(4 * j + 2) * pid_stride + i];
@@ -1157,9 +1162,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     // rows of step k (64-bit uniform offsets: K * N can exceed 32 bits)
     const size_t row = (size_t)k * n;
     float4 act_next = act;
-    if constexpr (POLICY == kPolicyPid) {
+    if constexpr (kPid) {
       static_assert(OBS >= 10, "the PID heuristic reads the 3D observation");
-      act = pid_policy<OBS>(pc, ctl, seen);
+      act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL>(pc, ctl, seen);
       if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
     } else if constexpr (POLICY == kPolicyRandom) {
       const float4 a = draw_action(c, i, TileIO<MODE>::episode_of(e.fe), (uint32_t)e.steps);
@@ -1181,12 +1186,12 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     }
     StepOut<OBS> out;
     advance<TASK, MODE, OBS, false>(c, q, o, e, act, io, i, lane, valid, tile, out);
-    if constexpr (POLICY == kPolicyPid) {
+    if constexpr (kPid) {
 #pragma unroll
       for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
       if (out.did_reset) {
 #pragma unroll
-        for (int j = 0; j < kPidControllers; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < NCTL; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
       }
     }
     if (valid) {
@@ -1209,9 +1214,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
   if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (opt_stats) tile.store_ret(e.ep_ret);
-  if constexpr (POLICY == kPolicyPid) {
+  if constexpr (kPid) {
 #pragma unroll
-    for (int j = 0; j < kPidControllers; ++j) {
+    for (int j = 0; j < NCTL; ++j) {
       pid_state[(size_t)(4 * j + 0) * pid_stride + i] = ctl[j].err_i;
       pid_state[(size_t)(4 * j + 1) * pid_stride + i] = ctl[j].last;
       pid_state[(size_t)(4 * j + 2) * pid_stride + i] = ctl[j].d1;
@@ -1374,10 +1379,20 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
   if (policy == kPolicyPid) {
     if constexpr (task_act_dim(TASK) == 4) {  // the heuristic reads the 3D observation
       if (pid == nullptr || pid_state == nullptr) return hipErrorInvalidValue;
-      if (lean)
+      if (pc.hover != 0) {
+        if constexpr (task_obs_dim(TASK) >= 12) {
+          if (lean)
+            CS_MANY(true, kPolicyPidHover);
+          else
+            CS_MANY(false, kPolicyPidHover);
+        } else {
+          return hipErrorInvalidValue;
+        }
+      } else if (lean) {
         CS_MANY(true, kPolicyPid);
-      else
+      } else {
         CS_MANY(false, kPolicyPid);
+      }
     } else {
       return hipErrorInvalidValue;
     }
