@@ -123,3 +123,15 @@ def test_bench_cpu_baseline_leg_runs_on_cpu():
     assert out["value"] > 1000 and out["one_core_other_law"]["actions"] == "const"
     assert out["all_cores"]["cores"] == (os.cpu_count() or 1) and out["all_cores"]["value"] > out["value"] * 0.5
     assert out["vectorised_numpy"]["value"] > out["value"]
+
+
+def test_header_is_plain_c():
+    """include/copterstep.h is a C ABI: it must compile as C99 (and as C++) on its own."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "copterstep.h")
+    if shutil.which("gcc"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                               "-x", "c", hdr])
+    if shutil.which("g++"):
+        subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
