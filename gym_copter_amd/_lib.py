@@ -85,6 +85,7 @@ SYMBOLS = {
     "cs_step_ex": (C.c_int, [_P, C.POINTER(StepIO), _P]),
     "cs_step_many": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_set_motors": (C.c_int, [_P, _P, _P]),
+    "cs_export_state": (C.c_int, [_P, _P, _P, _P, _P]),
     "cs_set_vehicle_params": (C.c_int, [_P, _P]),
     "cs_pid_gains_init": (C.c_int, [_P]),
     "cs_pid_configure": (C.c_int, [_P, _P]),

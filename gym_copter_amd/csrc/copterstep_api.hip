@@ -498,6 +498,15 @@ int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
   return CS_OK;
 }
 
+int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  const cs::DevConst c = make_const(ctx);
+  hipError_t e = cs::launch_export_state(ctx->cfg.state_mode, c, ctx->st, x_dev, status_dev, steps_dev,
+                                         (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_export_state: kernel launch");
+  return CS_OK;
+}
+
 // ---- host <-> device state exchange (not a hot path): the whole tile slab is staged on
 // the host and (de)tiled there --------------------------------------------------------
 

@@ -165,6 +165,8 @@ hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevStat
                             float* actions, float* obs, float* reward, uint8_t* term,
                             uint8_t* trunc, int policy, const PidConst* pid, double* pid_state,
                             uint32_t pid_stride, hipStream_t stream);
+hipError_t launch_export_state(int mode, const DevConst& c, const DevState& s, float* x, uint8_t* status,
+                               int32_t* steps, hipStream_t stream);
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,
                              hipStream_t stream);
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,

@@ -1264,6 +1264,33 @@ __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, co
 }
 
 // ---------------------------------------------------------------------------------
+// Dynamics.getState() / getStatus() for the batch, on the device: the full 12-slot state as a
+// [12, N] float32 struct-of-arrays (each value = the stored state rounded to float32, i.e. what an
+// observation would carry), flight status and step counter.  Coalesced row stores.
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void export_state_kernel(const DevConst c, const DevState s,
+                                                              float* __restrict__ x_out,
+                                                              uint8_t* __restrict__ status_out,
+                                                              int32_t* __restrict__ steps_out) {
+  using T = typename ModeOf<MODE>::T;
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= s.n) return;
+  const TileIO<MODE> tile(s, i);
+  T raw[12];
+  uint32_t g[3];
+  uint32_t meta;
+  tile.load_state(raw, g, meta);
+  if (x_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      x_out[(size_t)k * s.n + i] = (float)decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
+  }
+  if (status_out != nullptr) status_out[i] = (uint8_t)((meta >> kMetaStatusShift) & 3u);
+  if (steps_out != nullptr) steps_out[i] = (int32_t)(meta & kMetaStepsMask);
+}
+
+// ---------------------------------------------------------------------------------
 // explicit (masked) reset: Lander.reset() for every env with mask[i] != 0
 // ---------------------------------------------------------------------------------
 template <int TASK, int MODE>
@@ -1432,6 +1459,21 @@ hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevStat
                             uint32_t pid_stride, hipStream_t stream) {
   CS_DISPATCH(step_many_t, c, s, num_steps, actions, obs, reward, term, trunc, policy, pid,
               pid_state, pid_stride, stream)
+}
+
+hipError_t launch_export_state(int mode, const DevConst& c, const DevState& s, float* x, uint8_t* status,
+                               int32_t* steps, hipStream_t stream) {
+  const dim3 grid(grid_for(s.n)), block(kBlock);
+#define CS_LAUNCH(MODE)                                                                         \
+  if (mode == MODE) {                                                                           \
+    hipLaunchKernelGGL((export_state_kernel<MODE>), grid, block, 0, stream, c, s, x, status, steps); \
+    return hipGetLastError();                                                                   \
+  }
+  CS_LAUNCH(CS_STATE_F32G)
+  CS_LAUNCH(CS_STATE_F32_RN)
+  CS_LAUNCH(CS_STATE_F64)
+#undef CS_LAUNCH
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,

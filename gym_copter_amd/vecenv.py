@@ -443,6 +443,24 @@ class CopterVecEnv:
             _lib.check(self._lib.cs_set_motors(self._ctx, C.c_void_p(m.data_ptr()), self._stream()))
         self._keep = m
 
+    def state_tensors(self):
+        """Dynamics.getState() / getStatus() for the batch as DEVICE tensors, asynchronous on the
+        current stream: {'x': float32 [12, N] (upstream slot order, incl. psi / dpsi), 'status':
+        uint8 [N], 'steps': int32 [N]}.  The tensors are persistent buffers of this env."""
+        self._check_open()
+        torch = _torch()
+        if getattr(self, "_state_t", None) is None:
+            n = self.num_envs
+            self._state_t = {"x": torch.empty((12, n), dtype=torch.float32, device=self.device),
+                             "status": torch.empty(n, dtype=torch.uint8, device=self.device),
+                             "steps": torch.empty(n, dtype=torch.int32, device=self.device)}
+        t = self._state_t
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_export_state(self._ctx, C.c_void_p(t["x"].data_ptr()),
+                                                 C.c_void_p(t["status"].data_ptr()),
+                                                 C.c_void_p(t["steps"].data_ptr()), self._stream()))
+        return t
+
     def get_state(self):
         """Whole-batch state as NumPy (synchronises): dict with x[12,N] f64, status, steps,
         prev_shaping (NaN = None), force[3,N] newtons, flags, (episode_return)."""

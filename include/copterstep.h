@@ -20,6 +20,7 @@
  *   cs_step_many             K x _Task.step in one launch       envs/task.py:77-137 (lander.py:40-65 loop)
  *   cs_set_motors            Dynamics.setMotors (used directly) dynamics/__init__.py:114-197
  *   cs_get_state             Dynamics.getState / getStatus      dynamics/__init__.py:199-207,223-225
+ *   cs_export_state          the same, to device tensors        dynamics/__init__.py:199-207,223-225
  *   cs_set_state             Dynamics.setState / perturb        dynamics/__init__.py:210-217,227-229
  *   cs_set_altitude          _Task.set_altitude                 envs/task.py:67-69
  *   cs_obs_dim/cs_action_dim observation_space / action_space   envs/task.py:46-55 (attic variants: lander2d.py:43-50 ...)
@@ -239,6 +240,12 @@ int cs_set_vehicle_params(cs_ctx* ctx, const double* params_host);
 /* Physics only: `substeps` x Dynamics.setMotors(motors[i]) on every env, raw motor
  * values (no clipping, no task logic). */
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream);
+
+/* Dynamics.getState() / getStatus() (dynamics/__init__.py:199-207, :223-225) for the batch, on the
+ * DEVICE and asynchronous (enqueue only, graph-capturable): x_dev [12,N] float32 struct-of-arrays in
+ * upstream slot order (the full state, incl. psi / dpsi, which the Lander observation omits),
+ * status_dev [N] (CS_STATUS_*), steps_dev [N].  Each pointer may be NULL. */
+int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, void* stream);
 
 /* Whole-batch state exchange with HOST buffers (parity tests, checkpoint/restore).
  * Any pointer may be NULL.  x_host is [12,N] float64 struct-of-arrays in upstream slot

@@ -1076,3 +1076,23 @@ def test_streaming_instantiation_matches_k_step_kernel(mode):
         assert np.array_equal(ss[key], sm[key], equal_nan=True), key
     single.close()
     many.close()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_export_state_on_device(mode):
+    """cs_export_state (Dynamics.getState / getStatus as device tensors) agrees with the host-side
+    cs_get_state and with the observation the step returned."""
+    rng = np.random.default_rng(2)
+    n = 3001
+    env, _ = make_pair("lander3d", n, mode, autoreset="next_step", seed=4)
+    env.reset()
+    import torch
+    for t in range(12):
+        obs, *_ = env.step(torch.from_numpy(rng.uniform(-1, 1, (n, 4)).astype(np.float32)).to(env.device))
+    st, dev = env.get_state(), env.state_tensors()
+    with np.errstate(over="ignore"):
+        assert np.array_equal(to_np(dev["x"]), st["x"].astype(np.float32))
+    assert np.array_equal(to_np(dev["status"]), st["status"]) and np.array_equal(to_np(dev["steps"]), st["steps"])
+    live = (st["flags"] & 2) == 0             # envs waiting for their reset return the finished state's observation too
+    assert np.array_equal(to_np(dev["x"])[:10].T[live], to_np(obs)[live])
+    env.close()
