@@ -193,18 +193,29 @@ class TaskOracle:
         self.body = None
 
     # -- reset (task.py:145-197) ------------------------------------------
-    def reset(self, force_xyz=None, rng=None):
+    def reset(self, force_xyz=None, rng=None, pose=None, perturb=True):
+        """pose = (x, y, altitude, phi_deg, theta_deg) and perturb: _Task._reset's keywords
+        (task.py:145, :149-150, :163-170, :176)."""
         tp = self.tp
         self.prev_shaping = None
         self.body = RigidBody(self.vp, tp.frames_per_second * self.substeps, self.g)
+        if pose is None:
+            pose = (0, 0, tp.initial_altitude, 0, 0)
         x0 = np.zeros(12)
-        x0[Z] = -tp.initial_altitude
+        x0[X] = pose[0]
+        x0[Y] = pose[1]
+        x0[Z] = -pose[2]
+        x0[PHI] = np.radians(pose[3])
+        x0[THETA] = np.radians(pose[4])
         self.body.set_state(x0)
-        if force_xyz is None:
+        if not perturb:
+            force_xyz = [0, 0, 0]
+        elif force_xyz is None:
             draw = (rng or np.random).uniform
             force_xyz = [draw(-tp.initial_random_force, +tp.initial_random_force) for _ in range(3)]
         self.force = np.array([force_xyz[0], force_xyz[1], force_xyz[2], 0, 0, 0], dtype=np.float64)
-        self.body.perturb(self.force)
+        if perturb:
+            self.body.perturb(self.force)
         self.steps = 0
         return self.step(np.zeros(4), initializing=True)[0]
 

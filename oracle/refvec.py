@@ -222,22 +222,32 @@ class VecOracle:
         pend[active & ~contact] = False
 
     # ------------------------------------------------------------------ reset
-    def _reset_lanes(self, m, forces=None):
+    def _reset_lanes(self, m, forces=None, poses=None, perturb=True):
         """Masked reset (task.py:145-197): state, status, perturbation, the
-        'initializing' step's shaping, steps = 1."""
+        'initializing' step's shaping, steps = 1.  poses [5, n] = (x, y, altitude, phi_deg,
+        theta_deg) per env and perturb: _Task._reset's keywords."""
         tp = self.tp
         if not np.any(m):
             return
         self.x[:, m] = 0
-        self.x[4, m] = self.T.type(-tp.initial_altitude)
-        self.status[m] = AIRBORNE if -tp.initial_altitude < 0 else LANDED
-        if forces is None:
+        if poses is None:
+            self.x[4, m] = self.T.type(-tp.initial_altitude)
+        else:
+            p = np.asarray(poses, dtype=np.float64)[:, m]
+            x0 = np.zeros((12, p.shape[1]))
+            x0[0], x0[2], x0[4] = p[0], p[1], -p[2]
+            x0[6], x0[8] = np.radians(p[3]), np.radians(p[4])
+            self.x[:, m] = self._round(x0)
+        self.status[m] = np.where(self.x[4, m].astype(np.float64) < 0, AIRBORNE, LANDED)
+        if not perturb:
+            f = np.zeros((3, int(np.sum(m))))
+        elif forces is None:
             f = draw_forces(self.seed, self.env_ids[m], self.episode[m], tp.initial_random_force)
         else:
             f = np.asarray(forces, dtype=np.float64)[:, m]
         self.force[:, m] = f.astype(self.T)
         self.episode[m] += np.uint32(1)
-        self.pending[m] = True
+        self.pending[m] = bool(perturb)
         self.done_pending[m] = False
         xs = self.x[:, m].astype(np.float64)
         if self.kind == "lander":
@@ -248,12 +258,12 @@ class VecOracle:
         self.ep_return[m] = 0
         self.ep_length[m] = 0
 
-    def reset(self, mask=None, forces=None, seed=None):
+    def reset(self, mask=None, forces=None, seed=None, poses=None, perturb=True):
         """Reset all lanes (mask None) or lanes with mask[i] != 0.  Returns obs [n, obs_dim] f32."""
         if seed is not None:
             self.seed = int(seed)
         m = np.ones(self.n, dtype=bool) if mask is None else np.asarray(mask).astype(bool)
-        self._reset_lanes(m, forces)
+        self._reset_lanes(m, forces, poses, perturb)
         return self.observe()
 
     def observe(self):

@@ -205,7 +205,8 @@ def d_series(Dynamics, vp):
 # --------------------------------------------------------------------------
 # E-series: env-level traces
 # --------------------------------------------------------------------------
-def run_env(env, actions, seed, altitude=None, extra_after_done=25, action_dtype=np.float64):
+def run_env(env, actions, seed, altitude=None, extra_after_done=25, action_dtype=np.float64, pose=None,
+            perturb=True):
     """Drive env.reset() + env.step() with the recorded actions.
 
     The drawn perturbation force is rounded to float32 and re-installed before
@@ -215,11 +216,15 @@ def run_env(env, actions, seed, altitude=None, extra_after_done=25, action_dtype
     if altitude is not None:
         env.set_altitude(altitude)
     np.random.seed(seed)
-    obs0, _ = env.reset()
+    if pose is None:
+        obs0, _ = env.reset()
+    else:      # _Task._reset(pose=(x, y, altitude, phi_deg, theta_deg), perturb=...), as lander.py:85 uses it
+        obs0, _ = env._reset(pose=tuple(float(v) for v in pose), perturb=perturb)
     d = env.dynamics
     force = f32r(d._perturb * d.M)
     d.perturb(force.copy())
     rec = dict(obs=[], reward=[], done=[], status=[], steps=[], prev_shaping=[], x=[])
+    x0 = d._x.copy()
     T = actions.shape[0]
     first_done = -1
     t = 0
@@ -247,6 +252,8 @@ def run_env(env, actions, seed, altitude=None, extra_after_done=25, action_dtype
         force=force[:3], actions=actions[:n].astype(np.float64),
         action_is_f32=np.bool_(action_dtype == np.float32),
         obs0=np.asarray(obs0, dtype=np.float32), first_done=np.int64(first_done),
+        pose=np.asarray(pose if pose is not None else [0, 0, env.initial_altitude, 0, 0], dtype=np.float64),
+        perturb=np.bool_(perturb), x0=np.asarray(x0),
         obs=np.asarray(rec["obs"], dtype=np.float32), reward=np.asarray(rec["reward"]),
         done=np.asarray(rec["done"]), status=np.asarray(rec["status"], dtype=np.int8),
         steps=np.asarray(rec["steps"], dtype=np.int64),
@@ -318,6 +325,28 @@ def e_series(_Task, Lander, vp):
     cases["E22_hover_soft_landing"] = run_env(HoverRef(), f32r(1.6e-2) * ones, seed=11, altitude=0.05)
     cases["E23_hover_noisy"] = run_env(
         HoverRef(), f32r(hov * (1 + 0.01 * rng.standard_normal((T, 4)))), seed=12)
+    return cases
+
+
+def r_series(_Task, Lander, vp):
+    """Resets to a pose: _Task._reset(pose=(x, y, altitude, phi_deg, theta_deg), perturb=...)
+    (task.py:145-188; lander.py:85 is upstream's caller), then ordinary steps."""
+    rng = np.random.default_rng(515)
+    hov = hover_motor(vp)
+    HoverRef = make_hover_ref(_Task)
+    T = 400
+    ones = np.ones((T, 4))
+    noisy = lambda: f32r(hov * (1 + 0.01 * rng.standard_normal((T, 4))))
+    cases = {}
+    cases["R01_pose_offset_tilted"] = run_env(Lander(), noisy(), seed=80, pose=(3.0, -2.5, 8.0, 10.0, -5.0))
+    cases["R02_pose_no_perturb"] = run_env(Lander(), f32r(hov) * ones, seed=81, pose=(-4.0, 1.5, 6.0, -12.0, 20.0),
+                                           perturb=False)
+    cases["R03_pose_on_ground"] = run_env(Lander(), f32r(1.8e-2) * ones, seed=82, pose=(1.0, 1.0, 0.0, 0.0, 0.0))
+    cases["R04_pose_near_limit"] = run_env(Lander(), noisy(), seed=83, pose=(9.5, -9.0, 12.0, 40.0, 0.0), perturb=False)
+    cases["R05_pose_past_tilt_limit"] = run_env(Lander(), noisy(), seed=84, pose=(0.0, 0.0, 5.0, 50.0, 0.0))
+    cases["R06_hover_pose"] = run_env(HoverRef(), noisy(), seed=85, pose=(2.0, 2.0, 4.0, 5.0, 5.0))
+    cases["R07_pose_low_descent"] = run_env(Lander(), f32r(1.6e-2) * ones, seed=86, pose=(0.5, -0.5, 0.25, 0.0, 0.0),
+                                            perturb=False)
     return cases
 
 
@@ -434,6 +463,7 @@ def main():
     save("pid_traces.npz", p_series(Lander, load_mars_pid(), make_hover_ref(_Task)))
     save("variant_traces.npz", v_series(_Task, Lander, vp))
     save("vehicle_traces.npz", w_series(Dynamics, Lander, vp))
+    save("pose_traces.npz", r_series(_Task, Lander, vp))
     # known-answer constants observed from the reference (used as spot checks)
     meta = dict(numpy_version=np.array(np.__version__), hover_motor=np.float64(hover_motor(vp)))
     np.savez(os.path.join(OUT, "meta.npz"), **meta)

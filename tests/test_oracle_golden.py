@@ -121,3 +121,20 @@ def test_other_vehicles_and_worlds_bit_exact(name):
         obs, r, done, _, _ = o.step(a)
         assert np.array_equal(obs, g["obs"][t]) and r == g["reward"][t] and done == g["done"][t], (name, t)
         assert o.body.status == g["status"][t] and np.array_equal(o.body.x, g["x"][t]), (name, t)
+
+
+POSE = load_cases("pose_traces.npz")
+
+
+@pytest.mark.parametrize("name", POSE.names())
+def test_pose_reset_bit_exact(name):
+    """_Task._reset(pose=..., perturb=...) then ordinary steps: scalar oracle vs the reference."""
+    g = POSE[name]
+    o = TaskOracle(str(g["task"]))
+    obs0 = o.reset(force_xyz=g["force"], pose=g["pose"], perturb=bool(g["perturb"]))
+    assert np.array_equal(obs0, g["obs0"]) and np.array_equal(o.body.x, g["x0"])
+    for t, a in enumerate(g["actions"]):
+        obs, r, done, _, _ = o.step(a)
+        assert np.array_equal(obs, g["obs"][t]) and r == g["reward"][t] and done == g["done"][t], (name, t)
+        assert o.body.status == g["status"][t] and o.steps == g["steps"][t], (name, t)
+        assert np.array_equal(o.body.x, g["x"][t]), (name, t)

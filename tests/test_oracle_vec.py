@@ -289,3 +289,33 @@ def test_draw_actions_spec():
     # known answer (first env, seed 1234, episode 1, step 1), pinned when the spec was written
     k = draw_actions(1234, [0], 1, 1)[0]
     assert np.array_equal(k, np.float32(KNOWN_ACTION)), k.tolist()
+
+
+def test_vec_pose_resets_bit_exact_in_batch():
+    """All pose-reset golden episodes of a task as one batch (per-env poses; with / without perturbation)."""
+    from conftest import load_cases
+    POSE = load_cases("pose_traces.npz")
+    for task in ("lander3d", "hover3d"):
+        for perturb in (True, False):
+            cs = [c for c in POSE.names() if str(POSE[c]["task"]) == task and bool(POSE[c]["perturb"]) == perturb]
+            if not cs:
+                continue
+            n = len(cs)
+            poses = np.stack([POSE[c]["pose"] for c in cs], axis=1)
+            forces = np.stack([POSE[c]["force"] for c in cs], axis=1)
+            o = VecOracle(task, n)
+            obs0 = o.reset(forces=forces, poses=poses, perturb=perturb)
+            T = max(len(POSE[c]["reward"]) for c in cs)
+            acts = np.zeros((T, n, 4))
+            for i, c in enumerate(cs):
+                assert np.array_equal(obs0[i], POSE[c]["obs0"]), c
+                acts[:len(POSE[c]["actions"]), i] = POSE[c]["actions"]
+            for t in range(T):
+                with np.errstate(all="ignore"):
+                    obs, r, term, _ = o.step(acts[t])
+                for i, c in enumerate(cs):
+                    g = POSE[c]
+                    if t < len(g["reward"]):
+                        assert np.array_equal(obs[i], g["obs"][t]) and r[i] == g["reward"][t], (c, t)
+                        assert term[i] == g["done"][t] and o.status[i] == g["status"][t], (c, t)
+                        assert np.array_equal(o.x[:, i], g["x"][t]), (c, t)
