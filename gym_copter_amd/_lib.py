@@ -81,6 +81,7 @@ SYMBOLS = {
     "cs_seed": (C.c_int, [_P, C.c_uint64]),
     "cs_set_altitude": (C.c_int, [_P, C.c_double]),
     "cs_reset": (C.c_int, [_P, _P, _P, _P, _P]),
+    "cs_reset_pose": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "cs_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "cs_step_ex": (C.c_int, [_P, C.POINTER(StepIO), _P]),
     "cs_step_many": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),

@@ -275,9 +275,21 @@ int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, f
   if (check_ctx(ctx)) return CS_ERR_ARG;
   const cs::DevConst c = make_const(ctx);
   hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
-                                  force_xyz_dev, obs_dev, ctx->pid_state, ctx->pid_stride,
+                                  force_xyz_dev, obs_dev, ctx->pid_state, ctx->pid_stride, nullptr, 1,
                                   (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_reset: kernel launch");
+  return CS_OK;
+}
+
+int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, int32_t perturb,
+                  const float* force_xyz_dev, float* obs_dev, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (pose_dev == nullptr) return fail(CS_ERR_ARG, "cs_reset_pose: pose_dev is required");
+  const cs::DevConst c = make_const(ctx);
+  hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
+                                  force_xyz_dev, obs_dev, ctx->pid_state, ctx->pid_stride, pose_dev,
+                                  perturb != 0 ? 1 : 0, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_reset_pose: kernel launch");
   return CS_OK;
 }
 

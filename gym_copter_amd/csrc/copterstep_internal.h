@@ -171,6 +171,7 @@ hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, con
                              hipStream_t stream);
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,
                         const uint8_t* mask, const float* force_xyz, float* obs,
-                        double* pid_state, uint32_t pid_stride, hipStream_t stream);
+                        double* pid_state, uint32_t pid_stride, const float* pose, int perturb,
+                        hipStream_t stream);
 
 }  // namespace cs

@@ -1299,7 +1299,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
                                                        const float* __restrict__ force_xyz,
                                                        float* __restrict__ obs,
                                                        double* __restrict__ pid_state,
-                                                       const uint32_t pid_stride) {
+                                                       const uint32_t pid_stride,
+                                                       const float* __restrict__ pose,
+                                                       const int perturb) {
   using T = typename ModeOf<MODE>::T;
   constexpr int OBS = task_obs_dim(TASK);
   const uint32_t n = s.n;
@@ -1313,20 +1315,53 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     }
     double f[3];
     const uint32_t episode = TileIO<MODE>::episode_of(tile.load_fe());
-    if (force_xyz != nullptr) {
+    if (perturb == 0) {  // _reset(perturb=False), task.py:176
+      f[0] = f[1] = f[2] = 0.0;
+    } else if (force_xyz != nullptr) {
       f[0] = (double)force_xyz[0 * (size_t)n + i];
       f[1] = (double)force_xyz[1 * (size_t)n + i];
       f[2] = (double)force_xyz[2 * (size_t)n + i];
     } else {
       draw_force(c, i, episode, f);
     }
-    T xs[12];
+    const uint32_t pend = perturb != 0 ? kMetaPerturbPending : 0u;
+    if (pose == nullptr) {
+      T xs[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) xs[k] = (k == 4) ? (T)c.z0 : (T)0;
-    const uint32_t gs[3] = {0u, 0u, 0u};
-    tile.store_state(xs, gs, 1u | ((uint32_t)c.status0 << kMetaStatusShift) | kMetaPerturbPending);
+      for (int k = 0; k < 12; ++k) xs[k] = (k == 4) ? (T)c.z0 : (T)0;
+      const uint32_t gs[3] = {0u, 0u, 0u};
+      tile.store_state(xs, gs, 1u | ((uint32_t)c.status0 << kMetaStatusShift) | pend);
+      tile.store_prev((T)c.reset_shaping);  // NaN (= None) for Hover3D
+    } else {
+      // _reset(pose=(x, y, altitude, phi_deg, theta_deg)), task.py:163-170: NED z, np.radians
+      double x0[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) x0[k] = 0.0;
+      const double deg = 3.14159265358979323846 / 180.0;
+      x0[0] = (double)pose[0 * (size_t)n + i];
+      x0[2] = (double)pose[1 * (size_t)n + i];
+      x0[4] = -(double)pose[2 * (size_t)n + i];
+      x0[6] = (double)pose[3 * (size_t)n + i] * deg;
+      x0[8] = (double)pose[4 * (size_t)n + i] * deg;
+      T xs[12];
+      uint32_t gs[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const Stored<MODE> w = encode_word<MODE>(x0[k]);
+        xs[k] = w.word;
+        gs[k >> 2] |= w.guard << (8 * (k & 3));
+        x0[k] = w.value;
+      }
+      const uint32_t fs = x0[4] < 0.0 ? CS_STATUS_AIRBORNE : CS_STATUS_LANDED;  // setState, :215-217
+      tile.store_state(xs, gs, 1u | (fs << kMetaStatusShift) | pend);
+      // the 'initializing' step's shaping (task.py:197 -> lander.py:48-57), NaN (= None) for Hover
+      if constexpr (task_is_lander(TASK)) {
+        tile.store_prev((T)lander_shaping(c, x0));
+      } else {
+        tile.store_prev((T)c.reset_shaping);
+      }
+    }
     tile.store_fe(TileIO<MODE>::make_fe(f, episode + 1));
-    tile.store_prev((T)c.reset_shaping);  // NaN (= None) for Hover3D
     tile.store_ret(0.f);
   }
   if (obs != nullptr) {
@@ -1439,10 +1474,11 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
 
 template <int TASK, int MODE>
 hipError_t reset_t(const DevConst& c, const DevState& s, const uint8_t* mask, const float* force_xyz,
-                   float* obs, double* pid_state, uint32_t pid_stride, hipStream_t stream) {
+                   float* obs, double* pid_state, uint32_t pid_stride, const float* pose, int perturb,
+                   hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
   hipLaunchKernelGGL((reset_kernel<TASK, MODE>), grid, block, 0, stream, c, s, mask, force_xyz, obs,
-                     pid_state, pid_stride);
+                     pid_state, pid_stride, pose, perturb);
   return hipGetLastError();
 }
 
@@ -1493,8 +1529,9 @@ hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, con
 
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,
                         const uint8_t* mask, const float* force_xyz, float* obs,
-                        double* pid_state, uint32_t pid_stride, hipStream_t stream) {
-  CS_DISPATCH(reset_t, c, s, mask, force_xyz, obs, pid_state, pid_stride, stream)
+                        double* pid_state, uint32_t pid_stride, const float* pose, int perturb,
+                        hipStream_t stream) {
+  CS_DISPATCH(reset_t, c, s, mask, force_xyz, obs, pid_state, pid_stride, pose, perturb, stream)
 }
 
 }  // namespace cs

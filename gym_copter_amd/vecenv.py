@@ -194,7 +194,9 @@ class CopterVecEnv:
     def reset(self, seed=None, options=None):
         """Reset every env (or options['mask']); returns (obs[N,obs_dim], {}).
 
-        options: {'mask': bool[N], 'forces': float[3,N] newtons (else Philox U[-F,F))}.
+        options: {'mask': bool[N], 'forces': float[3,N] newtons (else Philox U[-F,F)),
+        'pose': float[5,N] or [5] = (x, y, altitude, roll_deg, pitch_deg) and 'perturb': bool --
+        _Task._reset's keywords (task.py:145)}.
         seed re-keys the perturbation stream (the reference draws from global np.random,
         task.py:199-202; here the draw is counter-based on (seed, global env id, episode #))."""
         self._check_open()
@@ -215,10 +217,24 @@ class CopterVecEnv:
         if forces is not None:
             force_t, _ = self._dev_f32(forces, (3, self.num_envs), "forces")
             force_p = C.c_void_p(force_t.data_ptr())
+        pose, perturb = options.get("pose"), bool(options.get("perturb", True))
+        pose_t = None
+        if pose is not None or not perturb:
+            if pose is None:
+                pose = (0.0, 0.0, float(self.config.initial_altitude), 0.0, 0.0)
+            if not isinstance(pose, torch.Tensor):
+                pose = np.asarray(pose, dtype=np.float32)
+                if pose.shape == (5,):
+                    pose = np.repeat(pose[:, None], self.num_envs, axis=1)
+            pose_t, _ = self._dev_f32(pose, (5, self.num_envs), "pose")
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.cs_reset(self._ctx, mask_p, force_p,
-                                          C.c_void_p(self._obs.data_ptr()), self._stream()))
-        self._keep = (mask_t, force_t)      # alive until the stream has consumed them
+            if pose_t is None:
+                _lib.check(self._lib.cs_reset(self._ctx, mask_p, force_p,
+                                              C.c_void_p(self._obs.data_ptr()), self._stream()))
+            else:
+                _lib.check(self._lib.cs_reset_pose(self._ctx, mask_p, C.c_void_p(pose_t.data_ptr()), int(perturb),
+                                                   force_p, C.c_void_p(self._obs.data_ptr()), self._stream()))
+        self._keep = (mask_t, force_t, pose_t)      # alive until the stream has consumed them
         return self._obs, {}
 
     def step(self, actions):

@@ -167,6 +167,14 @@ int cs_set_altitude(cs_ctx* ctx, double altitude);
 int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, float* obs_dev,
              void* stream);
 
+/* Reset to a pose: _Task._reset(pose=(x, y, altitude, phi_deg, theta_deg), perturb=...)
+ * (task.py:145, :163-176; upstream's caller is lander.py:85).  pose_dev: [5,N] float32 rows x, y,
+ * altitude (up positive), roll and pitch in degrees.  perturb = 0 starts without the random force
+ * (force_xyz_dev is then ignored).  Status, step counter and the Lander's initial shaping follow
+ * from the pose exactly as upstream's initializing step computes them. */
+int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, int32_t perturb,
+                  const float* force_xyz_dev, float* obs_dev, void* stream);
+
 int cs_step(cs_ctx* ctx, const float* actions_dev, float* obs_dev, float* reward_dev,
             uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
 int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream);

@@ -1096,3 +1096,76 @@ def test_export_state_on_device(mode):
     live = (st["flags"] & 2) == 0             # envs waiting for their reset return the finished state's observation too
     assert np.array_equal(to_np(dev["x"])[:10].T[live], to_np(obs)[live])
     env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# reset to a pose (cs_reset_pose)
+# ---------------------------------------------------------------------------------------
+POSE = load_cases("pose_traces.npz")
+
+
+@pytest.mark.parametrize("mode", ["float32", "float64"])
+def test_golden_pose_resets(mode):
+    """_Task._reset(pose=..., perturb=...) of the reference, then steps: per-env poses in one device batch."""
+    import torch
+    for task in ("lander3d", "hover3d"):
+        for perturb in (True, False):
+            cs = [c for c in POSE.names() if str(POSE[c]["task"]) == task and bool(POSE[c]["perturb"]) == perturb]
+            if not cs:
+                continue
+            n = len(cs)
+            poses = np.stack([POSE[c]["pose"] for c in cs], axis=1).astype(np.float32)
+            forces = np.stack([POSE[c]["force"] for c in cs], axis=1).astype(np.float32)
+            env, _ = make_pair(task, n, mode)
+            obs0, _ = env.reset(options={"pose": poses, "forces": forces, "perturb": perturb})
+            obs0 = to_np(obs0)
+            st = env.get_state()
+            tol = 1e-9 if mode == "float64" else BAR
+            T = max(len(POSE[c]["reward"]) for c in cs)
+            acts = np.zeros((T, n, 4), dtype=np.float32)
+            for i, c in enumerate(cs):
+                g = POSE[c]
+                assert scaled_err(obs0[i], g["obs0"]) <= (0 if mode == "float64" else 1e-7), c
+                assert scaled_err(st["x"][:, i], g["x0"]) <= (1e-15 if mode == "float64" else 3e-10), c
+                assert st["steps"][i] == 1 and bool(st["flags"][i] & 1) == perturb, c
+                acts[:len(g["actions"]), i] = g["actions"]
+            for t in range(T):
+                obs, r, term, _, _ = env.step(torch.from_numpy(acts[t]).to(env.device))
+                obs, r, term = to_np(obs), to_np(r), to_np(term)
+                for i, c in enumerate(cs):
+                    g = POSE[c]
+                    if t >= len(g["reward"]) or (int(g["first_done"]) >= 0 and t > int(g["first_done"]) + 5):
+                        continue
+                    assert scaled_err(obs[i], g["obs"][t]) <= tol, (c, t, scaled_err(obs[i], g["obs"][t]))
+                    assert bool(term[i]) == bool(g["done"][t]), (c, t)
+                    sh = abs(g["prev_shaping"][t]) if np.isfinite(g["prev_shaping"][t]) else 0.0
+                    r_tol = 5e-5 + 1e-5 * abs(g["reward"][t]) + (1e-12 if mode == "float64" else 6e-7) * sh
+                    assert abs(float(r[i]) - g["reward"][t]) <= r_tol, (c, t)
+            env.close()
+
+
+@pytest.mark.parametrize("task,mode", [("lander3d", "float32"), ("hover3d", "float32_rn"), ("lander2d", "float64")])
+def test_random_pose_resets_match_oracle(task, mode):
+    """Masked resets to random poses (some on the ground, some past the tilt limit), with and without
+    the perturbation, interleaved with steps: device vs oracle, state for state."""
+    rng = np.random.default_rng(77)
+    n = 1500
+    env, orc = make_pair(task, n, mode, autoreset="disabled", seed=12)
+    env.reset()
+    orc.reset()
+    A = env.action_dim
+    for rnd in range(4):
+        poses = np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), rng.uniform(0, 12, n),
+                          rng.uniform(-50, 50, n), rng.uniform(-50, 50, n)]).astype(np.float32)
+        poses[2, ::7] = 0.0                         # on the ground
+        mask = rng.random(n) < 0.6
+        perturb = rnd % 2 == 0
+        obs, _ = env.reset(options={"pose": poses, "mask": mask, "perturb": perturb})
+        want = orc.reset(mask=mask, poses=poses.astype(np.float64), perturb=perturb)
+        assert scaled_err(to_np(obs), want) <= (1e-7 if mode != "float64" else 0)
+        assert_state_close(env, orc, max(MODE_TOL[mode], 1e-7))
+        for t in range(6):
+            a = (HOVER * (1 + 0.2 * rng.standard_normal((n, A)))).astype(np.float32)
+            got, want, _ = step_both(env, orc, a)
+            assert_step_close(got, want, max(MODE_TOL[mode], 2e-6), r_abs=2e-3, r_rel=2e-6, ctx=(rnd, t))
+    env.close()
