@@ -37,12 +37,12 @@ for sub, label in (("trace", "bench default command, 65 536 envs"), ("trace_4m",
             print("   bench.py's own HIP-event launch time in this (profiled) run: %s us" % m.group(1))
 
 
-def counters(sub):
+def counters(sub, kernel="step_kernel"):
     f = find(sub, "*counter_collection.csv")
     acc = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f)):
-            if "step_kernel" in r["Kernel_Name"]:
+            if kernel in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
@@ -69,4 +69,20 @@ for sub in ("sq1", "sq2", "l2"):
     for k, v in sorted(c.items()):
         print("%-24s %14.1f" % (k, v))
     res.update({"pmc_" + k: v for k, v in c.items()})
+
+# the K-step kernels of the same runs (bench.py extras): executed instructions per wavefront and env-step
+print("\n== PMC, K-step kernels: per wavefront and env-step ==")
+res["pmc_k_step"] = {}
+for name, label, k in (("step_many_kernel<0, 0, true, 0>", "open loop", 64),
+                       ("step_many_kernel<0, 0, true, 1>", "PID policy", 100),
+                       ("step_many_kernel<0, 0, true, 2>", "random policy", 100)):
+    m = {}
+    for sub in ("sq1", "sq2"):
+        m.update(counters(sub, name))
+    if m.get("SQ_WAVES"):
+        per = {c: m[c] / m["SQ_WAVES"] / k for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD",
+                                                    "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES") if c in m}
+        res["pmc_k_step"][name] = per
+        print("%-14s (%3d steps/launch): " % (label, k) +
+              "  ".join("%s %.1f" % (c.replace("SQ_INSTS_", "").replace("SQ_", ""), v) for c, v in per.items()))
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
