@@ -33,7 +33,8 @@
  *   - Every function returns CS_OK (0) or a negative cs_status; cs_last_error() then
  *     holds a thread-local message.  Nothing throws across this boundary.
  *   - A context owns all of its device allocations (freed by cs_destroy) and belongs to
- *     ONE HIP device.  Pointers named *_dev are device pointers owned by the caller;
+ *     ONE HIP device (cs_config.device); the caller keeps that device current for the
+ *     calls that enqueue work, as with any stream-ordered HIP library.  Pointers named *_dev are device pointers owned by the caller;
  *     pointers named *_host are host pointers.
  *   - cs_reset / cs_step / cs_step_ex / cs_step_many / cs_rollout_* / cs_set_motors only
  *     ENQUEUE work on `stream` (a hipStream_t, NULL = the null stream) and return; the
