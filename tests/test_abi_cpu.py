@@ -65,6 +65,19 @@ def test_argument_errors_without_touching_a_device():
     cfg.substeps = 0
     assert lib.cs_create(C.byref(cfg), C.byref(ctx)) == -1
     assert lib.cs_step(None, None, None, None, None, None, None) == -1
+    # every entry point that takes a context refuses a null one with CS_ERR_ARG and a message
+    assert lib.cs_step_many(None, 4, None, None, None, None, None, None) == -1
+    assert lib.cs_rollout_pid(None, 4, None, None, None, None, None, None) == -1
+    assert lib.cs_rollout_random(None, 4, None, None, None, None, None, None) == -1
+    assert lib.cs_reset(None, None, None, None, None) == -1
+    assert lib.cs_reset_pose(None, None, None, 1, None, None, None) == -1
+    assert lib.cs_export_state(None, None, None, None, None) == -1
+    assert lib.cs_set_vehicle_params(None, None) == -1
+    assert lib.cs_pid_configure(None, None) == -1
+    assert lib.cs_last_error().decode() != ""
+    g = _lib.PidGains()
+    assert lib.cs_pid_gains_init(C.byref(g)) == 0 and g.struct_size == C.sizeof(g)
+    assert (g.rate_kp, g.rate_kd, g.pos_ki, g.descent_kp, g.alt_ki, g.alt_target) == (1.0, 1.0, 0.1, 1.15, 3.0, 5.0)
     assert lib.cs_destroy(None) == 0
 
 
