@@ -6,13 +6,27 @@ the batch) over one batch of synthetic actions that is already resident in HBM. 
 workload = BASELINE.json configs[1]: Lander3D, 65 536 envs, uniform random actions in
 [-1,1)^4, auto-reset on (NEXT_STEP), float32 state words, one GPU.
 
-  python bench.py --gpus 1 --steps K --warmup W
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N = 1: runs in this process.
+      N > 1 without a torch.distributed environment: this process starts the N ranks itself
+             (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1)
+             BEFORE it touches the GPU, relays their output and exits with their code.
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
-Rank 0 prints ONE JSON line (see the task contract): value = whole-job env-steps/s =
-N_gpus * envs_per_gpu * K / max-over-ranks wall time of the K timed steps, plus
+How the K steps are timed.  The K steps are captured as one hipGraph (chunks of at most
+--graph-chunk launches).  A timed REGION is R back-to-back passes of those K steps, bracketed by
+barrier + torch.cuda.synchronize() on both sides and timed with the host clock; R ("repeats") is
+chosen so that a region holds >= --min-region-ms of GPU work (a single 20-step pass is 0.1 ms:
+graph-launch and synchronisation overhead would be a third of it).  --regions such regions are timed,
+each reduced with MAX over ranks; the MEDIAN region gives ms_per_step = wall / (R * K) and
+value = total envs * R * K / wall.  `single_pass` reports the bare K-step pass for comparison.
+
+Rank 0 prints ONE JSON line (see the task contract) with, besides the contract keys,
   roofline     : algorithmic bytes (176 B/env-step) per launch over the
                  launch duration measured with HIP events on the launch stream, vs 8 TB/s
+  sweep        : the same kernel at the other single-GPU sizes / tasks (Lander3D and Hover3D at
+                 262 144 = BASELINE configs[2], 1 M and 4 M envs), each with launch_us and frac
+  config5      : BASELINE configs[4] (dt = 1e-3, 10 substeps) with BOTH bounds, HBM and f64 vector ALU
   cpu_baseline : the scalar NumPy port of the reference (oracle/refcpu.py), timed here on
                  the host, 1 core, bounded sample (a reported baseline, not a target); beside
                  it the other action law, all host cores (one process and env each) and the
@@ -22,11 +36,13 @@ envs: step_many (open loop over the resident action ring), rollout_pid (closed l
 on-device PID heuristic), rollout_random (actions drawn on device).
 Multi-GPU: the env batch is sharded by contiguous env-id range with no data-path
 collective in the timed region ("scaling": "weak"); the optional concatenated-observation
-all-gather over RCCL is timed separately and reported as value_with_allgather.
+all-gather over RCCL (--gather) is timed separately and reported as value_with_allgather.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -35,10 +51,18 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {"lander3d": 176, "hover3d": 176}
 HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# MI355X_MICROARCH.md: peak FP32 vector 157.3 TFLOP/s; float64 vector FMA issues at half that rate
+F64_VALU_PEAK_TFLOPS = 78.6
 HOVER = 0.016560178185018043                        # motor value with thrust == weight
+# float64 operations of one env step as the kernel evaluates it: per
+# Dynamics.setMotors call 3 sin/cos pairs (2 x 6 fused multiply-adds each + reduction), the body-Z
+# rotation, the state derivative and 12 Euler updates; once per step the motor model, the stored-word
+# rounding and the reward.  An FMA counts as 2.
+FLOPS_PER_SUBSTEP = 3 * 34 + 18 + 14 + 24
+FLOPS_PER_STEP_FIXED = 32 + 40 + 36
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2000)
@@ -51,17 +75,54 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--graph-chunk", type=int, default=100)
     p.add_argument("--ring", type=int, default=64, help="resident action batches cycled through")
+    p.add_argument("--prefetch", type=int, default=0,
+                   help="1 = hand the kernel the NEXT action batch of the ring as well (cs_step_io.next_actions_dev)")
+    p.add_argument("--min-region-ms", type=float, default=50.0, help="GPU work per timed region")
+    p.add_argument("--regions", type=int, default=5, help="timed regions (the median is reported)")
     p.add_argument("--gather", action="store_true", help="also time with the RCCL obs all-gather")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--no-sweep", action="store_true", help="skip the batch-size / task sweep and config 5")
     p.add_argument("--pid", type=int, default=100,
-                   help="also time cs_rollout_pid (closed loop, on-device PID heuristic) with this many "
-                        "steps per launch (0 = skip)")
+                   help="also time cs_rollout_pid / cs_rollout_random with this many steps per launch (0 = skip)")
     p.add_argument("--many", type=int, default=100,
                    help="also time cs_step_many with this many steps per launch (0 = skip)")
-    return p.parse_args()
+    p.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
+    return p.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, before anything touches the GPU
+# ------------------------------------------------------------------------------------------
+def needs_self_launch(gpus, environ):
+    """True when --gpus N > 1 was asked of a process that no launcher has given a rank."""
+    return gpus > 1 and "WORLD_SIZE" not in environ and "RANK" not in environ
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(gpus, argv, port=0, python=None):
+    """The command that runs this script as `gpus` ranks of one node (one per GPU, RCCL)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(a, argv):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = launcher_command(a.gpus, argv, a.master_port)
+    print("bench.py: starting %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)       # a child process: this one never initialises the GPU
+
+
+# ------------------------------------------------------------------------------------------
 def make_actions(torch, law, ring, n, device, seed):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -76,12 +137,13 @@ class Stepper:
     """Runs `count` consecutive env steps, as hipGraph replays of `chunk` captured
     launches plus eager launches for the remainder."""
 
-    def __init__(self, torch, env, actions, use_graph, chunk, post=None):
+    def __init__(self, torch, env, actions, use_graph, chunk, post=None, prefetch=True):
         self.torch, self.env, self.actions, self.post = torch, env, actions, post
         self.ring = actions.shape[0]
         self.pos = 0
         self.graph = None
         self.chunk = chunk
+        self.prefetch = prefetch and self.ring > 1 and hasattr(env, "step_prefetch")
         if use_graph:
             s = torch.cuda.Stream(device=env.device)
             s.wait_stream(torch.cuda.current_stream(env.device))
@@ -95,7 +157,10 @@ class Stepper:
                     self._one(j)
 
     def _one(self, j):
-        self.env.step(self.actions[j % self.ring])
+        if self.prefetch:   # the open-loop workload knows the next batch: let the kernel pull it towards its L2
+            self.env.step_prefetch(self.actions[j % self.ring], self.actions[(j + 1) % self.ring])
+        else:
+            self.env.step(self.actions[j % self.ring])
         if self.post is not None:
             self.post()
 
@@ -109,6 +174,62 @@ class Stepper:
             self._one(self.pos)
             self.pos += 1
             done += 1
+
+
+class Timer:
+    """barrier + synchronize on both sides of a region; host clock for the wall time (MAX over
+    ranks), HIP events on the launch stream for the device time of the same region."""
+
+    def __init__(self, torch, dist, device):
+        self.torch, self.dist, self.device = torch, dist, device
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def region(self, runner, count):
+        torch = self.torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        runner.run(count)
+        ev1.record()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        self.barrier()
+        wall = t1 - t0
+        if self.dist is not None:
+            t = torch.tensor([wall], device=self.device, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall, ev0.elapsed_time(ev1) * 1e-3
+
+    def measure(self, runner, steps, warmup, min_region_s, regions, quantum=1):
+        """-> dict: the median of `regions` timed regions of R * steps steps each (R chosen so that
+        a region holds >= min_region_s of GPU work), and the bare single pass of `steps` steps."""
+        steps = max(quantum, steps // quantum * quantum)
+        if warmup > 0:
+            runner.run(max(quantum, warmup // quantum * quantum))
+        w1, e1 = self.region(runner, steps)                       # also the calibration pass
+        if self.dist is not None:                                 # every rank must pick the same R
+            t = self.torch.tensor([e1], device=self.device, dtype=self.torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            e1 = float(t.item())
+        reps = max(1, int(min_region_s / max(e1, 1e-9) + 0.999))
+        walls, evs = [], []
+        for _ in range(max(1, regions)):
+            w, e = self.region(runner, steps * reps)
+            walls.append(w)
+            evs.append(e)
+        k = sorted(range(len(walls)), key=lambda i: walls[i])[len(walls) // 2]     # the median region
+        total = steps * reps
+        return {"steps": steps, "repeats": reps, "regions": len(walls), "wall_s": walls[k],
+                "s_per_step": walls[k] / total, "launch_s": evs[k] / total,
+                "launch_s_best": min(evs) / total,
+                "single_pass": {"steps": steps, "wall_ms": w1 * 1e3, "ms_per_step": w1 / steps * 1e3,
+                                "note": "one bare K-step pass incl. graph-launch + synchronisation overhead"}}
 
 
 def _cpu_model():
@@ -152,7 +273,7 @@ def cpu_baseline(task, law, seconds):
     """Scalar NumPy port of the reference (one env per object, same NumPy call structure):
     one core, bounded sample; the same on every host core at once (one process per core, each
     stepping its own env); plus the vectorised NumPy oracle as an extra row.  Runs BEFORE the
-    process touches the GPU, so that forking the workers is safe."""
+    process touches the GPU or RCCL, so that forking the workers is safe."""
     import numpy as np
     from oracle.refvec import VecOracle
     rng = np.random.default_rng(0)
@@ -194,165 +315,197 @@ def cpu_baseline(task, law, seconds):
                                  "sample": "oracle/refvec.py VecOracle, %d envs x %d steps" % (nv, k)}}
 
 
-def main():
-    a = parse()
-    import torch
+def roofline_block(task, n, launch_s, state, traffic=None, traffic_source=None):
+    achieved = ALGO_BYTES[task] * n / launch_s / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "step_kernel<%s,%s>" % (task, state), "launch_us": launch_s * 1e6,
+            "algorithmic_bytes_per_launch": ALGO_BYTES[task] * n}
+
+
+def run_config(torch, timer, gca, a, task, n, law, substeps, device, rank, steps, warmup, ring, min_region_s,
+               regions, use_graph=True, prefetch=True):
+    """One (task, batch, action law) point of the sweep: own env, own action ring, own graph."""
+    env = gca.CopterVecEnv(task=task, num_envs=n, device=device.index, seed=1234,
+                           autoreset_mode="next_step", state_dtype=a.state, substeps=substeps,
+                           env_id_base=rank * n)
+    actions = make_actions(torch, law, ring, n, device, 1234 + rank)
+    env.reset()
+    chunk = min(a.graph_chunk, max(1, steps))
+    st = Stepper(torch, env, actions, use_graph, chunk, prefetch=prefetch)
+    m = timer.measure(st, steps, warmup, min_region_s, regions, quantum=chunk if use_graph else 1)
+    env.close()
+    del st, actions, env
+    torch.cuda.empty_cache()
+    return m
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if needs_self_launch(a.gpus, os.environ):
+        sys.exit(self_launch(a, argv))
+
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if a.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # before torch.cuda / RCCL are initialised in this process (the baseline forks workers)
+        cpu = cpu_baseline(a.task, a.actions, a.cpu_seconds)
+
+    import torch
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.task, a.actions, a.cpu_seconds)      # before any HIP call (forks workers)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
 
-    import gym_copter_amd
+    import gym_copter_amd as gca
+    timer = Timer(torch, dist, device)
     n = a.envs
-    env = gym_copter_amd.CopterVecEnv(task=a.task, num_envs=n, device=local, seed=1234,
-                                      autoreset_mode="next_step", state_dtype=a.state,
-                                      substeps=a.substeps, env_id_base=rank * n)
+    min_region_s = a.min_region_ms * 1e-3
+    env = gca.CopterVecEnv(task=a.task, num_envs=n, device=local, seed=1234,
+                           autoreset_mode="next_step", state_dtype=a.state,
+                           substeps=a.substeps, env_id_base=rank * n)
     actions = make_actions(torch, a.actions, a.ring, n, device, 1234 + rank)
     env.reset()
     use_graph = not a.no_graph
     chunk = min(a.graph_chunk, max(1, a.steps))
-    stepper = Stepper(torch, env, actions, use_graph, chunk)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(st, k):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
-        t0 = time.perf_counter()
-        ev0.record()
-        st.run(k)
-        ev1.record()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        barrier()
-        wall = t1 - t0
-        if dist is not None:
-            t = torch.tensor([wall], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            wall = float(t.item())
-        return wall, ev0.elapsed_time(ev1) * 1e-3
-
-    stepper.run(a.warmup)
-    wall, ev_s = timed(stepper, a.steps)
+    stepper = Stepper(torch, env, actions, use_graph, chunk, prefetch=bool(a.prefetch))
+    m = timer.measure(stepper, a.steps, a.warmup, min_region_s, a.regions, quantum=chunk if use_graph else 1)
     total_envs = n * world
-    value = total_envs * a.steps / wall
-    launch_s = ev_s / a.steps                       # HIP events on the launch stream
-    achieved = ALGO_BYTES[a.task] * n / launch_s / 1e9
+    value = total_envs / m["s_per_step"]
 
     extra = {}
     if a.gather and dist is not None:
-        from gym_copter_amd.sharded import ShardGather
+        from gym_copter_amd.sharded import ShardGather, PackedOutputs
         gather = ShardGather(n, world)           # the product's RCCL all-gather of the obs rows
-        post = lambda: gather("obs", env._obs)
-        st2 = Stepper(torch, env, actions, False, chunk, post=post)
-        st2.run(min(a.warmup, 50))
-        w2, _ = timed(st2, a.steps)
-        extra["value_with_allgather"] = total_envs * a.steps / w2
-        extra["ms_per_step_with_allgather"] = w2 / a.steps * 1e3
+
+        def gather_leg(post, bind=None):
+            """step + collective per step, hipGraph-captured like the headline when RCCL allows it."""
+            if bind is not None:
+                bind()
+            mode = "graph"
+            try:
+                st = Stepper(torch, env, actions, use_graph, chunk, post=post, prefetch=bool(a.prefetch))
+            except Exception as e:      # capture of the collective refused: time it eagerly instead
+                torch.cuda.synchronize()
+                mode = "eager (capture failed: %s)" % type(e).__name__
+                st = Stepper(torch, env, actions, False, chunk, post=post, prefetch=bool(a.prefetch))
+            g = timer.measure(st, a.steps, min(a.warmup, 50), min_region_s, a.regions,
+                              quantum=chunk if mode == "graph" else 1)
+            return g, mode
+        g2, mode2 = gather_leg(lambda: gather("obs", env._obs))
+        extra["value_with_allgather"] = total_envs / g2["s_per_step"]
+        extra["ms_per_step_with_allgather"] = g2["s_per_step"] * 1e3
         # everything a global learner needs (obs, reward, both flags) in ONE all-gather: the kernel
         # writes its outputs straight into the packed per-rank buffer
-        from gym_copter_amd.sharded import PackedOutputs
         pk = PackedOutputs(n, env.obs_dim, world, device)
-        env.bind_outputs(pk.obs, pk.reward, pk.term, pk.trunc)
-        st3 = Stepper(torch, env, actions, False, chunk, post=pk.all_gather)
-        st3.run(min(a.warmup, 50))
-        w3, _ = timed(st3, a.steps)
-        extra["value_with_packed_allgather"] = total_envs * a.steps / w3
-        extra["ms_per_step_with_packed_allgather"] = w3 / a.steps * 1e3
+        g3, mode3 = gather_leg(pk.all_gather, bind=lambda: env.bind_outputs(pk.obs, pk.reward, pk.term, pk.trunc))
+        extra["value_with_packed_allgather"] = total_envs / g3["s_per_step"]
+        extra["ms_per_step_with_packed_allgather"] = g3["s_per_step"] * 1e3
+        extra["allgather_launch_mode"] = {"obs": mode2, "packed": mode3}
 
+    def k_step_leg(name, k, call, bytes_step, note):
+        class Runner:
+            def run(self, count):
+                for _ in range(count // k):
+                    call()
+        g = timer.measure(Runner(), max(k, a.steps // k * k), 2 * k, min_region_s, a.regions, quantum=k)
+        extra[name] = {"steps_per_launch": k, "value": total_envs / g["s_per_step"], "unit": "env-steps/s",
+                       "us_per_step": g["launch_s"] * 1e6, "repeats": g["repeats"],
+                       "algorithmic_bytes_per_env_step": bytes_step,
+                       "achieved_GBps": bytes_step * n / g["launch_s"] / 1e9, "note": note}
+
+    od = env.obs_dim
     if a.many > 0:
         # K steps per launch (env state stays in registers): same envs, same resident action ring
         k = min(a.many, actions.shape[0])
         block = actions[:k].contiguous()
-        reps = max(1, a.steps // k)
-
-        class Many:
-            def run(self, count):
-                for _ in range(count // k):
-                    env.step_many(block)
-        m = Many()
-        m.run(2 * k)
-        wm, evm = timed(m, reps * k)
-        per_step = evm / (reps * k)
-        od = env.obs_dim
-        bytes_step = 16 + 4 * od + 4 + 2 + 200.0 / k     # action in; obs, reward, flags out; state once per launch
-        extra["step_many"] = {
-            "steps_per_launch": k, "value": total_envs * reps * k / wm, "unit": "env-steps/s",
-            "us_per_step": per_step * 1e6,
-            "algorithmic_bytes_per_env_step": bytes_step,
-            "achieved_GBps": bytes_step * n / per_step / 1e9,
-            "note": "cs_step_many: bit-identical to K single-step launches "
-                    "(tests/test_gpu_parity.py::test_step_many_is_bit_identical_to_single_steps); "
-                    "open-loop actions only, so it is reported beside, not as, the headline value"}
-
+        k_step_leg("step_many", k, lambda: env.step_many(block), 16 + 4 * od + 4 + 2 + 200.0 / k,
+                   "cs_step_many: bit-identical to K single-step launches "
+                   "(tests/test_gpu_parity.py::test_step_many_is_bit_identical_to_single_steps); "
+                   "open-loop actions only, so it is reported beside, not as, the headline value")
     if a.pid > 0 and a.task == "lander3d":
         # closed loop: K steps per launch with the on-device PID heuristic choosing every action
         k = a.pid
-        reps = max(1, a.steps // k)
         env.configure_pid()
         env.reset()
-
-        class Roll:
-            def run(self, count):
-                for _ in range(count // k):
-                    env.rollout_pid(k)
-        m = Roll()
-        m.run(2 * k)
-        wm, evm = timed(m, reps * k)
-        per_step = evm / (reps * k)
-        od = env.obs_dim
-        bytes_step = 4 * od + 4 + 2 + (200.0 + 384.0) / k   # obs, reward, flags out; env + controller state once per launch
-        extra["rollout_pid"] = {
-            "steps_per_launch": k, "value": total_envs * reps * k / wm, "unit": "env-steps/s",
-            "us_per_step": per_step * 1e6,
-            "algorithmic_bytes_per_env_step": bytes_step,
-            "achieved_GBps": bytes_step * n / per_step / 1e9,
-            "note": "cs_rollout_pid: closed loop, upstream's PID landing heuristic evaluated on device "
-                    "(tests/test_gpu_parity.py::test_rollout_pid_policy_is_bit_exact); episodes under "
-                    "upstream's gains end by tilt after ~130 steps and auto-reset"}
-
+        k_step_leg("rollout_pid", k, lambda: env.rollout_pid(k), 4 * od + 4 + 2 + (200.0 + 384.0) / k,
+                   "cs_rollout_pid: closed loop, upstream's PID landing heuristic evaluated on device "
+                   "(tests/test_gpu_parity.py::test_rollout_pid_policy_is_bit_exact); episodes under "
+                   "upstream's gains end by tilt after ~130 steps and auto-reset")
     if a.pid > 0:
         # random policy on device: the headline's action law with no action tensor, K steps per launch
         k = a.pid
-        reps = max(1, a.steps // k)
         env.reset()
+        k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 200.0 / k,
+                   "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
+                   "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)")
+    env.close()
+    del stepper, env, actions
+    torch.cuda.empty_cache()
 
-        class RollR:
-            def run(self, count):
-                for _ in range(count // k):
-                    env.rollout_random(k)
-        m = RollR()
-        m.run(2 * k)
-        wm, evm = timed(m, reps * k)
-        per_step = evm / (reps * k)
-        bytes_step = 4 * env.obs_dim + 4 + 2 + 200.0 / k
-        extra["rollout_random"] = {
-            "steps_per_launch": k, "value": total_envs * reps * k / wm, "unit": "env-steps/s",
-            "us_per_step": per_step * 1e6, "algorithmic_bytes_per_env_step": bytes_step,
-            "achieved_GBps": bytes_step * n / per_step / 1e9,
-            "note": "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
-                    "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)"}
+    # ---- the same kernel at the other single-GPU points (driver-visible; N = 1 only) ----
+    if not a.no_sweep and world == 1:
+        sweep = []
+        points = [("lander3d", 262144, "uniform", 16), ("lander3d", 262144, "near_hover", 16),
+                  ("hover3d", 262144, "uniform", 16), ("lander3d", 1048576, "uniform", 8),
+                  ("hover3d", 1048576, "uniform", 8), ("lander3d", 4194304, "uniform", 4),
+                  ("hover3d", 4194304, "uniform", 4)]
+        for task, nn, law, ring in points:
+            if (task, nn, law) == (a.task, n, a.actions):
+                continue
+            try:
+                g = run_config(torch, timer, gca, a, task, nn, law, 1, device, rank, 100, 100, ring,
+                               min_region_s, 3, prefetch=bool(a.prefetch))
+                r = roofline_block(task, nn, g["launch_s"], a.state)
+                sweep.append({"task": task, "envs": nn, "actions": law, "ring": ring,
+                              "value": nn / g["s_per_step"], "unit": "env-steps/s",
+                              "ms_per_step": g["s_per_step"] * 1e3, "launch_us": r["launch_us"],
+                              "achieved_GBps": r["achieved"], "frac": r["frac"], "repeats": g["repeats"],
+                              "config": "BASELINE configs[2]" if (task, nn, law) == ("hover3d", 262144, "uniform") else None})
+            except Exception as e:          # a sweep point never costs the headline
+                sweep.append({"task": task, "envs": nn, "actions": law, "error": repr(e)})
+                torch.cuda.empty_cache()
+        extra["sweep"] = sweep
+        # BASELINE configs[4]: dt = 1e-3, 10 Dynamics.setMotors calls per env step -- both bounds
+        try:
+            nsub = 10
+            g = run_config(torch, timer, gca, a, "lander3d", 65536, "near_hover", nsub, device, rank, 100, 100,
+                           a.ring, min_region_s, 3, prefetch=bool(a.prefetch))
+            r = roofline_block("lander3d", 65536, g["launch_s"], a.state)
+            flops = (FLOPS_PER_SUBSTEP * nsub + FLOPS_PER_STEP_FIXED) * 65536
+            tf = flops / g["launch_s"] / 1e12
+            extra["config5"] = {
+                "workload": "lander3d, 65536 envs, near_hover actions, dt=0.001 x 10 substeps (BASELINE configs[4])",
+                "value": 65536 / g["s_per_step"], "unit": "env-steps/s", "ms_per_step": g["s_per_step"] * 1e3,
+                "launch_us": r["launch_us"], "repeats": g["repeats"],
+                "bounds": [
+                    {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"]},
+                    {"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / F64_VALU_PEAK_TFLOPS,
+                     "flop_per_env_step": FLOPS_PER_SUBSTEP * nsub + FLOPS_PER_STEP_FIXED,
+                     "note": "float64 vector ALU (no MFMA on this path): algorithmic flops of DESIGN.md section 4"}]}
+        except Exception as e:
+            extra["config5"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
 
-    traffic = None
+    traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("%s_%d" % (a.task, n))
+            if traffic is not None:
+                tsrc = ("profiles/traffic.json: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes) of this "
+                        "kernel and batch, committed with the profiles -- NOT measured by this run")
         except Exception:
             traffic = None
 
@@ -360,8 +513,12 @@ def main():
         "metric": "env-steps/sec Lander3D at 65 536 envs" if (a.task, n) == ("lander3d", 65536)
                   else "env-steps/sec %s at %d envs" % (a.task, n),
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True,
+        "warmup": a.warmup, "ms_per_step": m["s_per_step"] * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "repeats": m["repeats"], "regions": m["regions"], "timed_steps_per_region": m["steps"] * m["repeats"],
+        "timing": "median of %d regions of %d x %d steps, each bracketed by barrier + synchronize, MAX over ranks"
+                  % (m["regions"], m["repeats"], m["steps"]),
+        "single_pass": m["single_pass"],
         "config": {"workload": "%s, %d envs/GPU, %s actions, auto-reset NEXT_STEP, %s state words, "
                                "dt=%g x %d substeps, %s" % (a.task, n, a.actions, a.state,
                                                           1.0 / (100 * a.substeps), a.substeps,
@@ -369,19 +526,15 @@ def main():
                                                           if use_graph else "eager launches"),
                    "envs_per_gpu": n, "total_envs": total_envs, "task": a.task,
                    "actions": a.actions, "state_words": a.state, "substeps": a.substeps,
+                   "action_ring": a.ring, "next_action_prefetch": bool(a.prefetch),
                    "parallelism": "env-shard x%d" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "step_kernel<%s,%s>" % (a.task, a.state),
-                     "launch_us": launch_s * 1e6,
-                     "algorithmic_bytes_per_launch": ALGO_BYTES[a.task] * n},
+        "roofline": roofline_block(a.task, n, m["launch_s"], a.state, traffic, tsrc),
     }
     out.update(extra)
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out), flush=True)
-    env.close()
     if dist is not None:
         dist.destroy_process_group()
 

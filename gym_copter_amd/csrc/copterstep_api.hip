@@ -322,6 +322,20 @@ int cs_step(cs_ctx* ctx, const float* actions_dev, float* obs_dev, float* reward
   return cs_step_ex(ctx, &io, stream);
 }
 
+int cs_step_prefetch(cs_ctx* ctx, const float* actions_dev, const float* next_actions_dev,
+                     float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
+                     uint8_t* truncated_dev, void* stream) {
+  cs_step_io io;
+  std::memset(&io, 0, sizeof io);
+  io.actions_dev = actions_dev;
+  io.next_actions_dev = next_actions_dev;
+  io.obs_dev = obs_dev;
+  io.reward_dev = reward_dev;
+  io.terminated_dev = terminated_dev;
+  io.truncated_dev = truncated_dev;
+  return cs_step_ex(ctx, &io, stream);
+}
+
 int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float* obs_dev,
                  float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;

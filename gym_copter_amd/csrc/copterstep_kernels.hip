@@ -886,6 +886,21 @@ __device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, c
   if constexpr (!LEAN) {
     if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
   }
+  // Open-loop callers may name the NEXT step's action batch: touch this tile's rows of it (one
+  // dword per 16-byte row = every 128-byte line of the 1 KiB block) so that the next launch -- same
+  // tile, same XCD -- finds them in this XCD's L2 instead of waiting for the Infinity Cache / HBM.
+  // Issued behind the first-round loads' last wait (the fake operands tie it there: a wait counts
+  // loads in issue order, so an earlier position would make the physics wait for this one too);
+  // the destination stays reserved to the end of the kernel and is never read.
+  uint32_t prefetch_sink = 0;
+  if (io.next_actions_dev != nullptr) {
+    constexpr uint32_t row = (uint32_t)task_act_dim(TASK) * 4u;
+    asm volatile("global_load_dword %0, %1, %2"
+                 : "=v"(prefetch_sink)
+                 : "v"((valid ? i : 0u) * row), "s"(io.next_actions_dev), "v"(in.act.x), "v"(in.raw[0]),
+                   "v"(in.raw[4]), "v"(in.raw[8]), "v"(e.fe.v[0]), "v"(in.prev_sh)
+                 : "memory");
+  }
   StepOut<OBS> out;
   advance<TASK, MODE, OBS, true>(c, q, o, e, in.act, io, i, lane, valid, tile, out);
 
@@ -903,6 +918,7 @@ __device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, c
     if (io.truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(io.truncated_dev, i));
   }
   write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, n, valid, out.row);
+  asm volatile("" ::"v"(prefetch_sink));  // the prefetch's landing register is live up to here
   CS_STAMP(6);
 }
 
@@ -914,7 +930,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
     // first loads do not wait for an s_load of the argument block
     char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
-    const DevConst c, const DevState s_rest, const cs_step_io io_rest) {
+    const float* const next_actions_dev, const DevConst c, const DevState s_rest, const cs_step_io io_rest) {
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
@@ -924,6 +940,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
   io.reward_dev = reward_dev;
   io.terminated_dev = terminated_dev;
   io.truncated_dev = truncated_dev;
+  io.next_actions_dev = next_actions_dev;
   StepOpts o;
   o.stats = !LEAN && c.stats;
   o.trunc = !LEAN && c.tl_trunc;
@@ -1131,7 +1148,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   for (int k = 0; k < 12; ++k) e.x[k] = decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
 
   cs_step_io io;  // no optional outputs in the K-step form
-  io.actions_dev = nullptr;
+  io.actions_dev = io.next_actions_dev = nullptr;
   io.obs_dev = io.reward_dev = io.final_obs_dev = io.done_return_dev = nullptr;
   io.terminated_dev = io.truncated_dev = nullptr;
   io.done_count_dev = io.done_ids_dev = io.done_length_dev = nullptr;
@@ -1413,7 +1430,7 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, hi
 #define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE)                                                  \
   hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE>), grid, block, 0,  \
                      stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev,            \
-                     io.terminated_dev, io.truncated_dev, c, s, io)
+                     io.terminated_dev, io.truncated_dev, io.next_actions_dev, c, s, io)
   if (!lean)
     CS_STEP(false, false, false);
   else if (s.n <= kNtActionMaxEnvs)  // the state fits the L2s: keep the action stream out of them

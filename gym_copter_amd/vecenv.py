@@ -289,6 +289,28 @@ class CopterVecEnv:
                     trunc.cpu().numpy(), {k: _to_numpy(v) for k, v in infos.items()})
         return self._obs, self._reward, term, trunc, infos
 
+    def step_prefetch(self, actions, next_actions):
+        """step(actions) for open-loop callers that already hold the NEXT action batch as a device
+        tensor (recorded or pre-generated actions): the kernel also touches `next_actions`' cache lines
+        so that the next launch finds them close by (cs_step_io.next_actions_dev).  Same results as
+        step(); device float32 tensors only."""
+        self._check_open()
+        torch = _torch()
+        shape = (self.num_envs, self.action_dim)
+        for t in (actions, next_actions):
+            if (not isinstance(t, torch.Tensor) or tuple(t.shape) != shape or t.dtype != torch.float32
+                    or t.device != self.device or not t.is_contiguous()):
+                raise ValueError("step_prefetch needs contiguous float32 %s tensors on %s" % (shape, self.device))
+        if self._final_obs is not None or self._done is not None:
+            raise RuntimeError("step_prefetch serves the default outputs only")
+        po, pr, pt, pu = self._out_ptrs
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_step_prefetch(self._ctx, C.c_void_p(actions.data_ptr()),
+                                                  C.c_void_p(next_actions.data_ptr()), po, pr, pt, pu,
+                                                  self._stream()))
+        self._keep = (actions, next_actions)
+        return self._obs, self._reward, self._term_b, self._trunc_b, {}
+
     def step_many(self, actions):
         """K steps in ONE kernel launch for resident action batches: actions [K,N,4] ->
         (obs [K,N,obs_dim], reward [K,N], terminated [K,N], truncated [K,N]).  Bit-identical to

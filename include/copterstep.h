@@ -14,7 +14,8 @@
  *                                                               dynamics/__init__.py:71-76, vehicles/dji_phantom.py:9-26
  *   cs_seed                  _Task.seed                         envs/task.py:71-75
  *   cs_reset                 Lander.reset -> _Task._reset       envs/lander.py:35-37, envs/task.py:145-202
- *   cs_step / cs_step_ex     _Task.step + Lander._get_reward    envs/task.py:77-137, envs/lander.py:39-74
+ *   cs_step / cs_step_ex / cs_step_prefetch
+ *                            _Task.step + Lander._get_reward    envs/task.py:77-137, envs/lander.py:39-74
  *                            (+ attic hover.py:18-21, hover3d.py:32-37 for CS_TASK_HOVER3D)
  *                            which calls Dynamics.setMotors     dynamics/__init__.py:114-197,249-302
  *   cs_step_many             K x _Task.step in one launch       envs/task.py:77-137 (lander.py:40-65 loop)
@@ -54,7 +55,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 1
+#define CS_ABI_VERSION 2
 
 typedef enum cs_status {
   CS_OK = 0,
@@ -145,6 +146,11 @@ typedef struct cs_step_io {
   int32_t* done_ids_dev;     /* [N] local env index */
   float* done_return_dev;    /* [N] (needs cfg.episode_stats) */
   int32_t* done_length_dev;  /* [N] */
+  /* Optional hint for open-loop workloads (recorded / pre-generated action batches, the "resident
+     ring" of the benchmark): the action batch the NEXT step will be given, [N,A] like actions_dev.
+     The kernel only touches its cache lines so that they are near the compute units when the next
+     launch asks for them; nothing is computed from it and results do not depend on it. */
+  const float* next_actions_dev;
 } cs_step_io;
 
 int cs_version(void);
@@ -179,6 +185,10 @@ int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, i
 int cs_step(cs_ctx* ctx, const float* actions_dev, float* obs_dev, float* reward_dev,
             uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
 int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream);
+/* cs_step with cs_step_io.next_actions_dev (see there): identical results, one more pointer. */
+int cs_step_prefetch(cs_ctx* ctx, const float* actions_dev, const float* next_actions_dev,
+                     float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
+                     uint8_t* truncated_dev, void* stream);
 
 /* K consecutive steps in ONE launch for action batches that are already resident (open
  * loop: recorded or random actions, shooting-style planners).  actions_dev [K,N,4];
