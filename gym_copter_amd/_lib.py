@@ -15,6 +15,11 @@ TASK_LANDER3D, TASK_HOVER3D, TASK_LANDER2D, TASK_LANDER1D, TASK_HOVER2D, TASK_HO
 STATE_F32G, STATE_F32_RN, STATE_F64 = 0, 1, 2
 AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
 STATUS_CRASHED, STATUS_LANDED, STATUS_LEVELING, STATUS_AIRBORNE = 0, 1, 2, 3
+ARITH_F64, ARITH_F32 = 0, 1
+THRUST_B, THRUST_LIFT = 0, 1
+VEHICLE_ROWS = 12
+EPISODE_STATS = 6
+COMM_ID_BYTES = 128
 
 
 class CopterStepError(RuntimeError):
@@ -42,6 +47,8 @@ class Config(C.Structure):
         ("target_radius", C.c_double), ("yaw_penalty_factor", C.c_double),
         ("xyz_penalty_factor", C.c_double), ("dz_max", C.c_double), ("dz_penalty", C.c_double),
         ("inside_radius_bonus", C.c_double),
+        ("action_arith", C.c_int32), ("thrust_model", C.c_int32), ("rotor_gyro", C.c_int32),
+        ("reserved_", C.c_int32), ("rho", C.c_double), ("C_L", C.c_double),
     ]
 
 
@@ -66,6 +73,12 @@ class PidGains(C.Structure):
                                           "alt_kp alt_ki alt_kd alt_target alt_windup").split()]
 
 
+class Tuning(C.Structure):
+    """cs_tuning (include/copterstep.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("split_max_envs", C.c_uint32),
+                ("nt_action_max_envs", C.c_uint32), ("nt_state_min_envs", C.c_uint32)]
+
+
 PID_LANDER, PID_HOVER = 0, 1
 PID_ROWS = 24          # 6 controllers x {errorI, lastError, deltaError1, deltaError2}
 
@@ -87,6 +100,14 @@ SYMBOLS = {
     "cs_step_prefetch": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "cs_step_many": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_set_motors": (C.c_int, [_P, _P, _P]),
+    "cs_set_perturbation": (C.c_int, [_P, _P, _P, _P]),
+    "cs_episode_stats": (C.c_int, [_P, _P, _P]),
+    "cs_set_tuning": (C.c_int, [_P, C.POINTER(Tuning)]),
+    "cs_get_tuning": (C.c_int, [_P, C.POINTER(Tuning)]),
+    "cs_comm_unique_id": (C.c_int, [_P]),
+    "cs_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "cs_comm_destroy": (C.c_int, [_P]),
+    "cs_allgather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "cs_export_state": (C.c_int, [_P, _P, _P, _P, _P]),
     "cs_set_vehicle_params": (C.c_int, [_P, _P]),
     "cs_pid_gains_init": (C.c_int, [_P]),

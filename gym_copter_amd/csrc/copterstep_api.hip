@@ -1,8 +1,11 @@
 // copterstep_api.hip -- the C ABI of libcopterstep.so (include/copterstep.h): context
 // ownership, derivation of the per-launch constants from cs_config, error reporting,
 // and host<->device state exchange.  All compute lives in copterstep_kernels.hip.
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -21,6 +24,10 @@ struct cs_ctx {
   double* pid_state = nullptr;
   uint32_t pid_stride = 0;
   double* veh = nullptr;  // per-env coefficient columns (cs_set_vehicle_params), owned
+  cs::Tuning tune{};
+  // the per-launch constants, derived from cfg once and again after cs_seed / cs_set_altitude
+  cs::DevConst dc;
+  bool dc_valid = false;
 };
 
 namespace {
@@ -46,30 +53,99 @@ double stored_word(const cs_config& cfg, double v) {
   return cfg.state_mode == CS_STATE_F64 ? v : (double)(float)v;
 }
 
-// Per-launch constants.  Uniform factors and reciprocals are folded once here in float64;
-// the kernels multiply where upstream divides (a few ulp(f64) apart).
+// The caller owns the current device (include/copterstep.h); entry points that must talk to the
+// context's own device switch to it for their duration only.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+const double kPi = 3.141592653589793238462643383279502884;
+
+// The eleven folded coefficients of one vehicle + world (copterstep_kernels.hip: Coef).  Uniform
+// factors and reciprocals are folded here in float64; the kernels multiply where upstream divides
+// (a few ulp(f64) apart).
+struct VehicleIn {
+  double B, D, M, L, Ix, Iy, Iz, Jr, maxrpm, G, rho, C_L;
+};
+void fold_vehicle(const VehicleIn& v, int thrust_model, double (&out)[cs::kCoefRows]) {
+  const double ws = v.maxrpm * kPi / 30.0;  // motor value -> rad/s
+  const double ws2 = ws * ws;
+  double kthrust, kroll;  // force per unit sum(m^2), roll/pitch torque per unit difference of m^2
+  if (thrust_model == CS_THRUST_LIFT) {
+    // Lift_i = 0.5*rho*S*C_L*(omega_i*L/2)^2, S = 0.05*L*4; U2 = u2(Lift), U3 = u3(Lift)
+    // (attic/mars/dynamics/__init__.py:84-88, :151-163)
+    const double S = 0.05 * v.L * 4.0;
+    const double KL = 0.5 * v.rho * S * v.C_L * (v.L / 2.0) * (v.L / 2.0) * ws2;
+    kthrust = KL;
+    kroll = KL;
+  } else {
+    kthrust = v.B * ws2;          // U1 = B * sum(omega^2), dynamics/__init__.py:127
+    kroll = v.L * v.B * ws2;      // U2 = L*B*u2(omega^2), :128-129
+  }
+  out[0] = -kthrust / v.M;
+  out[1] = kroll / v.Ix;
+  out[2] = kroll / v.Iy;
+  out[3] = (v.D * ws2) / v.Iz;
+  out[4] = v.G;
+  out[5] = (v.Iy - v.Iz) / v.Ix;
+  out[6] = (v.Iz - v.Ix) / v.Iy;
+  out[7] = (v.Ix - v.Iy) / v.Iz;
+  out[8] = 2.0 / v.M;
+  out[9] = v.Jr / v.Ix * ws;
+  out[10] = v.Jr / v.Iy * ws;
+}
+
+// Per-launch constants.
 cs::DevConst make_const(const cs_ctx* ctx) {
   const cs_config& g = ctx->cfg;
   cs::DevConst c;
   std::memset(&c, 0, sizeof c);
-  const double pi = 3.141592653589793238462643383279502884;
-  const double ws = g.maxrpm * pi / 30.0;  // motor value -> rad/s
-  const double ws2 = ws * ws;
-  c.k_thrust = -(g.B * ws2) / g.M;
-  c.k_roll = (g.L * g.B * ws2) / g.Ix;
-  c.k_pitch = (g.L * g.B * ws2) / g.Iy;
-  c.k_yaw = (g.D * ws2) / g.Iz;
-  c.G = g.G;
-  c.c_dphi = (g.Iy - g.Iz) / g.Ix;
-  c.c_dthe = (g.Iz - g.Ix) / g.Iy;
-  c.c_dpsi = (g.Ix - g.Iy) / g.Iz;
+  double k[cs::kCoefRows];
+  fold_vehicle(VehicleIn{g.B, g.D, g.M, g.L, g.Ix, g.Iy, g.Iz, g.Jr, g.maxrpm, g.G, g.rho, g.C_L},
+               g.thrust_model, k);
+  c.k_thrust = k[0];
+  c.k_roll = k[1];
+  c.k_pitch = k[2];
+  c.k_yaw = k[3];
+  c.G = k[4];
+  c.c_dphi = k[5];
+  c.c_dthe = k[6];
+  c.c_dpsi = k[7];
+  c.two_inv_M = k[8];
+  c.g_phi = k[9];
+  c.g_the = k[10];
+  c.gyro = g.rotor_gyro != 0 ? 1 : 0;
+  c.act_f32 = g.action_arith == CS_ARITH_F32 ? 1 : 0;
+  // NumPy's float32 motor model: each Python scalar becomes the float32 nearest to it
+  c.f32_maxrpm = (float)g.maxrpm;
+  c.f32_pi = (float)kPi;
+  c.f32_B = (float)g.B;
+  c.f32_LB = (float)(g.L * g.B);
+  c.f32_D = (float)g.D;
+  c.f32_M = (float)g.M;
+  c.f32_Ix = (float)g.Ix;
+  c.f32_Iy = (float)g.Iy;
+  c.f32_Iz = (float)g.Iz;
   c.dt = 1.0 / (g.frames_per_second * (double)g.substeps);
-  c.two_inv_M = 2.0 / g.M;
   c.land_vx = g.landing_vel_x;
   c.land_vy = g.landing_vel_y;
   c.land_ang = g.landing_angle;
   c.bounds = g.bounds;
-  c.max_angle = g.max_angle_deg * (pi / 180.0);  // np.radians, task.py:58
+  c.max_angle = g.max_angle_deg * (kPi / 180.0);  // np.radians, task.py:58
   c.oob_penalty = g.out_of_bounds_penalty;
   c.z0 = -g.initial_altitude;
   c.force_mag = g.initial_random_force;
@@ -92,13 +168,30 @@ cs::DevConst make_const(const cs_ctx* ctx) {
   c.tl_trunc = g.time_limit_truncates;
   c.stats = g.episode_stats;
   c.status0 = (c.z0 < 0.0) ? CS_STATUS_AIRBORNE : CS_STATUS_LANDED;  // setState, :215-217
-  c.seed_lo = (uint32_t)g.seed;
-  c.seed_hi = (uint32_t)(g.seed >> 32);
+  // Philox keys: the two halves of splitmix64(seed) -- every bit of the 64-bit seed matters
+  const uint64_t h = splitmix64(g.seed);
+  c.key_force = (uint32_t)h;
+  c.key_action = (uint32_t)(h >> 32);
   c.id_lo = (uint32_t)(uint64_t)g.env_id_base;
-  c.id_hi = (uint32_t)((uint64_t)g.env_id_base >> 32);
-  c.guard_mask = 0x1FE00000u;
   cs::trig_constants(c.trig);
   return c;
+}
+
+// the cached constants of a context (rebuilt after cs_seed / cs_set_altitude)
+const cs::DevConst& constants(cs_ctx* ctx) {
+  if (!ctx->dc_valid) {
+    ctx->dc = make_const(ctx);
+    ctx->dc_valid = true;
+  }
+  return ctx->dc;
+}
+
+uint32_t env_u32(const char* name) {
+  const char* v = std::getenv(name);
+  if (v == nullptr || *v == 0) return 0;
+  char* end = nullptr;
+  const unsigned long long x = std::strtoull(v, &end, 10);
+  return (end != nullptr && *end == 0 && x <= 0xFFFFFFFFull) ? (uint32_t)x : 0u;
 }
 
 int check_ctx(const cs_ctx* ctx) {
@@ -161,6 +254,11 @@ int cs_config_init(cs_config* cfg, int task) {
   cfg->dz_max = 10;
   cfg->dz_penalty = 100;
   cfg->inside_radius_bonus = 100;
+  cfg->action_arith = CS_ARITH_F64;
+  cfg->thrust_model = CS_THRUST_B;
+  cfg->rotor_gyro = 0;
+  cfg->rho = 1.225;  // Earth air density, attic/mars/dynamics/__init__.py:86
+  cfg->C_L = 0.4;    // attic/mars/dynamics/ingenuity.py:55
   return CS_OK;
 }
 
@@ -182,7 +280,14 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   if (cfg->substeps < 1 || cfg->substeps > 1000)
     return fail(CS_ERR_ARG, "cs_create: substeps must be in [1, 1000]");
   if (cfg->max_steps < 1 || cfg->max_steps > (int32_t)cs::kMetaStepsMask - 2)
-    return fail(CS_ERR_ARG, "cs_create: max_steps must be in [1, 2^24 - 3]");
+    return fail(CS_ERR_ARG, "cs_create: max_steps must be in [1, 2^20 - 3]");
+  if (cfg->action_arith != CS_ARITH_F64 && cfg->action_arith != CS_ARITH_F32)
+    return fail(CS_ERR_ARG, "cs_create: unknown action_arith");
+  if (cfg->thrust_model != CS_THRUST_B && cfg->thrust_model != CS_THRUST_LIFT)
+    return fail(CS_ERR_ARG, "cs_create: unknown thrust_model");
+  if (cfg->action_arith == CS_ARITH_F32 && (cfg->thrust_model != CS_THRUST_B || cfg->rotor_gyro != 0))
+    return fail(CS_ERR_ARG, "cs_create: the float32 motor model restates the live model only "
+                            "(thrust_model = CS_THRUST_B, rotor_gyro = 0)");
   if (!(cfg->frames_per_second > 0) || !(cfg->M > 0) || !(cfg->Ix > 0) || !(cfg->Iy > 0) ||
       !(cfg->Iz > 0))
     return fail(CS_ERR_ARG, "cs_create: frames_per_second, M, Ix, Iy, Iz must be positive");
@@ -194,12 +299,15 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
                                    hipGetErrorString(e) + "); there is no CPU fallback");
   if (cfg->device < 0 || cfg->device >= ndev)
     return fail(CS_ERR_DEVICE, "cs_create: device ordinal out of range");
-  CS_HIP(hipSetDevice(cfg->device));
+  DeviceGuard guard(cfg->device);
 
   cs_ctx* ctx = new (std::nothrow) cs_ctx;
   if (ctx == nullptr) return fail(CS_ERR_MEMORY, "cs_create: host allocation failed");
   std::memset(ctx, 0, sizeof *ctx);
   ctx->cfg = *cfg;
+  ctx->tune.split_max_envs = env_u32("COPTERSTEP_SPLIT_MAX_ENVS");
+  ctx->tune.nt_action_max_envs = env_u32("COPTERSTEP_NT_ACTION_MAX_ENVS");
+  ctx->tune.nt_state_min_envs = env_u32("COPTERSTEP_NT_STATE_MIN_ENVS");
   ctx->layout = cs::make_layout(cfg->state_mode);
   cs::DevState& s = ctx->st;
   s.n = (uint32_t)cfg->num_envs;
@@ -232,7 +340,7 @@ extern "C" int cs_debug_read_stamps(cs_ctx* ctx, unsigned long long* host, void*
 
 int cs_destroy(cs_ctx* ctx) {
   if (ctx == nullptr) return CS_OK;
-  (void)hipSetDevice(ctx->cfg.device);
+  DeviceGuard guard(ctx->cfg.device);
   if (ctx->st.tiles) (void)hipFree(ctx->st.tiles);
   if (ctx->pid_state) (void)hipFree(ctx->pid_state);
   if (ctx->veh) (void)hipFree(ctx->veh);
@@ -261,19 +369,21 @@ int cs_action_dim(const cs_ctx* ctx, int32_t* out) {
 int cs_seed(cs_ctx* ctx, uint64_t seed) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   ctx->cfg.seed = seed;
+  ctx->dc_valid = false;
   return CS_OK;
 }
 
 int cs_set_altitude(cs_ctx* ctx, double altitude) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   ctx->cfg.initial_altitude = altitude;
+  ctx->dc_valid = false;
   return CS_OK;
 }
 
 int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, float* obs_dev,
              void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
-  const cs::DevConst c = make_const(ctx);
+  const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
                                   force_xyz_dev, obs_dev, ctx->pid_state, ctx->pid_stride, nullptr, 1,
                                   (hipStream_t)stream);
@@ -285,7 +395,7 @@ int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, i
                   const float* force_xyz_dev, float* obs_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (pose_dev == nullptr) return fail(CS_ERR_ARG, "cs_reset_pose: pose_dev is required");
-  const cs::DevConst c = make_const(ctx);
+  const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
                                   force_xyz_dev, obs_dev, ctx->pid_state, ctx->pid_stride, pose_dev,
                                   perturb != 0 ? 1 : 0, (hipStream_t)stream);
@@ -303,8 +413,8 @@ int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream) {
     return fail(CS_ERR_ARG, "cs_step: done_* lists need done_count_dev");
   if (io->done_count_dev != nullptr)
     CS_HIP(hipMemsetAsync(io->done_count_dev, 0, sizeof(int32_t), (hipStream_t)stream));
-  const cs::DevConst c = make_const(ctx);
-  hipError_t e = cs::launch_step(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, *io,
+  const cs::DevConst& c = constants(ctx);
+  hipError_t e = cs::launch_step(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, *io, ctx->tune,
                                  (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_step: kernel launch");
   return CS_OK;
@@ -341,7 +451,7 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (actions_dev == nullptr) return fail(CS_ERR_ARG, "cs_step_many: actions_dev is required");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_step_many: num_steps must be >= 1");
-  const cs::DevConst c = make_const(ctx);
+  const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       const_cast<float*>(actions_dev), obs_dev, reward_dev,
                                       terminated_dev, truncated_dev, cs::CS_POLICY_NONE, nullptr,
@@ -352,7 +462,9 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
 
 int cs_set_vehicle_params(cs_ctx* ctx, const double* params_host) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
-  CS_HIP(hipSetDevice(ctx->cfg.device));
+  if (ctx->cfg.action_arith == CS_ARITH_F32 && params_host != nullptr)
+    return fail(CS_ERR_ARG, "cs_set_vehicle_params: per-env vehicles are not available with the float32 motor model");
+  DeviceGuard guard(ctx->cfg.device);
   CS_HIP(hipDeviceSynchronize());
   if (params_host == nullptr) {  // back to the uniform vehicle of cs_config
     ctx->st.veh = nullptr;
@@ -363,19 +475,18 @@ int cs_set_vehicle_params(cs_ctx* ctx, const double* params_host) {
   const uint32_t stride = ctx->st.ntiles * 64u;  // padded like the tiles: no bounds checks on device
   const double* P = params_host;
   auto at = [&](int row, size_t i) { return P[(size_t)row * n + i]; };
-  std::vector<double> cols((size_t)9 * stride, 0.0);
-  const double pi = 3.14159265358979323846;
+  std::vector<double> cols((size_t)cs::kCoefRows * stride, 0.0);
   for (size_t i = 0; i < n; ++i) {
-    const double B = at(0, i), D = at(1, i), M = at(2, i), L = at(3, i), Ix = at(4, i), Iy = at(5, i),
-                 Iz = at(6, i), maxrpm = at(8, i), G = at(9, i);
-    if (!(M > 0.0) || !(Ix > 0.0) || !(Iy > 0.0) || !(Iz > 0.0) || !std::isfinite(B * D * L * maxrpm * G))
+    const VehicleIn v{at(0, i), at(1, i), at(2, i), at(3, i), at(4, i), at(5, i),
+                      at(6, i), at(7, i), at(8, i), at(9, i), at(10, i), at(11, i)};
+    const bool lift = ctx->cfg.thrust_model == CS_THRUST_LIFT;
+    if (!(v.M > 0.0) || !(v.Ix > 0.0) || !(v.Iy > 0.0) || !(v.Iz > 0.0) ||
+        !std::isfinite(v.B * v.D * v.L * v.maxrpm * v.G * v.Jr) || (lift && !std::isfinite(v.rho * v.C_L)))
       return fail(CS_ERR_ARG, "cs_set_vehicle_params: env " + std::to_string(i) +
                                   ": M, Ix, Iy, Iz must be positive and every value finite");
-    // the same folding as make_const()
-    const double ws = maxrpm * pi / 30.0, ws2 = ws * ws;
-    const double v[9] = {-(B * ws2) / M,  (L * B * ws2) / Ix, (L * B * ws2) / Iy, (D * ws2) / Iz, G,
-                         (Iy - Iz) / Ix, (Iz - Ix) / Iy,     (Ix - Iy) / Iz,     2.0 / M};
-    for (int j = 0; j < 9; ++j) cols[(size_t)j * stride + i] = v[j];
+    double k[cs::kCoefRows];
+    fold_vehicle(v, ctx->cfg.thrust_model, k);  // the same folding as make_const()
+    for (int j = 0; j < cs::kCoefRows; ++j) cols[(size_t)j * stride + i] = k[j];
   }
   if (ctx->veh == nullptr) CS_HIP(hipMalloc((void**)&ctx->veh, cols.size() * sizeof(double)));
   CS_HIP(hipMemcpy(ctx->veh, cols.data(), cols.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -418,7 +529,7 @@ int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* g) {
     return fail(CS_ERR_ARG, "cs_pid_configure: unknown heuristic");
   if (g->heuristic == CS_PID_HOVER && cs::task_obs_dim(ctx->cfg.task) < 12)
     return fail(CS_ERR_ARG, "cs_pid_configure: the hover heuristic reads dpsi, i.e. needs the Hover3D observation");
-  CS_HIP(hipSetDevice(ctx->cfg.device));
+  DeviceGuard guard(ctx->cfg.device);
   if (ctx->pid_state == nullptr) {
     // one float64 row per controller field, padded like the tiles so that lanes past the
     // last env have somewhere harmless to read and write
@@ -491,7 +602,7 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_rollout_pid: the heuristic flies the 3D tasks only");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_pid: num_steps must be >= 1");
-  const cs::DevConst c = make_const(ctx);
+  const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,
                                       truncated_dev, cs::CS_POLICY_PID, &ctx->pid, ctx->pid_state,
@@ -505,7 +616,7 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
                       void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_random: num_steps must be >= 1");
-  const cs::DevConst c = make_const(ctx);
+  const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,
                                       truncated_dev, cs::CS_POLICY_RANDOM, nullptr, nullptr, 0,
@@ -517,7 +628,7 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (motors_dev == nullptr) return fail(CS_ERR_ARG, "cs_set_motors: motors_dev is required");
-  const cs::DevConst c = make_const(ctx);
+  const cs::DevConst& c = constants(ctx);
   hipError_t e =
       cs::launch_set_motors(ctx->cfg.state_mode, c, ctx->st, motors_dev, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_set_motors: kernel launch");
@@ -526,11 +637,145 @@ int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
 
 int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
-  const cs::DevConst c = make_const(ctx);
+  const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_export_state(ctx->cfg.state_mode, c, ctx->st, x_dev, status_dev, steps_dev,
                                          (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_export_state: kernel launch");
   return CS_OK;
+}
+
+int cs_set_perturbation(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (force_xyz_dev == nullptr) return fail(CS_ERR_ARG, "cs_set_perturbation: force_xyz_dev is required");
+  hipError_t e = cs::launch_set_perturbation(ctx->cfg.state_mode, ctx->st, mask_dev, force_xyz_dev,
+                                             (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_set_perturbation: kernel launch");
+  return CS_OK;
+}
+
+int cs_episode_stats(cs_ctx* ctx, double* stats_dev, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (stats_dev == nullptr) return fail(CS_ERR_ARG, "cs_episode_stats: stats_dev is required");
+  CS_HIP(hipMemsetAsync(stats_dev, 0, CS_EPISODE_STATS * sizeof(double), (hipStream_t)stream));
+  hipError_t e = cs::launch_episode_stats(ctx->cfg.state_mode, ctx->st, stats_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_episode_stats: kernel launch");
+  return CS_OK;
+}
+
+int cs_set_tuning(cs_ctx* ctx, const cs_tuning* t) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (t == nullptr || t->struct_size != sizeof(cs_tuning))
+    return fail(CS_ERR_ARG, "cs_set_tuning: tuning missing or struct_size mismatch");
+  ctx->tune.split_max_envs = t->split_max_envs;
+  ctx->tune.nt_action_max_envs = t->nt_action_max_envs;
+  ctx->tune.nt_state_min_envs = t->nt_state_min_envs;
+  return CS_OK;
+}
+
+int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out) {
+  if (check_ctx(ctx) || out == nullptr) return fail(CS_ERR_ARG, "cs_get_tuning: null argument");
+  const cs::Tuning d = cs::default_tuning();
+  out->struct_size = (uint32_t)sizeof(cs_tuning);
+  out->split_max_envs = ctx->tune.split_max_envs ? ctx->tune.split_max_envs : d.split_max_envs;
+  out->nt_action_max_envs = ctx->tune.nt_action_max_envs ? ctx->tune.nt_action_max_envs : d.nt_action_max_envs;
+  out->nt_state_min_envs = ctx->tune.nt_state_min_envs ? ctx->tune.nt_state_min_envs : d.nt_state_min_envs;
+  return CS_OK;
+}
+
+// ---- RCCL all-gather for C / C++ hosts: librccl is loaded on first use --------------------------
+// (the Python package gathers through torch.distributed, whose "nccl" backend is the same RCCL)
+namespace {
+
+struct Rccl {
+  struct Id {  // ncclUniqueId: 128 bytes, passed by value
+    char bytes[CS_COMM_ID_BYTES];
+  };
+  void* lib = nullptr;
+  int (*get_unique_id)(void*) = nullptr;
+  int (*comm_init_rank)(void**, int, Id, int) = nullptr;
+  int (*comm_destroy)(void*) = nullptr;
+  int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*get_error_string)(int) = nullptr;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (r.lib) {
+      r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.lib, "ncclGetUniqueId");
+      r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(r.lib, "ncclCommInitRank");
+      r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.lib, "ncclCommDestroy");
+      r.all_gather = (decltype(r.all_gather))dlsym(r.lib, "ncclAllGather");
+      r.get_error_string = (decltype(r.get_error_string))dlsym(r.lib, "ncclGetErrorString");
+      if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather) r.lib = nullptr;
+    }
+  }
+  return r.lib ? &r : nullptr;
+}
+
+int rccl_fail(Rccl* r, int code, const char* what) {
+  return fail(CS_ERR_HIP, std::string(what) + ": " +
+                              (r->get_error_string ? r->get_error_string(code) : "RCCL error " + std::to_string(code)));
+}
+
+}  // namespace
+
+struct cs_comm {
+  void* comm;
+  int32_t world, rank;
+};
+
+int cs_comm_unique_id(void* id_out) {
+  if (id_out == nullptr) return fail(CS_ERR_ARG, "cs_comm_unique_id: null buffer");
+  Rccl* r = rccl();
+  if (r == nullptr) return fail(CS_ERR_DEVICE, "cs_comm_unique_id: librccl.so.1 not found");
+  static_assert(sizeof(Rccl::Id) == CS_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  const int rc = r->get_unique_id(id_out);
+  return rc == 0 ? CS_OK : rccl_fail(r, rc, "ncclGetUniqueId");
+}
+
+int cs_comm_create(const void* id, int32_t world_size, int32_t rank, cs_comm** out) {
+  if (id == nullptr || out == nullptr) return fail(CS_ERR_ARG, "cs_comm_create: null argument");
+  *out = nullptr;
+  if (world_size < 1 || rank < 0 || rank >= world_size)
+    return fail(CS_ERR_ARG, "cs_comm_create: rank must be in [0, world_size)");
+  Rccl* r = rccl();
+  if (r == nullptr) return fail(CS_ERR_DEVICE, "cs_comm_create: librccl.so.1 not found");
+  Rccl::Id uid;
+  std::memcpy(uid.bytes, id, sizeof uid.bytes);
+  void* comm = nullptr;
+  const int rc = r->comm_init_rank(&comm, world_size, uid, rank);  // the caller's current device
+  if (rc != 0) return rccl_fail(r, rc, "ncclCommInitRank");
+  cs_comm* c = new (std::nothrow) cs_comm{comm, world_size, rank};
+  if (c == nullptr) {
+    (void)r->comm_destroy(comm);
+    return fail(CS_ERR_MEMORY, "cs_comm_create: host allocation failed");
+  }
+  *out = c;
+  return CS_OK;
+}
+
+int cs_comm_destroy(cs_comm* comm) {
+  if (comm == nullptr) return CS_OK;
+  Rccl* r = rccl();
+  if (r != nullptr && comm->comm != nullptr) (void)r->comm_destroy(comm->comm);
+  delete comm;
+  return CS_OK;
+}
+
+int cs_allgather(cs_comm* comm, const void* send_dev, void* recv_dev, int64_t bytes, void* stream) {
+  if (comm == nullptr || send_dev == nullptr || recv_dev == nullptr || bytes < 0)
+    return fail(CS_ERR_ARG, "cs_allgather: bad argument");
+  Rccl* r = rccl();
+  if (r == nullptr) return fail(CS_ERR_DEVICE, "cs_allgather: librccl.so.1 not found");
+  const int rc = r->all_gather(send_dev, recv_dev, (size_t)bytes, /* ncclInt8 */ 0, comm->comm, (hipStream_t)stream);
+  return rc == 0 ? CS_OK : rccl_fail(r, rc, "ncclAllGather");
 }
 
 // ---- host <-> device state exchange (not a hot path): the whole tile slab is staged on
@@ -541,7 +786,7 @@ static double f32g_decode(float w, uint32_t guard) {
   double d = (double)w;
   uint64_t b;
   std::memcpy(&b, &d, sizeof b);
-  b |= (uint64_t)guard << 21;
+  b |= (uint64_t)guard << cs::kGuardLsb;
   std::memcpy(&d, &b, sizeof b);
   return d;
 }
@@ -549,8 +794,8 @@ static double f32g_decode(float w, uint32_t guard) {
 static void f32g_encode(double v, float* w, uint32_t* guard) {
   uint64_t b;
   std::memcpy(&b, &v, sizeof b);
-  b += 1ULL << 20;
-  *guard = (uint32_t)(b >> 21) & 0xFFu;
+  b += 1ULL << (cs::kGuardLsb - 1);
+  *guard = (uint32_t)(b >> cs::kGuardLsb) & cs::kGuardFieldMask;
   const uint64_t t = b & ~0x1FFFFFFFULL;
   double d;
   std::memcpy(&d, &t, sizeof d);
@@ -589,6 +834,9 @@ struct HostTiles {
     return u;
   }
   void set_u32(size_t i, cs::Field f, uint32_t u) { std::memcpy(at(i, f), &u, 4); }
+  // guard word of state slot k and the field's position in it
+  cs::Field gword(int k) const { return k < 6 ? ctx->layout.gT() : ctx->layout.gR(); }
+  static int gshift(int k) { return cs::kGuardBits * (k < 6 ? k : k - 6); }
 };
 
 }  // namespace
@@ -599,7 +847,7 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_get_state: episode_stats is disabled");
-  CS_HIP(hipSetDevice(ctx->cfg.device));
+  DeviceGuard guard_dev(ctx->cfg.device);
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
   const cs::Layout& L = ctx->layout;
   const size_t n = ctx->st.n;
@@ -612,25 +860,37 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
   }
   CS_HIP(hipMemcpy(h.buf.data(), ctx->st.tiles, h.buf.size(), hipMemcpyDeviceToHost));
   const bool guard = ctx->cfg.state_mode == CS_STATE_F32G;
+  const cs::DevConst& c = constants(ctx);
   for (size_t i = 0; i < n; ++i) {
     const uint32_t meta = h.get_u32(i, L.meta());
+    const uint32_t episode = h.get_u32(i, L.epi());
     if (x_host) {
       for (int k = 0; k < 12; ++k) {
         double v = h.get_word(i, L.x(k));
         if (guard)
-          v = f32g_decode((float)v, (h.get_u32(i, L.g(k >> 2)) >> (8 * (k & 3))) & 0xFFu);
+          v = f32g_decode((float)v, (h.get_u32(i, h.gword(k)) >> HostTiles::gshift(k)) & cs::kGuardFieldMask);
         x_host[(size_t)k * n + i] = v;
       }
     }
-    if (status_host) status_host[i] = (uint8_t)((meta >> cs::kMetaStatusShift) & 3u);
+    if (status_host) status_host[i] = (uint8_t)(h.get_u32(i, L.gT()) >> cs::kStatusShift);
     if (steps_host) steps_host[i] = (int32_t)(meta & cs::kMetaStepsMask);
     if (flags_host)
       flags_host[i] = (uint8_t)(((meta & cs::kMetaPerturbPending) ? 1 : 0) |
-                                ((meta & cs::kMetaResetPending) ? 2 : 0));
+                                ((meta & cs::kMetaResetPending) ? 2 : 0) |
+                                ((meta & cs::kMetaExplicitForce) ? 4 : 0));
     if (prev_shaping_host) prev_shaping_host[i] = h.get_word(i, L.prev());
-    if (force_xyz_host)
-      for (int j = 0; j < 3; ++j) force_xyz_host[(size_t)j * n + i] = h.get_word(i, L.f(j));
-    if (episode_host) episode_host[i] = h.get_u32(i, L.epi());
+    if (force_xyz_host) {
+      // this episode's reset perturbation: the explicit force of the FE group, or the Philox draw
+      // of (seed, global env id, episode - 1), restated on the host; zero before the first reset
+      double f[3] = {0.0, 0.0, 0.0};
+      if (meta & cs::kMetaExplicitForce) {
+        for (int j = 0; j < 3; ++j) f[j] = h.get_word(i, L.f(j));
+      } else if (episode != 0) {
+        cs::host_draw_force(c.key_force, c.id_lo + (uint32_t)i, episode - 1u, c.force_mag, L.word == 4, f);
+      }
+      for (int j = 0; j < 3; ++j) force_xyz_host[(size_t)j * n + i] = f[j];
+    }
+    if (episode_host) episode_host[i] = episode;
     if (episode_return_host) {
       float f;
       std::memcpy(&f, h.at(i, L.ret_()), 4);
@@ -647,7 +907,7 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_set_state: episode_stats is disabled");
-  CS_HIP(hipSetDevice(ctx->cfg.device));
+  DeviceGuard guard_dev(ctx->cfg.device);
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
   const cs::Layout& L = ctx->layout;
   const size_t n = ctx->st.n;
@@ -662,8 +922,10 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
   const bool guard = ctx->cfg.state_mode == CS_STATE_F32G;
   for (size_t i = 0; i < n; ++i) {
     uint32_t meta = h.get_u32(i, L.meta());
+    uint32_t gT = h.get_u32(i, L.gT()), gR = h.get_u32(i, L.gR());
     if (x_host) {
-      uint32_t gw[3] = {0, 0, 0};
+      gT &= 3u << cs::kStatusShift;
+      gR = 0;
       for (int k = 0; k < 12; ++k) {
         const double v = x_host[(size_t)k * n + i];
         if (guard) {
@@ -671,17 +933,15 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
           uint32_t gb;
           f32g_encode(v, &w, &gb);
           std::memcpy(h.at(i, L.x(k)), &w, 4);
-          gw[k >> 2] |= gb << (8 * (k & 3));
+          (k < 6 ? gT : gR) |= gb << HostTiles::gshift(k);
         } else {
           h.set_word(i, L.x(k), v);
         }
       }
-      if (guard)
-        for (int j = 0; j < 3; ++j) h.set_u32(i, L.g(j), gw[j]);
     }
     if (status_host) {
       if (status_host[i] > 3) return fail(CS_ERR_ARG, "cs_set_state: status out of range");
-      meta = (meta & ~(3u << cs::kMetaStatusShift)) | ((uint32_t)status_host[i] << cs::kMetaStatusShift);
+      gT = (gT & ~(3u << cs::kStatusShift)) | ((uint32_t)status_host[i] << cs::kStatusShift);
     }
     if (steps_host) {
       if (steps_host[i] < 0 || steps_host[i] > (int32_t)cs::kMetaStepsMask)
@@ -692,10 +952,14 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
       meta = (meta & ~(cs::kMetaPerturbPending | cs::kMetaResetPending)) |
              ((flags_host[i] & 1) ? cs::kMetaPerturbPending : 0u) |
              ((flags_host[i] & 2) ? cs::kMetaResetPending : 0u);
+    if (force_xyz_host) {  // an explicitly installed force (Dynamics.perturb)
+      for (int j = 0; j < 3; ++j) h.set_word(i, L.f(j), force_xyz_host[(size_t)j * n + i]);
+      meta |= cs::kMetaExplicitForce;
+    }
+    h.set_u32(i, L.gT(), gT);
+    h.set_u32(i, L.gR(), gR);
     h.set_u32(i, L.meta(), meta);
     if (prev_shaping_host) h.set_word(i, L.prev(), prev_shaping_host[i]);
-    if (force_xyz_host)
-      for (int j = 0; j < 3; ++j) h.set_word(i, L.f(j), force_xyz_host[(size_t)j * n + i]);
     if (episode_host) h.set_u32(i, L.epi(), episode_host[i]);
     if (episode_return_host) {
       const float f = (float)episode_return_host[i];

@@ -12,24 +12,43 @@ namespace cs {
 
 // ---------------------------------------------------------------------------------
 // State layout in HBM: wavefront-tiled ("AoSoA", tile = one wavefront = 64 envs), with
-// the fields of one env grouped four to a 16-byte vector so that every access of the
-// step kernel is ONE 16-byte-per-lane instruction covering 1 KiB of contiguous memory:
+// the fields of one env grouped four words to a vector so that every access of the
+// step kernel is ONE 16-byte-per-lane instruction covering 1 KiB of contiguous memory
+// (float32 modes; float64 words double every group):
 //
-//   byte address = tiles + tile*tile_bytes + field.off + lane*field.stride
+//   byte address = tiles + tile*tile_bytes + group.off + lane*group.stride
 //
-//   X0  {x, dx, y, dy}            X1  {z, dz, phi, dphi}        X2  {theta, dtheta, psi, dpsi}
-//   GM  {guard0, guard1, guard2, meta}          (CS_STATE_F32G; otherwise META is a dword row)
+//   T1  {x, dx, y, dy}                        translational half of the rigid body ...
+//   T2  {z, dz, gT, meta}                     ... with its guard bits, flight status and counters
+//   R1  {phi, dphi, theta, dtheta}            rotational half ...
+//   R2  {psi, dpsi, gR, episode}              ... with its guard bits and the episode counter
 //   PS  prev_shaping (dword/qword row; NaN = upstream's None)
-//   FE  {force_x, force_y, force_z, episode}    pending reset perturbation [N] + episodes started
+//   FE  {force_x, force_y, force_z, 0}        EXPLICIT reset perturbation [N] (options['forces'],
+//                                             Dynamics.perturb); touched only while one is installed
 //   RET running episode return (dword row, episode_stats)
 //
-//   meta  = steps (bits 0..23) | flight status (24..25) | flags (28 perturbation pending,
-//           29 reset pending);   guard j = guard bytes of components 4j..4j+3.
+//   gT    = 5 guard bits of each of x, dx, y, dy, z, dz (bit 5j.. = slot j) | flight status (bits 30..31)
+//   gR    = 5 guard bits of each of phi .. dpsi         (bit 5j.. = slot 6+j)
+//   meta  = steps (bits 0..19) | perturbation pending (20) | perturbation is the explicit
+//           one of the FE group (21; otherwise it is the Philox draw of this episode) |
+//           reset pending (22, NEXT_STEP auto-reset)
+//   episode = episodes started so far (the Philox counter word of the reset draw)
 //
-// A wavefront therefore touches one contiguous 5.5 KB region, and every field is reached
-// from a per-lane base address with an instruction immediate.
+// In the float64 mode a group's third 8-byte word carries (gT or gR) in its low and (meta or
+// episode) in its high dword and the fourth word is unused; there are no guard bits.
+//
+// The split into a translational and a rotational half is the split of the physics itself:
+// within one Dynamics.setMotors() the two halves only READ each other (attitude -> thrust
+// direction), so the small-batch kernel gives them to two wavefronts (copterstep_kernels.hip).
+// A wavefront touches one contiguous 5.5 KB region, and every field is reached from a per-lane
+// base address with an instruction immediate.
 // ---------------------------------------------------------------------------------
 constexpr int kTileEnvs = 64;
+constexpr int kGuardBits = 5;                    // stored significand = 24 + 5 bits
+constexpr uint32_t kGuardFieldMask = 0x1Fu;
+constexpr int kGuardLsb = 24;                    // guard = bits 28..24 of the float64 mantissa's low dword
+constexpr uint32_t kGuardMaskLo = 0x1F000000u;   // those bits, as a mask of the low dword
+constexpr int kStatusShift = 30;                 // in gT
 
 struct Field {
   uint32_t off, stride;
@@ -37,17 +56,23 @@ struct Field {
 
 struct Layout {
   uint32_t word;          // bytes per float word (4 or 8)
-  bool guard;             // guard words present (GM group) or bare META row
-  uint32_t xg[3];         // offsets of the X0..X2 groups (lane stride 4*word)
-  uint32_t gm;            // GM group (lane stride 16) or META row (lane stride 4)
+  bool guard;             // guard bits kept (CS_STATE_F32G)
+  uint32_t grp[4];        // offsets of T1, T2, R1, R2 (lane stride 4*word)
   uint32_t ps, fe, ret;   // PS row (stride word), FE group (stride 4*word), RET row (stride 4)
   uint32_t tile_bytes;
-  constexpr Field x(int k) const { return {xg[k >> 2] + (uint32_t)(k & 3) * word, 4 * word}; }
-  constexpr Field g(int j) const { return {gm + (uint32_t)j * 4u, 16u}; }
-  constexpr Field meta() const { return guard ? Field{gm + 12u, 16u} : Field{gm, 4u}; }
+  // state slot k (0..11, upstream order) -> its word
+  constexpr Field x(int k) const {
+    const int grp_of[12] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 3, 3};
+    const int pos_of[12] = {0, 1, 2, 3, 0, 1, 0, 1, 2, 3, 0, 1};
+    return {grp[grp_of[k]] + (uint32_t)pos_of[k] * word, 4 * word};
+  }
+  // the four 32-bit integer words: gT, meta (T2), gR, episode (R2)
+  constexpr Field gT() const { return {grp[1] + 2 * word, 4 * word}; }
+  constexpr Field meta() const { return {grp[1] + (word == 4 ? 12u : 20u), 4 * word}; }
+  constexpr Field gR() const { return {grp[3] + 2 * word, 4 * word}; }
+  constexpr Field epi() const { return {grp[3] + (word == 4 ? 12u : 20u), 4 * word}; }
   constexpr Field prev() const { return {ps, word}; }
   constexpr Field f(int j) const { return {fe + (uint32_t)j * word, 4 * word}; }
-  constexpr Field epi() const { return {fe + 3u * word, 4 * word}; }
   constexpr Field ret_() const { return {ret, 4u}; }
 };
 
@@ -57,12 +82,10 @@ constexpr Layout make_layout(int mode) {
   l.guard = mode == CS_STATE_F32G;
   const uint32_t n = kTileEnvs;
   uint32_t o = 0;
-  for (int j = 0; j < 3; ++j) {
-    l.xg[j] = o;
+  for (int j = 0; j < 4; ++j) {
+    l.grp[j] = o;
     o += n * 4 * l.word;
   }
-  l.gm = o;
-  o += l.guard ? n * 16u : n * 4u;
   l.ps = o;
   o += n * l.word;
   l.fe = o;
@@ -73,10 +96,10 @@ constexpr Layout make_layout(int mode) {
   return l;
 }
 
-constexpr uint32_t kMetaStepsMask = 0x00FFFFFFu;
-constexpr int kMetaStatusShift = 24;
-constexpr uint32_t kMetaPerturbPending = 1u << 28;  // FE force not yet consumed by the physics
-constexpr uint32_t kMetaResetPending = 1u << 29;    // NEXT_STEP: env finished, reset on next step
+constexpr uint32_t kMetaStepsMask = 0x000FFFFFu;    // 20 bits
+constexpr uint32_t kMetaPerturbPending = 1u << 20;  // the episode's reset perturbation is not consumed yet
+constexpr uint32_t kMetaExplicitForce = 1u << 21;   // ... and it is the FE group's force, not the Philox draw
+constexpr uint32_t kMetaResetPending = 1u << 22;    // NEXT_STEP: env finished, reset on next step
 
 // Uniform (per-launch) constants, all float64, derived once on the host from cs_config.
 struct DevConst {
@@ -87,32 +110,47 @@ struct DevConst {
   double k_yaw;     //  D * (maxrpm*pi/30)^2 / Iz
   double G;
   double c_dphi, c_dthe, c_dpsi;  // (Iy-Iz)/Ix, (Iz-Ix)/Iy, (Ix-Iy)/Iz   :275-289
-  double dt;
   double two_inv_M;  // 2 / M: the reset perturbation enters the derivative twice (:263-271, :183)
+  // rotor-inertia (gyroscopic) term Jr * Omega: zero in the live model (Omega = 0, :135); the retired
+  // Mars model keeps Omega = u4(omegas) (attic/mars/dynamics/__init__.py:143)
+  double g_phi, g_the;  // Jr/Ix * maxrpm*pi/30,  Jr/Iy * maxrpm*pi/30
+  double dt;
   double land_vx, land_vy, land_ang;  // :71-73
   double bounds, max_angle, oob_penalty, z0, force_mag;
   double xyz_pen, yaw_pen, dz_max, dz_pen, target_r2, bonus;
   double reset_shaping;  // shaping potential of the reset state (NaN for Hover3D)
   int32_t max_steps, nsub, autoreset, tl_trunc, stats, status0;
-  uint32_t seed_lo, seed_hi;  // Philox key (the counter holds env id + episode number)
-  uint32_t id_lo, id_hi;      // global id of local env 0
-  uint32_t guard_mask;        // 0x1FE00000 (bits 28..21), kept in an SGPR for v_and_or_b32
+  uint32_t key_force, key_action;  // Philox keys (the counter holds env id + episode number)
+  uint32_t id_lo;                  // global id of local env 0
+  int32_t gyro;                    // 1 = the rotor-inertia term is live (full-featured kernels only)
+  int32_t act_f32;                 // 1 = NumPy's float32 evaluation of the motor model (f32_* below)
   uint32_t pad_;
+  // float32 motor model of a float32 action array under NumPy >= 2 promotion
+  // (dynamics/__init__.py:120-132 with `motors` a float32 ndarray): every scalar is the float32
+  // rounding of the Python value it multiplies or divides
+  float f32_maxrpm, f32_pi, f32_B, f32_LB, f32_D, f32_M, f32_Ix, f32_Iy, f32_Iz, f32_pad;
   // sin/cos constants: [0] 2/pi, [1..3] pi/2 in three pieces (33+33+53 bits, fdlibm
-  // pio2_1, pio2_2, pio2_2t), [4..9] S1..S6, [10..15] C1..C6 (fdlibm k_sin / k_cos)
-  double trig[16];
+  // pio2_1, pio2_2, pio2_2t), [4..9] S1..S6, [10..15] C1..C6 (fdlibm k_sin / k_cos),
+  // [16..19] / [20..24] the shorter minimax polynomials of the float32 state modes
+  double trig[25];
 };
 
-inline void trig_constants(double (&t)[16]) {
-  const double v[16] = {6.36619772367581382433e-01,  1.57079632673412561417e+00,
+inline void trig_constants(double (&t)[25]) {
+  const double v[25] = {6.36619772367581382433e-01,  1.57079632673412561417e+00,
                         6.07710050630396597660e-11,  2.02226624879595063154e-21,
                         -1.66666666666666324348e-01, 8.33333333332248946124e-03,
                         -1.98412698298579493134e-04, 2.75573137070700676789e-06,
                         -2.50507602534068634195e-08, 1.58969099521155010221e-10,
                         4.16666666666666019037e-02,  -1.38888888888741095749e-03,
                         2.48015872894767294178e-05,  -2.75573143513906633035e-07,
-                        2.08757232129817482790e-09,  -1.13596475577881948265e-11};
-  for (int i = 0; i < 16; ++i) t[i] = v[i];
+                        2.08757232129817482790e-09,  -1.13596475577881948265e-11,
+                        // sin(y) = y + y^3 * (s0 + s1 z + s2 z^2 + s3 z^3), z = y^2, |y| <= pi/4: 1.4e-11
+                        -0x1.555555545e43fp-3, 0x1.11110def9bd00p-7, -0x1.a013a80b71025p-13,
+                        0x1.6dbe28b3498d4p-19,
+                        // cos(y) = 1 + z * (c0 + c1 z + c2 z^2 + c3 z^3 + c4 z^4): 2.3e-13
+                        -0x1.fffffffffe699p-2, 0x1.5555555150044p-5, -0x1.6c16bae67d7a6p-10,
+                        0x1.a012993437ed5p-16, -0x1.2474f436b27edp-22};
+  for (int i = 0; i < 25; ++i) t[i] = v[i];
 }
 
 // Compile-time traits of the tasks (include/copterstep.h: CS_TASK_*).
@@ -142,12 +180,14 @@ struct PidConst {
 constexpr int kPidControllers = 6;  // roll rate, pitch rate, roll position, pitch position, yaw rate, altitude
 constexpr int kPidRows = 4 * kPidControllers;
 
+// per-env vehicle / world coefficient columns (cs_set_vehicle_params): rows of DevState::veh
+constexpr int kCoefRows = 11;  // k_thrust, k_roll, k_pitch, k_yaw, G, c_dphi, c_dthe, c_dpsi, two_inv_M, g_phi, g_the
+
 struct DevState {
   char* tiles;      // ntiles * tile_bytes
   uint32_t n;       // envs
   uint32_t ntiles;  // allocated tiles: a multiple of 4 that covers the whole launch grid
-  // per-env vehicle / world coefficients (cs_set_vehicle_params): [9][veh_stride] float64 rows
-  // k_thrust, k_roll, k_pitch, k_yaw, G, c_dphi, c_dthe, c_dpsi, two_inv_M; nullptr = uniform
+  // [kCoefRows][veh_stride] float64 rows; nullptr = uniform
   const double* veh;
   uint32_t veh_stride;
 #ifdef CS_STAMPS
@@ -155,8 +195,17 @@ struct DevState {
 #endif
 };
 
+// Launcher choices that depend on the batch size (see launch_step); 0 = built-in default.
+struct Tuning {
+  uint32_t split_max_envs;      // <= this many envs: two wavefronts per tile (translational + rotational)
+  uint32_t nt_action_max_envs;  // <= this many envs: action rows are loaded with the non-temporal hint
+  uint32_t nt_state_min_envs;   // >= this many envs: the state is streamed past the caches
+};
+
+Tuning default_tuning();
+
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
-                       const cs_step_io& io, hipStream_t stream);
+                       const cs_step_io& io, const Tuning& tune, hipStream_t stream);
 // policy 0: open loop, `actions` is the [K,N,A] input.  1: closed loop under the on-device PID
 // heuristic (`pid`, `pid_state` required).  2: on-device U[-1,1) random policy.  For 1 and 2
 // `actions` is an optional [K,N,A] output.
@@ -173,5 +222,17 @@ hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s
                         const uint8_t* mask, const float* force_xyz, float* obs,
                         double* pid_state, uint32_t pid_stride, const float* pose, int perturb,
                         hipStream_t stream);
+// Dynamics.perturb() for the envs with mask[i] != 0 (nullptr = all): install force_xyz [3,N] newtons
+// as the pending explicit perturbation.
+hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* mask,
+                                   const float* force_xyz, hipStream_t stream);
+// Running episode statistics: stats[0] = envs, [1] = envs airborne, [2] = sum of steps, [3] = max steps,
+// [4] = episodes started (sum), [5] = running episode return (sum; needs episode_stats), as float64.
+hipError_t launch_episode_stats(int mode, const DevState& s, double* stats_dev, hipStream_t stream);
+
+// The Philox2x32-10 reset-force draw, restated for the host (cs_get_state reports the pending force
+// of an env whose perturbation is the Philox one).
+void host_draw_force(uint32_t key, uint32_t env_id, uint32_t episode, double force_mag, bool f32_words,
+                     double (&f)[3]);
 
 }  // namespace cs

@@ -1,13 +1,22 @@
 // copterstep_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for the
-// gym-copter rigid-body hot path.  One thread = one environment, one wavefront = one
-// 64-env tile of the wavefront-tiled struct-of-arrays state (copterstep_internal.h), the
-// whole of _Task.step() fused into ONE kernel:
+// gym-copter rigid-body hot path.  One thread = one environment, one tile = 64 envs of the
+// wavefront-tiled struct-of-arrays state (copterstep_internal.h), the whole of _Task.step()
+// fused into ONE kernel:
 //
 //   action clip -> motor model -> body-Z->NED rotation -> flight-status machine ->
-//   forward-Euler integrate (x substeps) -> reward / termination -> (auto-reset with a
-//   Philox2x32-10 perturbation draw) -> AoS observation row written through a
-//   per-wavefront LDS transpose as full 16-byte-per-lane stores -> wave-ballot
-//   compaction of the finished-episode list.
+//   forward-Euler integrate (x substeps) -> reward / termination -> (auto-reset; the reset
+//   perturbation is a Philox2x32-10 draw evaluated where it is consumed) -> AoS observation row
+//   written through a per-wavefront LDS transpose as full 16-byte-per-lane stores ->
+//   wave-ballot compaction of the finished-episode list.
+//
+// Two forms of that kernel:
+//   step_kernel        one wavefront per tile.  Batches that give every SIMD two or more wavefronts.
+//   step_split_kernel  two wavefronts per tile, one integrating the translational half of the rigid
+//                      body (x..dz: thrust direction, ground contact, position shaping) and one the
+//                      rotational half (phi..dpsi: torques, tilt, yaw shaping); they meet once, through
+//                      LDS, for the reward.  A lone wavefront issues one instruction per ~5.5 cycles
+//                      whatever its type (tools/ubench.hip), a SIMD takes two such streams at once: at
+//                      65 536 envs (one tile per SIMD) the split halves the issue-bound part of the step.
 //
 // Upstream semantics followed (paths relative to the upstream checkout):
 //   dynamics/__init__.py:114-197 (setMotors), :249-290 (state derivative),
@@ -17,13 +26,18 @@
 // Numerics: all arithmetic is float64 in registers (the thrust-minus-gravity term and
 // the motor-difference torques are catastrophic cancellations in float32); only the
 // stored state words are float32 (CS_STATE_F32G / _F32_RN) or float64 (CS_STATE_F64).
-// The default CS_STATE_F32G keeps, next to each float32 word, 8 guard bits (the next 8
-// mantissa bits, four components packed per dword), so that 1000 forward-Euler
+// The default CS_STATE_F32G keeps, next to each float32 word, 5 guard bits (the next 5
+// mantissa bits, six components packed per dword), so that 1000 forward-Euler
 // accumulations x += dt*dxdt do not stagnate when dt*dxdt << ulp(x).
 // This is an elementwise ODE: no MFMA.
 #include <type_traits>
 
 #include "copterstep_internal.h"
+
+// every multiply-add below is written out (fma / explicit products): the one-step, the split and the
+// K-step kernels must round identically, which an optimiser's per-context choice of fused operations
+// would break
+#pragma clang fp contract(off)
 
 namespace cs {
 namespace {
@@ -38,7 +52,7 @@ namespace {
     unsigned long long t_;                                                          \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
     __builtin_amdgcn_sched_barrier(0);                                              \
-    if (lane == 0 && s.stamps) s.stamps[(size_t)(i >> 6) * 8 + (slot)] = t_;        \
+    if (lane == 0 && s.stamps) s.stamps[(size_t)tile_index * 8 + (slot)] = t_;      \
   } while (0)
 #else
 #define CS_STAMP(slot) ((void)0)
@@ -50,13 +64,20 @@ constexpr int kWave = 64;
 template <int MODE>
 struct ModeOf {
   using T = float;
+  using W = uint32_t;  // a state word as raw bits
   static constexpr Layout L = make_layout(MODE);
 };
 template <>
 struct ModeOf<CS_STATE_F64> {
   using T = double;
+  using W = unsigned long long;
   static constexpr Layout L = make_layout(CS_STATE_F64);
 };
+
+__device__ __forceinline__ float as_word(uint32_t w) { return __uint_as_float(w); }
+__device__ __forceinline__ double as_word(unsigned long long w) { return __longlong_as_double((long long)w); }
+__device__ __forceinline__ uint32_t as_bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ unsigned long long as_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 
 // caller-owned arrays: uniform base + 32-bit byte offset (global saddr + voffset addressing)
 template <class U, class P>
@@ -68,17 +89,20 @@ __device__ __forceinline__ U* at32(P* base, uint32_t byte_off) {
 // flags) pass through once: stored as streams they do not displace the env state, which the
 // same XCD re-reads every step (workgroup -> XCD assignment is the same in every launch), from
 // that XCD's L2 -- measured -5 % time from 131 072 to 1 M envs.  Action rows are loaded as
-// streams only for batches whose state fits the L2s (kNtActionMaxEnvs): there it keeps a long
-// ring of action tensors from evicting the state (-5 % at 65 536 envs with a 64-deep ring); for
+// streams only for batches whose state fits the L2s (Tuning::nt_action_max_envs): there it keeps a
+// long ring of action tensors from evicting the state (-5 % at 65 536 envs with a 64-deep ring); for
 // larger batches a non-temporal load is slower than a plain one (+2..7 %).  tools/ab.sh.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define CS_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
 constexpr uint32_t kNtActionMaxEnvs = 98304;
-// From this batch size the env state (88 B per env) no longer fits the 256 MiB Infinity Cache;
+// From this batch size the env state no longer fits the 256 MiB Infinity Cache;
 // streaming it (non-temporal loads and stores) measured -17 % time at 4 M envs and -14 % at 16 M
 // under reset churn, but +7..25 % at 1 M envs and below, where the caches do hold it.
 constexpr uint32_t kNtStateMinEnvs = 3670016;  // 3.5 M (3 M envs still measured 5..10 % better un-streamed)
+// Up to this batch size a tile gets two wavefronts (step_split_kernel): beyond it every SIMD already
+// holds two or more one-wavefront tiles and the split only adds its hand-over.
+constexpr uint32_t kSplitMaxEnvs = 98304;
 
 template <bool STREAM, class V>
 __device__ __forceinline__ V load_maybe_stream(const V* p) {
@@ -94,30 +118,29 @@ struct alignas(4 * sizeof(T)) Vec4 {
   T v[4];
 };
 
-// Per-lane view of this wavefront's tile.  Every field is base + immediate: the bases are
-// biased by kBias so that all offsets fit the signed 13-bit immediate of global_load/store,
-// and a whole 4-word group moves as one 16-byte-per-lane instruction (float32 modes).
+// Per-lane view of one tile.  The tile base is wave-uniform (64-bit, scalar registers), the lane
+// offset is 32-bit and biased by kBias so that every field offset fits the signed 13-bit immediate of
+// global_load/store (float32 modes), and a whole 4-word group moves as one 16-byte-per-lane
+// instruction.
 constexpr int kBias = 4096;
 
-// STREAM: the 16-byte state / guard / FE groups are accessed with the non-temporal hint
-// (batches whose state exceeds the 256 MiB Infinity Cache: see launch_step).
+// STREAM: the state groups are accessed with the non-temporal hint (batches whose state exceeds the
+// 256 MiB Infinity Cache: see launch_step).
 template <int MODE, bool STREAM = false>
 struct TileIO {
   using T = typename ModeOf<MODE>::T;
+  using W = typename ModeOf<MODE>::W;
+  using Group = Vec4<W>;
   static constexpr Layout L = ModeOf<MODE>::L;
-  static constexpr bool kWholeRowFe = STREAM;
-  char* b16;  // lane stride 16      (GM group)
-  char* bg;   // lane stride 4*word  (X0..X2, FE groups)
-  char* b4;   // lane stride 4       (RET row, bare META row)
-  char* bw;   // lane stride word    (PS row)
+  char* bg;  // lane stride 4*word  (T1, T2, R1, R2, FE groups)
+  char* b4;  // lane stride 4       (RET row)
+  char* bw;  // lane stride word    (PS row)
 
-  __device__ __forceinline__ TileIO(const DevState& s, uint32_t i) {
-    const uint32_t lane = i & 63u;
-    const uint32_t off = (i >> 6) * L.tile_bytes + kBias;
-    b16 = s.tiles + (off + lane * 16u);
-    bg = s.tiles + (off + lane * (4u * L.word));
-    b4 = s.tiles + (off + lane * 4u);
-    bw = s.tiles + (off + lane * L.word);
+  __device__ __forceinline__ TileIO(const DevState& s, uint32_t tile, uint32_t lane) {
+    char* tb = s.tiles + (size_t)tile * L.tile_bytes;  // wave-uniform: scalar arithmetic, 64-bit
+    bg = tb + (uint32_t)(kBias + lane * (4u * L.word));
+    b4 = tb + (uint32_t)(kBias + lane * 4u);
+    bw = tb + (uint32_t)(kBias + lane * L.word);
   }
   template <class U>
   static __device__ __forceinline__ U ld(const char* p, uint32_t off) {
@@ -140,76 +163,40 @@ struct TileIO {
       *reinterpret_cast<U*>(p + ((int)off - kBias)) = v;
     }
   }
-
-  // 12 state words, 3 guard words, meta: 4 vector loads (float32 + guard mode)
-  __device__ __forceinline__ void load_state(T (&raw)[12], uint32_t (&g)[3], uint32_t& meta) const {
-    if constexpr (L.guard) {
-      const Vec4<uint32_t> gm = ld<Vec4<uint32_t>>(b16, L.gm);
-      g[0] = gm.v[0];
-      g[1] = gm.v[1];
-      g[2] = gm.v[2];
-      meta = gm.v[3];
-    } else {
-      g[0] = g[1] = g[2] = 0;
-      meta = ld<uint32_t>(b4, L.gm);
-    }
-    // attitude groups first: the physics needs the angles before anything else
-    const int order[3] = {1, 2, 0};
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-      const int j = order[jj];
-      const Vec4<T> v = ld<Vec4<T>>(bg, L.xg[j]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) raw[4 * j + k] = v.v[k];
-    }
-  }
-  __device__ __forceinline__ void store_state(const T (&w)[12], const uint32_t (&g)[3],
-                                              uint32_t meta) const {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      Vec4<T> v;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v.v[k] = w[4 * j + k];
-      st(bg, L.xg[j], v);
-    }
-    if constexpr (L.guard) {
-      Vec4<uint32_t> gm;
-      gm.v[0] = g[0];
-      gm.v[1] = g[1];
-      gm.v[2] = g[2];
-      gm.v[3] = meta;
-      st(b16, L.gm, gm);
-    } else {
-      st(b4, L.gm, meta);
-    }
-  }
+  __device__ __forceinline__ Group load_group(int j) const { return ld<Group>(bg, L.grp[j]); }
+  __device__ __forceinline__ void store_group(int j, const Group& g) const { st(bg, L.grp[j], g); }
   __device__ __forceinline__ T load_prev() const { return ld<T>(bw, L.ps); }
   __device__ __forceinline__ void store_prev(T v) const { st(bw, L.ps, v); }
   __device__ __forceinline__ float load_ret() const { return ld<float>(b4, L.ret); }
   __device__ __forceinline__ void store_ret(float v) const { st(b4, L.ret, v); }
-  // FE group: pending force [N] + episodes started (kept in the low 32 bits of word 3).
-  // Returned raw so that nothing forces a wait on this (second-round) load before its use.
-  __device__ __forceinline__ Vec4<T> load_fe() const { return ld<Vec4<T>>(bg, L.fe); }
-  static __device__ __forceinline__ uint32_t episode_of(const Vec4<T>& v) {
-    if constexpr (sizeof(T) == 4) {
-      return __float_as_uint((float)v.v[3]);
+  // FE group: the EXPLICIT pending force [N] (plain accesses: rare)
+  __device__ __forceinline__ Vec4<T> load_fe() const {
+    return *reinterpret_cast<const Vec4<T>*>(bg + ((int)L.fe - kBias));
+  }
+  __device__ __forceinline__ void store_fe(const Vec4<T>& v) const {
+    *reinterpret_cast<Vec4<T>*>(bg + ((int)L.fe - kBias)) = v;
+  }
+
+  // the two integer words of a T2 / R2 group
+  static __device__ __forceinline__ uint32_t int_lo(const Group& g) {  // gT or gR
+    return (uint32_t)g.v[2];
+  }
+  static __device__ __forceinline__ uint32_t int_hi(const Group& g) {  // meta or episode
+    if constexpr (sizeof(W) == 4) {
+      return g.v[3];
     } else {
-      return (uint32_t)(unsigned long long)__double_as_longlong((double)v.v[3]);
+      return (uint32_t)(g.v[2] >> 32);
     }
   }
-  static __device__ __forceinline__ Vec4<T> make_fe(const double (&f)[3], uint32_t episode) {
-    Vec4<T> v;
-    v.v[0] = (T)f[0];
-    v.v[1] = (T)f[1];
-    v.v[2] = (T)f[2];
-    if constexpr (sizeof(T) == 4) {
-      v.v[3] = (T)__uint_as_float(episode);
+  static __device__ __forceinline__ void set_ints(Group& g, uint32_t lo, uint32_t hi) {
+    if constexpr (sizeof(W) == 4) {
+      g.v[2] = lo;
+      g.v[3] = hi;
     } else {
-      v.v[3] = (T)__longlong_as_double((long long)(unsigned long long)episode);
+      g.v[2] = (W)lo | ((W)hi << 32);
+      g.v[3] = 0;
     }
-    return v;
   }
-  __device__ __forceinline__ void store_fe(const Vec4<T>& v) const { st(bg, L.fe, v); }
 };
 
 // ---------------------------------------------------------------------------------
@@ -221,9 +208,9 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t& o0, uint32_t& o1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi = __umulhi(0xD256D193U, c0), lo = 0xD256D193U * c0;
-    c0 = hi ^ key ^ c1;
-    c1 = lo;
+    const unsigned long long p = (unsigned long long)0xD256D193U * c0;  // one v_mad_u64_u32
+    c0 = (uint32_t)(p >> 32) ^ key ^ c1;
+    c1 = (uint32_t)p;
     key += 0x9E3779B9U;
   }
   o0 = c0;
@@ -232,67 +219,54 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 // Reset perturbation force (task.py:177-188, :199-202): three U[-F, F) draws keyed by
 // (seed, global env id, this env's episode number) -- a pure function of those three,
-// so it is invariant to batch size, sharding, launch history and hipGraph replay.
-// counter = (global env id, episode), key = seed_lo ^ seed_hi; the 64 output bits give
-// three 21-bit uniforms.  u*2F and the subtraction are kept un-fused so the CPU oracle
-// reproduces the value bit-for-bit.
+// so it is invariant to batch size, sharding, launch history and hipGraph replay, and it can be
+// evaluated where it is consumed (the first integrating call of the episode) instead of being
+// stored.  counter = (global env id, episode), key = DevConst::key_force (a mix of the 64-bit
+// seed); the 64 output bits give three 21-bit uniforms.  u*2F and the subtraction are kept un-fused
+// and the result is rounded to the state word type, so the CPU oracle reproduces the value bit for bit.
+template <class T>
 __device__ __forceinline__ void draw_force(const DevConst& c, uint32_t i, uint32_t episode,
                                            double (&f)[3]) {
   uint32_t r0, r1;
-  philox2x32_10(c.id_lo + i, episode, c.seed_lo ^ c.seed_hi, r0, r1);
+  philox2x32_10(c.id_lo + i, episode, c.key_force, r0, r1);
   const uint32_t u[3] = {r0 >> 11, r1 >> 11, ((r0 & 0x7FFu) << 10) | (r1 & 0x3FFu)};
+  const double two_f = 2.0 * c.force_mag * 0x1.0p-21;  // power-of-two scaling: exact
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double v = (double)u[k] * 0x1.0p-21;
-    {
-#pragma clang fp contract(off)
-      const double scaled = v * (2.0 * c.force_mag);
-      f[k] = scaled - c.force_mag;
-    }
+    const double scaled = (double)u[k] * two_f;
+    f[k] = (double)(T)(scaled - c.force_mag);
   }
 }
 
 // On-device random policy: action ~ U[-1, 1)^4 on a 2^-15 grid (exact in float32), keyed by
 // (seed, global env id, episode number, step counter of the episode) -- again a pure function
 // of the env's own stored state, so it does not depend on batch size, sharding or how the steps
-// are grouped into launches.  counter = (global env id, episode), key = (seed_lo ^ seed_hi ^
-// 0x5DEECE66) + steps; the 64 output bits give four 16-bit uniforms.
+// are grouped into launches.  counter = (global env id, episode), key = DevConst::key_action +
+// steps; the 64 output bits give four 16-bit uniforms.
 __device__ __forceinline__ float4 draw_action(const DevConst& c, uint32_t i, uint32_t episode,
                                               uint32_t steps) {
   uint32_t r0, r1;
-  philox2x32_10(c.id_lo + i, episode, (c.seed_lo ^ c.seed_hi ^ 0x5DEECE66u) + steps, r0, r1);
+  philox2x32_10(c.id_lo + i, episode, c.key_action + steps, r0, r1);
   auto u = [](uint32_t bits) { return (float)bits * 0x1.0p-15f - 1.0f; };  // exact
   return make_float4(u(r0 >> 16), u(r0 & 0xFFFFu), u(r1 >> 16), u(r1 & 0xFFFFu));
 }
 
 // ---------------------------------------------------------------------------------
-// stored-word codec.  encode(): float64 register -> stored word (+ guard byte), and
-// the float64 value the stored representation decodes to (what the next step and
-// this step's reward/termination logic see).  decode() is its inverse.
+// stored-word codec.  CS_STATE_F32G: float32 word = value truncated to 24 significant bits; the
+// guard field holds significant bits 25..29, i.e. bits 28..24 of the float64 mantissa's low dword
+// (field j of a packed guard word sits at bit 5j).  round_stored() = float64 register -> the
+// float64 value the stored representation decodes to (what the next step and this step's
+// reward / termination logic see); split_stored() = that value -> word + guard field;
+// decode_word() the inverse.
 // ---------------------------------------------------------------------------------
 template <int MODE>
-struct Stored {
-  typename ModeOf<MODE>::T word;  // what goes to the state row
-  uint32_t guard;                 // CS_STATE_F32G: next 8 mantissa bits
-  double value;                   // exact value of (word, guard)
-};
-
-template <int MODE>
-__device__ __forceinline__ double decode_word(typename ModeOf<MODE>::T w, uint32_t gword, int k,
-                                              uint32_t guard_mask) {
+__device__ __forceinline__ double decode_word(typename ModeOf<MODE>::T w, uint32_t gword, int j) {
   if constexpr (MODE == CS_STATE_F32G) {
-    // float32 word = value truncated to 24 significant bits; the guard byte holds
-    // significant bits 25..32, i.e. bits 28..21 of the float64 mantissa.  Byte k&3 of the
-    // packed guard word is moved to bits 28..21 with one shift and one and-or.
-    const int sh = 21 - 8 * (k & 3);
+    const int sh = kGuardLsb - kGuardBits * j;  // field j -> bits 28..24: one shift and one and-or
     const uint32_t moved = sh >= 0 ? (gword << sh) : (gword >> -sh);
-    // lo |= moved & 0x1FE00000 as ONE instruction (the mask sits in an SGPR; the low dword of
-    // the converted word has only bits 31..29 possibly set)
     const double d = (double)w;
-    uint32_t lo;
-    asm("v_and_or_b32 %0, %1, %2, %3"
-        : "=v"(lo)
-        : "v"(moved), "s"(guard_mask), "v"((uint32_t)__double2loint(d)));
+    // the low dword of a converted float32 has only bits 31..29 possibly set
+    const uint32_t lo = (moved & kGuardMaskLo) | (uint32_t)__double2loint(d);
     return __hiloint2double(__double2hiint(d), (int)lo);
   } else {
     return (double)w;
@@ -300,55 +274,85 @@ __device__ __forceinline__ double decode_word(typename ModeOf<MODE>::T w, uint32
 }
 
 template <int MODE>
-__device__ __forceinline__ Stored<MODE> encode_word(double v) {
-  Stored<MODE> o;
-  o.guard = 0;
-  if constexpr (MODE == CS_STATE_F64) {
-    o.word = v;
-    o.value = v;
-  } else if constexpr (MODE == CS_STATE_F32_RN) {
-    o.word = (float)v;
-    o.value = (double)o.word;
-  } else {
-    // CS_STATE_F32G: round to 32 significant bits (add half of bit 21, the carry
-    // propagates through the exponent), then split: top 24 bits -> float32 word (exact
-    // conversion), next 8 -> guard byte.
-    unsigned long long b = (unsigned long long)__double_as_longlong(v) + (1ULL << 20);
-    o.guard = (uint32_t)(b >> 21) & 0xFFu;
-    o.word = (float)__longlong_as_double((long long)(b & ~0x1FFFFFFFULL));
-    o.value = __longlong_as_double((long long)(b & ~0x1FFFFFULL));
-  }
-  return o;
-}
-
-// The two halves of encode_word(), for code that keeps an env in registers over several steps:
-// round_stored() = the value the stored representation would decode to (all that the next
-// step needs); split_stored() = the word + guard byte of such a value, needed only when the
-// env finally goes back to HBM.
-template <int MODE>
 __device__ __forceinline__ double round_stored(double v) {
   if constexpr (MODE == CS_STATE_F64) {
     return v;
   } else if constexpr (MODE == CS_STATE_F32_RN) {
     return (double)(float)v;
   } else {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v) + (1ULL << 20);
-    return __longlong_as_double((long long)(b & ~0x1FFFFFULL));
+    // round to 29 significant bits: add half of bit 24 (the carry propagates through the
+    // exponent), clear bits 23..0
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v) + (1ULL << (kGuardLsb - 1));
+    return __longlong_as_double((long long)(b & ~((1ULL << kGuardLsb) - 1ULL)));
   }
 }
 
 template <int MODE>
-__device__ __forceinline__ void split_stored(double value, typename ModeOf<MODE>::T& word,
-                                             uint32_t& guard) {
-  using T = typename ModeOf<MODE>::T;
+__device__ __forceinline__ uint32_t guard_of(double value) {
   if constexpr (MODE == CS_STATE_F32G) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(value);
-    guard = (uint32_t)(b >> 21) & 0xFFu;
-    word = (float)__longlong_as_double((long long)(b & ~0x1FFFFFFFULL));
+    return ((uint32_t)__double2loint(value) >> kGuardLsb) & kGuardFieldMask;  // one v_bfe_u32
   } else {
-    guard = 0;
-    word = (T)value;
+    return 0u;
   }
+}
+
+// The twelve float32 words of twelve stored values in one go (CS_STATE_F32G): a stored value has 29
+// significant bits, its word is the value truncated to 24 -- v_cvt_f32_f64 under round-toward-zero
+// (the conversion follows MODE.fp_round[1:0], the float32 field: tools/ubench.hip), which saves the
+// and + register-pair copy per component that masking the low dword first would cost.
+__device__ __forceinline__ void words_of_rtz(const double (&v)[12], float (&w)[12]) {
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "s_nop 0\n\t"
+      "v_cvt_f32_f64 %0, %12\n\tv_cvt_f32_f64 %1, %13\n\tv_cvt_f32_f64 %2, %14\n\tv_cvt_f32_f64 %3, %15\n\t"
+      "v_cvt_f32_f64 %4, %16\n\tv_cvt_f32_f64 %5, %17\n\tv_cvt_f32_f64 %6, %18\n\tv_cvt_f32_f64 %7, %19\n\t"
+      "v_cvt_f32_f64 %8, %20\n\tv_cvt_f32_f64 %9, %21\n\tv_cvt_f32_f64 %10, %22\n\tv_cvt_f32_f64 %11, %23\n\t"
+      "s_nop 0\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]),
+        "=&v"(w[7]), "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+        "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]));
+}
+// six of them (one half of the rigid body)
+__device__ __forceinline__ void words_of_rtz6(const double* v, float* w) {
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+      "s_nop 0\n\t"
+      "v_cvt_f32_f64 %0, %6\n\tv_cvt_f32_f64 %1, %7\n\tv_cvt_f32_f64 %2, %8\n\t"
+      "v_cvt_f32_f64 %3, %9\n\tv_cvt_f32_f64 %4, %10\n\tv_cvt_f32_f64 %5, %11\n\t"
+      "s_nop 0\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]));
+}
+
+// float32 / float64 words of already rounded values
+template <int MODE>
+__device__ __forceinline__ void words12(const double (&v)[12], typename ModeOf<MODE>::T (&w)[12]) {
+  if constexpr (MODE == CS_STATE_F32G) {
+    words_of_rtz(v, w);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) w[k] = (typename ModeOf<MODE>::T)v[k];
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void words6(const double* v, typename ModeOf<MODE>::T* w) {
+  if constexpr (MODE == CS_STATE_F32G) {
+    words_of_rtz6(v, w);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = (typename ModeOf<MODE>::T)v[k];
+  }
+}
+// packed guard fields of six already rounded values (one v_bfe_u32 + one v_lshl_or_b32 each)
+template <int MODE>
+__device__ __forceinline__ uint32_t pack_guards6(const double* v) {
+  uint32_t g = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) g |= guard_of<MODE>(v[j]) << (kGuardBits * j);
+  return g;
 }
 
 // np.clip(a, 0, 1) incl. its NaN passthrough (v_med3_f32 alone would turn NaN into 0)
@@ -360,27 +364,42 @@ __device__ __forceinline__ float clip01(float a) {
 // ---------------------------------------------------------------------------------
 // float64 sin/cos and sqrt, sized for this kernel (no library slow paths, no scratch)
 // ---------------------------------------------------------------------------------
-// Cody-Waite reduction by pi/2 in three pieces (33+33+53 bits) + the fdlibm minimax
-// kernels: <= ~1 ulp for |x| < 2^19*pi/2.  Larger angles (not reached by a physical
-// trajectory: 8e5 rad) are first folded by multiples of 2^17 * 2pi, which keeps full
+// Cody-Waite reduction by pi/2 in three pieces (33+33+53 bits) + a polynomial kernel on
+// |y| <= pi/4: the fdlibm k_sin / k_cos minimax polynomials (<= ~1 ulp) where the state is kept in
+// float64 words (FULL), and two shorter ones (sin 1.4e-11, cos 2.3e-13 absolute) where it is
+// rounded to 29 or 24 significant bits anyway.  Larger angles than 2^19*pi/2 (not reached by a
+// physical trajectory: 8e5 rad) are first folded by multiples of 2^17 * 2pi, which keeps full
 // accuracy up to ~8e11 rad and degrades gracefully beyond.
-// sin and cos of a reduced argument |y| <= pi/4 (fdlibm k_sin / k_cos polynomials)
+template <bool FULL>
 __device__ __forceinline__ void sincos_kernel(const double* t, double y, double& sy, double& cy) {
   const double z = y * y;
-  double ps = fma(z, t[9], t[8]);
-  ps = fma(z, ps, t[7]);
-  ps = fma(z, ps, t[6]);
-  ps = fma(z, ps, t[5]);
-  ps = fma(z, ps, t[4]);
-  sy = fma(y * z, ps, y);
-  double pc = fma(z, t[15], t[14]);
-  pc = fma(z, pc, t[13]);
-  pc = fma(z, pc, t[12]);
-  pc = fma(z, pc, t[11]);
-  pc = fma(z, pc, t[10]);
-  cy = 1.0 - fma(0.5, z, -(z * z) * pc);
+  if constexpr (FULL) {
+    double ps = fma(z, t[9], t[8]);
+    ps = fma(z, ps, t[7]);
+    ps = fma(z, ps, t[6]);
+    ps = fma(z, ps, t[5]);
+    ps = fma(z, ps, t[4]);
+    sy = fma(y * z, ps, y);
+    double pc = fma(z, t[15], t[14]);
+    pc = fma(z, pc, t[13]);
+    pc = fma(z, pc, t[12]);
+    pc = fma(z, pc, t[11]);
+    pc = fma(z, pc, t[10]);
+    cy = 1.0 - fma(0.5, z, -(z * z) * pc);
+  } else {
+    double ps = fma(z, t[19], t[18]);
+    ps = fma(z, ps, t[17]);
+    ps = fma(z, ps, t[16]);
+    sy = fma(y * z, ps, y);
+    double pc = fma(z, t[24], t[23]);
+    pc = fma(z, pc, t[22]);
+    pc = fma(z, pc, t[21]);
+    pc = fma(z, pc, t[20]);
+    cy = fma(z, pc, 1.0);
+  }
 }
 
+template <bool FULL>
 __device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& s, double& c) {
   if (__builtin_expect(fabs(x) >= 8.0e5, 0)) {
     const double n1 = rint(x * (1.0 / (6.283185307179586476925 * 131072.0)));
@@ -390,7 +409,7 @@ __device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& 
     x = fma(-n1, 2.02226624879595063154e-21 * 524288.0, x);
   }
   // the constants come from the kernel-argument block (DevConst::trig, filled by
-  // trig_constants()): two wide scalar loads instead of ~32 literal moves per wavefront
+  // trig_constants()): wide scalar loads instead of literal moves per wavefront
   const double* t = k.trig;
   const double fn = rint(x * t[0]);
   double y = fma(-fn, t[1], x);
@@ -398,22 +417,50 @@ __device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& 
   y = fma(-fn, t[3], y);
   const int q = (int)fn;
   double sy, cy;
-  sincos_kernel(t, y, sy, cy);
+  sincos_kernel<FULL>(t, y, sy, cy);
   const double s0 = (q & 1) ? cy : sy;
   const double c0 = (q & 1) ? sy : cy;
   s = (q & 2) ? -s0 : s0;
   c = ((q + 1) & 2) ? -c0 : c0;
 }
 
-// sqrt for a >= 0: hardware v_rsq_f64 seed + two Heron corrections (<= 1 ulp);
-// 0, +inf and NaN pass through.
+// sin and cos of the three Euler angles.  Roll and pitch of a live env are inside +-pi/4 (the task
+// ends the episode beyond, task.py:116): when that holds for the whole wavefront the reduction is the
+// identity (fn = 0, y = x exactly) and is skipped -- bit-identical to the general path.  Yaw is
+// unbounded, but the yaw torque of this airframe is weak (D << B): it usually qualifies too.
+struct Trig {
+  double sph, cph, sth, cth, sps, cps;
+};
+template <bool FULL>
+__device__ __forceinline__ void sincos_roll_pitch(const DevConst& c, double phi, double the, Trig& t) {
+  if (__all(fabs(phi) < 0.785 && fabs(the) < 0.785)) {
+    sincos_kernel<FULL>(c.trig, phi, t.sph, t.cph);
+    sincos_kernel<FULL>(c.trig, the, t.sth, t.cth);
+  } else {
+    sincos_f64<FULL>(c, phi, t.sph, t.cph);
+    sincos_f64<FULL>(c, the, t.sth, t.cth);
+  }
+}
+template <bool FULL>
+__device__ __forceinline__ void sincos_yaw(const DevConst& c, double psi, Trig& t) {
+  if (__all(fabs(psi) < 0.785)) {
+    sincos_kernel<FULL>(c.trig, psi, t.sps, t.cps);
+  } else {
+    sincos_f64<FULL>(c, psi, t.sps, t.cps);
+  }
+}
+
+// sqrt for a >= 0: hardware v_rsq_f64 seed + Heron corrections; 0, +inf and NaN pass through.
+// STEPS = 2: <= 1 ulp.  STEPS = 1 (~2^-40 relative): the shaping potential, whose only consumers are a
+// float32 reward and a prev_shaping word of the state's precision.
+template <int STEPS>
 __device__ __forceinline__ double sqrt_f64(double a) {
   const double r = __builtin_amdgcn_rsq(a);
   double y = a * r;
   const double h = 0.5 * r;
-  y = fma(fma(-y, y, a), h, y);
-  y = fma(fma(-y, y, a), h, y);
-  return (a == 0.0 || a == __builtin_huge_val()) ? a : y;
+#pragma unroll
+  for (int k = 0; k < STEPS; ++k) y = fma(fma(-y, y, a), h, y);
+  return __builtin_amdgcn_class(a, 0x260) ? a : y;  // +-0 (0x20 | 0x40) and +inf (0x200)
 }
 
 // ---------------------------------------------------------------------------------
@@ -423,12 +470,12 @@ __device__ __forceinline__ double sqrt_f64(double a) {
 // uniform factor folded in on the host (see DevConst).  Uniform for the batch (scalar
 // registers) or, with cs_set_vehicle_params, one set per env (vector registers).
 struct Coef {
-  double k_thrust, k_roll, k_pitch, k_yaw, G, c_dphi, c_dthe, c_dpsi, two_inv_M;
+  double k_thrust, k_roll, k_pitch, k_yaw, G, c_dphi, c_dthe, c_dpsi, two_inv_M, g_phi, g_the;
 };
-constexpr int kCoefRows = 9;
 
 __device__ __forceinline__ Coef uniform_coef(const DevConst& c) {
-  return Coef{c.k_thrust, c.k_roll, c.k_pitch, c.k_yaw, c.G, c.c_dphi, c.c_dthe, c.c_dpsi, c.two_inv_M};
+  return Coef{c.k_thrust, c.k_roll, c.k_pitch, c.k_yaw, c.G, c.c_dphi, c.c_dthe, c.c_dpsi, c.two_inv_M,
+              c.g_phi, c.g_the};
 }
 
 // per-env coefficient columns: [kCoefRows][stride] float64, coalesced 8 B per lane
@@ -436,7 +483,7 @@ __device__ __forceinline__ Coef load_coef(const double* veh, uint32_t stride, ui
   double v[kCoefRows];
 #pragma unroll
   for (int j = 0; j < kCoefRows; ++j) v[j] = veh[(size_t)j * stride + i];
-  return Coef{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
+  return Coef{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10]};
 }
 
 struct Wrench {  // per-env, constant across substeps
@@ -444,24 +491,117 @@ struct Wrench {  // per-env, constant across substeps
   double aphi;   // U2 / Ix
   double athe;   // U3 / Iy
   double apsi;   // U4 / Iz
+  double om;     // u4(motor values): the rotor-inertia term's Omega / (maxrpm*pi/30) (GYRO builds)
 };
 
 // dynamics/__init__.py:120-132 + _u2/_u3/_u4 (:231-247).  The squares of the motor
 // values are exact in float64 (24-bit inputs); the uniform factors (maxrpm*pi/30)^2,
 // B, L*B, D and the 1/M, 1/I divisions are folded into one host-side constant each.
-__device__ __forceinline__ Wrench motor_model(const Coef& c, float a0, float a1, float a2,
-                                              float a3) {
+__device__ __forceinline__ double thrust_model(const Coef& c, float a0, float a1, float a2, float a3) {
   const double m0 = (double)a0, m1 = (double)a1, m2 = (double)a2, m3 = (double)a3;
   const double q0 = m0 * m0, q1 = m1 * m1, q2 = m2 * m2, q3 = m3 * m3;
-  Wrench w;
-  w.bz = c.k_thrust * (((q0 + q1) + q2) + q3);
+  return c.k_thrust * (((q0 + q1) + q2) + q3);
+}
+__device__ __forceinline__ void torque_model(const Coef& c, float a0, float a1, float a2, float a3,
+                                             Wrench& w) {
+  const double m0 = (double)a0, m1 = (double)a1, m2 = (double)a2, m3 = (double)a3;
+  const double q0 = m0 * m0, q1 = m1 * m1, q2 = m2 * m2, q3 = m3 * m3;
   w.aphi = c.k_roll * ((q1 + q2) - (q0 + q3));   // roll right
   w.athe = c.k_pitch * ((q1 + q3) - (q0 + q2));  // pitch forward
   w.apsi = c.k_yaw * ((q0 + q1) - (q2 + q3));    // yaw cw
-  return w;
+  w.om = (m0 + m1) - (m2 + m3);
+}
+
+// The same with NumPy's float32 evaluation (cs_config.action_arith = CS_ARITH_F32): what the
+// reference computes when `action` is a float32 ndarray -- omegas, their squares, U1..U4 and
+// the divisions by M and I all stay float32 (NumPy >= 2 promotion: a Python scalar adopts the
+// array's dtype), and only then meet the float64 state.  dynamics/__init__.py:120-132, :143,
+// :275-289.
+__device__ __forceinline__ Wrench motor_model_f32(const DevConst& c, float a0, float a1, float a2,
+                                                  float a3) {
+  const float m[4] = {a0, a1, a2, a3};
+  float w2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float w = ((m[j] * c.f32_maxrpm) * c.f32_pi) / 30.0f;
+    w2[j] = w * w;
+  }
+  const float U1 = c.f32_B * (((0.0f + w2[0]) + w2[1]) + w2[2] + w2[3]);
+  const float U2 = c.f32_LB * ((w2[1] + w2[2]) - (w2[0] + w2[3]));
+  const float U3 = c.f32_LB * ((w2[1] + w2[3]) - (w2[0] + w2[2]));
+  const float U4 = c.f32_D * ((w2[0] + w2[1]) - (w2[2] + w2[3]));
+  Wrench r;
+  r.bz = (double)(-U1 / c.f32_M);
+  r.aphi = (double)(U2 / c.f32_Ix);
+  r.athe = (double)(U3 / c.f32_Iy);
+  r.apsi = (double)(U4 / c.f32_Iz);
+  r.om = 0.0;
+  return r;
 }
 
 enum { kCallOther = 0, kCallIntegrated = 1, kCallFroze = 2 };
+
+// What one Dynamics.setMotors() call does, from the state BEFORE it (dynamics/__init__.py:145-177):
+//   netz < 0 lifts a LANDED body off; LEVELING -> wings level + LANDED; AIRBORNE with z > 0 and
+//   dz > 0 is ground contact: freeze (no integrate, perturbation kept), CRASHED or LEVELING
+//   (upstream tests dz against LANDING_VEL_Y and |dy| against LANDING_VEL_X, :166-171).
+struct CallPlan {
+  bool leveling, contact, integ;
+  int fs_next;
+};
+__device__ __forceinline__ CallPlan plan_call(const DevConst& c, int fs, double netz, double z, double dz,
+                                              double dy, double phi) {
+  if (fs == CS_STATUS_LANDED && netz < 0.0) fs = CS_STATUS_AIRBORNE;
+  CallPlan p;
+  p.leveling = fs == CS_STATUS_LEVELING;
+  const bool air = fs == CS_STATUS_AIRBORNE;
+  p.contact = air && z > 0.0 && dz > 0.0;
+  const bool hard = dz > c.land_vy || fabs(dy) > c.land_vx || fabs(phi) > c.land_ang;
+  p.integ = air && !p.contact;
+  p.fs_next = p.leveling ? CS_STATUS_LANDED
+                         : (p.contact ? (hard ? CS_STATUS_CRASHED : CS_STATUS_LEVELING) : fs);
+  return p;
+}
+
+// body-Z -> NED (dynamics/__init__.py:292-302) and net vertical acceleration (:143)
+__device__ __forceinline__ void thrust_ned(const Coef& q, double bz, const Trig& t, double& ax, double& ay,
+                                           double& netz) {
+  ax = bz * fma(t.cph * t.cps, t.sth, t.sph * t.sps);
+  ay = bz * fma(t.cph * t.sps, t.sth, -(t.cps * t.sph));
+  netz = fma(bz, t.cph * t.cth, q.G);
+}
+
+// forward Euler of the translational half (slots 0..5) with the (doubled) pending perturbation
+__device__ __forceinline__ void euler_translation(double dt, double ax, double ay, double netz, double px,
+                                                  double py, double pz, double* x) {
+  x[0] = fma(dt, x[1], x[0]);
+  x[2] = fma(dt, x[3], x[2]);
+  x[4] = fma(dt, x[5], x[4]);
+  x[1] = fma(dt, ax + px, x[1]);
+  x[3] = fma(dt, ay + py, x[3]);
+  x[5] = fma(dt, netz + pz, x[5]);
+}
+
+// state derivative (:273-289) + forward Euler of the rotational half: r[0..5] = phi, dphi, theta,
+// dtheta, psi, dpsi
+template <bool GYRO>
+__device__ __forceinline__ void euler_rotation(const Coef& q, const Wrench& w, double dt, bool leveling,
+                                               double* r) {
+  const double dphi = r[1], dthe = r[3], dpsi = r[5];
+  double d7 = fma(dpsi * dthe, q.c_dphi, w.aphi);
+  double d9s = fma(dpsi * dphi, q.c_dthe, w.athe);
+  if constexpr (GYRO) {  // - Jr/Ix*dthe*Omega, + Jr/Iy*dphi*Omega (inside the negated sum)
+    d7 = fma(-(q.g_phi * dthe), w.om, d7);
+    d9s = fma(q.g_the * dphi, w.om, d9s);
+  }
+  const double d11 = fma(dthe * dphi, q.c_dpsi, w.apsi);
+  r[0] = leveling ? 0.0 : fma(dt, dphi, r[0]);
+  r[2] = leveling ? 0.0 : fma(dt, dthe, r[2]);
+  r[4] = fma(dt, dpsi, r[4]);
+  r[1] = fma(dt, d7, r[1]);
+  r[3] = fma(dt, -d9s, r[3]);
+  r[5] = fma(dt, d11, r[5]);
+}
 
 // One Dynamics.setMotors() (dynamics/__init__.py:134-197) on the register-resident
 // state, written branch-free: every lane evaluates the derivative, and lanes that do
@@ -469,75 +609,38 @@ enum { kCallOther = 0, kCallIntegrated = 1, kCallFroze = 2 };
 // (px,py,pz) = 2*force/M, the pending reset perturbation in its doubled form (upstream
 // adds it inside the derivative, :263-271, and again at :183), zero when none is
 // pending.  Returns what the call did.
+template <bool FULL, bool GYRO>
 __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, const Wrench& w,
                                             double (&x)[12], int& fs, double px, double py,
                                             double pz) {
-  double sph, cph, sth, cth, sps, cps;
-  // roll and pitch of a live env are inside +-pi/4 (the task ends the episode beyond,
-  // task.py:116): when that holds for the whole wavefront the reduction is the identity
-  // (fn = 0, y = x exactly) and is skipped -- bit-identical to the general path
-  if (__all(fabs(x[6]) < 0.785 && fabs(x[8]) < 0.785)) {
-    sincos_kernel(c.trig, x[6], sph, cph);
-    sincos_kernel(c.trig, x[8], sth, cth);
-  } else {
-    sincos_f64(c, x[6], sph, cph);
-    sincos_f64(c, x[8], sth, cth);
-  }
-  // yaw is unbounded, but the yaw torque of this airframe is weak (D << B): it usually qualifies too
-  if (__all(fabs(x[10]) < 0.785)) {
-    sincos_kernel(c.trig, x[10], sps, cps);
-  } else {
-    sincos_f64(c, x[10], sps, cps);
-  }
-  const double ax = w.bz * fma(cph * cps, sth, sph * sps);
-  const double ay = w.bz * fma(cph * sps, sth, -(cps * sph));
-  const double netz = fma(w.bz, cph * cth, q.G);
-
-  if (fs == CS_STATUS_LANDED && netz < 0.0) fs = CS_STATUS_AIRBORNE;
-  const bool leveling = fs == CS_STATUS_LEVELING;
-  const bool air = fs == CS_STATUS_AIRBORNE;
-  // ground contact: freeze (no integrate, perturbation kept).  Upstream tests dz against
-  // LANDING_VEL_Y and |dy| against LANDING_VEL_X (:166-171).
-  const bool contact = air && x[4] > 0.0 && x[5] > 0.0;
-  const bool hard = x[5] > c.land_vy || fabs(x[3]) > c.land_vx || fabs(x[6]) > c.land_ang;
-  const bool integ = air && !contact;
-
-  const double dt = integ ? c.dt : 0.0;
-  const double dphi = x[7], dthe = x[9], dpsi = x[11];
-  const double d7 = fma(dpsi * dthe, q.c_dphi, w.aphi);
-  const double d9 = -fma(dpsi * dphi, q.c_dthe, w.athe);
-  const double d11 = fma(dthe * dphi, q.c_dpsi, w.apsi);
-  x[0] = fma(dt, x[1], x[0]);
-  x[2] = fma(dt, x[3], x[2]);
-  x[4] = fma(dt, x[5], x[4]);
-  x[6] = leveling ? 0.0 : fma(dt, dphi, x[6]);
-  x[8] = leveling ? 0.0 : fma(dt, dthe, x[8]);
-  x[10] = fma(dt, dpsi, x[10]);
-  x[1] = fma(dt, ax + px, x[1]);
-  x[3] = fma(dt, ay + py, x[3]);
-  x[5] = fma(dt, netz + pz, x[5]);
-  x[7] = fma(dt, d7, x[7]);
-  x[9] = fma(dt, d9, x[9]);
-  x[11] = fma(dt, d11, x[11]);
-
-  fs = leveling ? CS_STATUS_LANDED
-                : (contact ? (hard ? CS_STATUS_CRASHED : CS_STATUS_LEVELING) : fs);
-  return integ ? kCallIntegrated : (contact ? kCallFroze : kCallOther);
+  Trig t;
+  sincos_roll_pitch<FULL>(c, x[6], x[8], t);
+  sincos_yaw<FULL>(c, x[10], t);
+  double ax, ay, netz;
+  thrust_ned(q, w.bz, t, ax, ay, netz);
+  const CallPlan p = plan_call(c, fs, netz, x[4], x[5], x[3], x[6]);
+  const double dt = p.integ ? c.dt : 0.0;
+  euler_translation(dt, ax, ay, netz, px, py, pz, x);
+  euler_rotation<GYRO>(q, w, dt, p.leveling, x + 6);
+  fs = p.fs_next;
+  return p.integ ? kCallIntegrated : (p.contact ? kCallFroze : kCallOther);
 }
 
-// `nsub` x Dynamics.setMotors with one wrench.  The pending perturbation (pend, force
-// f[] in newtons) can only enter the FIRST call: a call that freezes on ground contact
-// keeps it, but the status it leaves (CRASHED / LEVELING) makes the next call drop it.
-template <class T>
+// `nsub` x Dynamics.setMotors with one wrench.  The pending perturbation can only enter the FIRST
+// call: a call that freezes on ground contact keeps it, but the status it leaves (CRASHED / LEVELING)
+// makes the next call drop it.
+template <bool FULL, bool GYRO>
 __device__ __forceinline__ void physics_substeps(const DevConst& c, const Coef& q, const Wrench& w,
-                                                 double (&x)[12], int& fs, bool& pend,
-                                                 const Vec4<T>& f) {
-  double px = pend ? (double)f.v[0] * q.two_inv_M : 0.0;
-  double py = pend ? (double)f.v[1] * q.two_inv_M : 0.0;
-  double pz = pend ? (double)f.v[2] * q.two_inv_M : 0.0;
+                                                 double (&x)[12], int& fs, bool& pend, double px,
+                                                 double py, double pz) {
+  if (c.nsub == 1) {  // upstream's own configuration: no loop
+    const int what = physics_call<FULL, GYRO>(c, q, w, x, fs, px, py, pz);
+    pend = pend && what == kCallFroze;
+    return;
+  }
 #pragma clang loop unroll(disable)
   for (int sub = 0; sub < c.nsub; ++sub) {
-    const int what = physics_call(c, q, w, x, fs, px, py, pz);
+    const int what = physics_call<FULL, GYRO>(c, q, w, x, fs, px, py, pz);
     // a call that froze keeps the perturbation (upstream's early return); it is inert
     // there (dt = 0) and the next call, which cannot integrate either, drops it
     const bool keep = pend && what == kCallFroze;
@@ -548,16 +651,18 @@ __device__ __forceinline__ void physics_substeps(const DevConst& c, const Coef& 
   }
 }
 
-// Lander shaping potential (lander.py:48-57) on the stored state.
-// (every multiply-add is written out, with contraction off: the one-step and the K-step kernels
-// must round identically, which an optimiser's per-context choice of fused operations would break)
-__device__ __forceinline__ double lander_shaping(const DevConst& c, const double (&x)[12]) {
-#pragma clang fp contract(off)
+// Lander shaping potential (lander.py:48-57) on the stored state, in its two parts
+__device__ __forceinline__ double shaping_position(const DevConst& c, const double* x) {  // x[0..5]
   double s6 = x[0] * x[0];
 #pragma unroll
   for (int k = 1; k < 6; ++k) s6 = fma(x[k], x[k], s6);
-  const double s2 = fma(x[11], x[11], x[10] * x[10]);
-  double sh = -fma(c.xyz_pen, sqrt_f64(s6), c.yaw_pen * sqrt_f64(s2));
+  return c.xyz_pen * sqrt_f64<1>(s6);
+}
+__device__ __forceinline__ double shaping_yaw(const DevConst& c, double psi, double dpsi) {
+  return c.yaw_pen * sqrt_f64<1>(fma(dpsi, dpsi, psi * psi));
+}
+__device__ __forceinline__ double lander_shaping(const DevConst& c, const double (&x)[12]) {
+  double sh = -(shaping_position(c, x) + shaping_yaw(c, x[10], x[11]));
   if (fabs(x[5]) > c.dz_max) sh -= c.dz_pen;
   return sh;
 }
@@ -572,7 +677,10 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
                                            uint32_t env0, uint32_t n, bool valid,
                                            const float (&row)[OBS]) {
   if (out == nullptr) return;
-  if (env0 + (uint32_t)kWave <= n) {  // full wavefront (a wavefront past the end has env0 >= n)
+  // full wavefront (a wavefront past the end has env0 >= n) and a 16-byte aligned block: the K-step
+  // kernels offset `out` by k*n*OBS floats, which an odd n leaves only 8-byte aligned
+  const bool vec_ok = env0 + (uint32_t)kWave <= n && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  if (vec_ok) {
 #pragma unroll
     for (int j = 0; j < OBS; j += 2) {
       *reinterpret_cast<float2*>(lds_wave + lane * OBS + j) = make_float2(row[j], row[j + 1]);
@@ -592,7 +700,7 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
         CS_NT_STORE(rv, at32<f32x4>(out, base + (uint32_t)k * 1024u));
       }
     }
-  } else if (valid) {  // ragged last wavefront: plain row stores
+  } else if (valid) {  // ragged last wavefront / unaligned block: plain row stores
     float* dst = out + (size_t)(env0 + lane) * OBS;
 #pragma unroll
     for (int j = 0; j < OBS; ++j) dst[j] = row[j];
@@ -606,15 +714,13 @@ template <int MODE>
 struct Env {
   using T = typename ModeOf<MODE>::T;
   double x[12];        // the values the stored representation decodes to
-  T xs[12];            // stored words of x   } valid after advance()
-  uint32_t gs[3];      // guard words of x    }
   int steps, fs;       // step counter, flight status
-  bool pend;           // reset perturbation (fe.v[0..2]) not yet consumed
+  bool pend;           // this episode's reset perturbation is not yet consumed
+  bool expl;           // ... and it is the explicit force of the FE group (else: the Philox draw)
   bool reset_pending;  // NEXT_STEP: finished, resets at the next step
-  bool fe_dirty;       // fe was rewritten by a reset and has to be stored
+  uint32_t episode;    // episodes started
   double prev_sh;
   float ep_ret;
-  Vec4<T> fe;          // FE group, raw: force [N] + episodes started
 };
 
 template <int OBS>
@@ -626,8 +732,62 @@ struct StepOut {
 };
 
 struct StepOpts {  // uniform switches (compiled out in LEAN builds)
-  bool stats, trunc, done_list, same_step;
+  bool stats, trunc, done_list, same_step, gyro, act_f32;
 };
+
+// the raw groups of one tile <-> Env
+template <int MODE, class TILE>
+__device__ __forceinline__ void unpack_env(const DevConst& c, const typename TILE::Group& t1,
+                                           const typename TILE::Group& t2, const typename TILE::Group& r1,
+                                           const typename TILE::Group& r2, Env<MODE>& e) {
+  const uint32_t gT = TILE::int_lo(t2), meta = TILE::int_hi(t2), gR = TILE::int_lo(r2);
+  e.episode = TILE::int_hi(r2);
+  e.steps = (int)(meta & kMetaStepsMask);
+  e.fs = (int)(gT >> kStatusShift);
+  e.pend = (meta & kMetaPerturbPending) != 0;
+  e.expl = (meta & kMetaExplicitForce) != 0;
+  e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    e.x[k] = decode_word<MODE>(as_word(t1.v[k]), gT, k);
+    e.x[6 + k] = decode_word<MODE>(as_word(r1.v[k]), gR, k);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    e.x[4 + k] = decode_word<MODE>(as_word(t2.v[k]), gT, 4 + k);
+    e.x[10 + k] = decode_word<MODE>(as_word(r2.v[k]), gR, 4 + k);
+  }
+}
+
+__device__ __forceinline__ uint32_t pack_meta(int steps, bool pend, bool expl, bool reset_pending) {
+  return (uint32_t)steps | (pend ? kMetaPerturbPending : 0u) | (expl ? kMetaExplicitForce : 0u) |
+         (reset_pending ? kMetaResetPending : 0u);
+}
+
+template <int MODE, class TILE>
+__device__ __forceinline__ void store_env(const TILE& tile, const Env<MODE>& e) {
+  using T = typename ModeOf<MODE>::T;
+  T w[12];
+  words12<MODE>(e.x, w);
+  const uint32_t gT = pack_guards6<MODE>(e.x) | ((uint32_t)e.fs << kStatusShift);
+  const uint32_t gR = pack_guards6<MODE>(e.x + 6);
+  typename TILE::Group t1, t2, r1, r2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    t1.v[k] = as_bits(w[k]);
+    r1.v[k] = as_bits(w[6 + k]);
+  }
+  t2.v[0] = as_bits(w[4]);
+  t2.v[1] = as_bits(w[5]);
+  r2.v[0] = as_bits(w[10]);
+  r2.v[1] = as_bits(w[11]);
+  TILE::set_ints(t2, gT, pack_meta(e.steps, e.pend, e.expl, e.reset_pending));
+  TILE::set_ints(r2, gR, e.episode);
+  tile.store_group(0, t1);
+  tile.store_group(1, t2);
+  tile.store_group(2, r1);
+  tile.store_group(3, r2);
+}
 
 // One action row -> the four motor demands: _get_motors (lander.py:95-97 for the 3D tasks; the
 // fan-outs of attic lander2d.py:48-50 / lander1d.py:46-48 for the variants).  Coalesced
@@ -647,81 +807,126 @@ __device__ __forceinline__ float4 load_action(const float* base, uint32_t env) {
   }
 }
 
+// The pending reset perturbation of an env in its doubled form 2*F/M (dynamics :263-271 + :183):
+// the explicit force of the FE group, or this episode's Philox draw, evaluated here, where it is used.
+template <int MODE, class TILE>
+__device__ __forceinline__ void pending_perturbation(const DevConst& c, const Coef& q, const TILE& tile,
+                                                     uint32_t i, uint32_t episode, bool pend, bool expl,
+                                                     double& px, double& py, double& pz) {
+  using T = typename ModeOf<MODE>::T;
+  px = py = pz = 0.0;
+  if (pend) {
+    double f[3];
+    draw_force<T>(c, i, episode - 1u, f);
+    if (expl) {
+      const Vec4<T> fe = tile.load_fe();
+      f[0] = (double)fe.v[0];
+      f[1] = (double)fe.v[1];
+      f[2] = (double)fe.v[2];
+    }
+    px = f[0] * q.two_inv_M;
+    py = f[1] * q.two_inv_M;
+    pz = f[2] * q.two_inv_M;
+  }
+}
+
+// reward / termination of one step (task.py:104-130, lander.py:58-74) from its ingredients
+struct Verdict {
+  double reward;
+  bool term, trunc;
+};
+template <int TASK>
+__device__ __forceinline__ Verdict judge_step(const DevConst& c, bool opt_trunc, int status0, int steps,
+                                              double sh, double prev_sh, double x, double y, double phi,
+                                              double the) {
+  double reward;
+  bool done = false;
+  if constexpr (task_is_lander(TASK)) {
+    reward = (prev_sh != prev_sh) ? 0.0 : sh - prev_sh;  // NaN == None
+    if (status0 == CS_STATUS_LANDED) {
+      done = true;
+      if (fma(x, x, y * y) < c.target_r2) reward += c.bonus;
+    }
+  } else {
+    reward = 1.0;
+  }
+  if (fabs(x) >= c.bounds || fabs(y) >= c.bounds) {
+    done = true;
+    reward -= c.oob_penalty;
+  } else if (fabs(phi) >= c.max_angle || fabs(the) >= c.max_angle) {
+    done = true;
+    reward = -c.oob_penalty;
+  } else if (status0 == CS_STATUS_CRASHED) {
+    done = true;
+  }
+  const bool limit = steps == c.max_steps;
+  Verdict v;
+  v.trunc = opt_trunc && limit && !done;
+  v.term = done || (!opt_trunc && limit);
+  v.reward = reward;
+  return v;
+}
+
 // _Task.step() (task.py:77-137) for one register-resident env: Dynamics.setMotors x
 // substeps -> stored-word rounding -> reward / termination -> optional done list and
 // final_obs -> masked auto-reset (task.py:145-197).  Shared by the one-step and the
-// K-step kernels, so both advance an env bit-identically.  ONE_STEP: the env is stored right
-// after this call, so a reset writes the FE group from inside its branch and does not keep
-// the register copies (x, fe) up to date.
-template <int TASK, int MODE, int OBS, bool ONE_STEP, class TILE>
+// K-step kernels, so both advance an env bit-identically.
+template <int TASK, int MODE, int OBS, bool LEAN, class TILE>
 __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const StepOpts& o,
                                         Env<MODE>& e, const float4 act, const cs_step_io& io, uint32_t i,
                                         int lane, bool valid, const TILE& tile,
                                         StepOut<OBS>& out) {
-#pragma clang fp contract(off)  // see lander_shaping()
   using T = typename ModeOf<MODE>::T;
   constexpr int FIRST = task_obs_first(TASK);
+  constexpr bool FULL = MODE == CS_STATE_F64;
   const bool resetting = e.reset_pending;  // only ever set under NEXT_STEP auto-reset
   double reward = 0.0;
   bool term = false, trunc = false;
-  e.gs[0] = e.gs[1] = e.gs[2] = 0;
 
   // ---- Dynamics.setMotors x substeps (skipped when the env entered LANDED) ----
   const int status0 = e.fs;
   if (!resetting && status0 != CS_STATUS_LANDED) {
     // np.clip(action, 0, 1), task.py:91
-    const Wrench w = motor_model(q, clip01(act.x), clip01(act.y), clip01(act.z), clip01(act.w));
-    physics_substeps(c, q, w, e.x, e.fs, e.pend, e.fe);
+    const float a0 = clip01(act.x), a1 = clip01(act.y), a2 = clip01(act.z), a3 = clip01(act.w);
+    Wrench w;
+    bool f32_model = false;
+    if constexpr (!LEAN) f32_model = o.act_f32;
+    if (f32_model) {
+      w = motor_model_f32(c, a0, a1, a2, a3);
+    } else {
+      w.bz = thrust_model(q, a0, a1, a2, a3);
+      torque_model(q, a0, a1, a2, a3, w);
+    }
+    double px, py, pz;
+    pending_perturbation<MODE>(c, q, tile, i, e.episode, e.pend, e.expl, px, py, pz);
+    bool gyro = false;
+    if constexpr (!LEAN) gyro = o.gyro;
+    if (gyro) {
+      physics_substeps<FULL, true>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+    } else {
+      physics_substeps<FULL, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+    }
   }
 
-  // ---- round to the stored word; everything below sees exactly what is stored ----
+  // ---- round to the stored precision; everything below sees exactly what is stored ----
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
-    if constexpr (ONE_STEP) {
-      const Stored<MODE> w = encode_word<MODE>(e.x[k]);
-      e.xs[k] = w.word;
-      e.gs[k >> 2] |= w.guard << (8 * (k & 3));
-      e.x[k] = w.value;
-    } else {
-      // the env stays in registers: only the decoded value is needed now, the words are split
-      // off when it is stored (step_many_kernel's epilogue)
-      e.x[k] = round_stored<MODE>(e.x[k]);
-    }
+    e.x[k] = round_stored<MODE>(e.x[k]);
     // float32 observation: round-to-nearest of the stored value (slots FIRST .. FIRST+OBS-1)
     if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)e.x[k];
   }
 
   // ---- reward / termination (task.py:104-130, lander.py:46-74) ----
   if (!resetting) {
-    bool done = false;
-    if constexpr (task_is_lander(TASK)) {
-      const double sh = lander_shaping(c, e.x);
-      reward = (e.prev_sh != e.prev_sh) ? 0.0 : sh - e.prev_sh;  // NaN == None
-      e.prev_sh = (double)(T)sh;
-      if (status0 == CS_STATUS_LANDED) {
-        done = true;
-        if (fma(e.x[0], e.x[0], e.x[2] * e.x[2]) < c.target_r2) reward += c.bonus;
-      }
-    } else {
-      reward = 1.0;
-    }
-    if (fabs(e.x[0]) >= c.bounds || fabs(e.x[2]) >= c.bounds) {
-      done = true;
-      reward -= c.oob_penalty;
-    } else if (fabs(e.x[6]) >= c.max_angle || fabs(e.x[8]) >= c.max_angle) {
-      done = true;
-      reward = -c.oob_penalty;
-    } else if (status0 == CS_STATUS_CRASHED) {
-      done = true;
-    }
-    const bool limit = e.steps == c.max_steps;
-    if (o.trunc) {
-      trunc = limit && !done;
-    } else {
-      done = done || limit;
-    }
+    double sh = 0.0;
+    if constexpr (task_is_lander(TASK)) sh = lander_shaping(c, e.x);
+    const Verdict v = judge_step<TASK>(c, o.trunc, status0, e.steps, sh, e.prev_sh, e.x[0], e.x[2],
+                                       e.x[6], e.x[8]);
+    if constexpr (task_is_lander(TASK)) e.prev_sh = (double)(T)sh;
+    reward = v.reward;
+    term = v.term;
+    trunc = v.trunc;
     e.steps = min(e.steps + 1, (int)kMetaStepsMask);
-    term = done;
     e.ep_ret += (float)reward;
   }
   const bool fin = term || trunc;
@@ -750,32 +955,21 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     for (int k = 0; k < OBS; ++k) dst[k] = out.row[k];
   }
 
-  // ---- masked reset (task.py:145-197): fresh state, Philox force, shaping, steps = 1 ----
+  // ---- masked reset (task.py:145-197): fresh state, a new episode number (its perturbation is the
+  //      Philox draw of that number, evaluated when the physics consumes it), shaping, steps = 1 ----
   const bool do_reset = resetting || (o.same_step && fin);
   e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && fin;
   if (do_reset) {
-    double fr[3];
-    const uint32_t episode = TileIO<MODE>::episode_of(e.fe);
-    draw_force(c, i, episode, fr);
-    if constexpr (ONE_STEP && !TILE::kWholeRowFe) {
-      tile.store_fe(TileIO<MODE>::make_fe(fr, episode + 1));
-    } else {
-      e.fe = TileIO<MODE>::make_fe(fr, episode + 1);
-      e.fe_dirty = true;
-    }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
       const T w0 = (k == 4) ? (T)c.z0 : (T)0;
-      if constexpr (ONE_STEP) {
-        e.xs[k] = w0;
-      } else {
-        e.x[k] = (double)w0;
-      }
+      e.x[k] = (double)w0;
       if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
     }
-    e.gs[0] = e.gs[1] = e.gs[2] = 0;
+    e.episode += 1u;
     e.fs = c.status0;
     e.pend = true;
+    e.expl = false;
     e.steps = 1;
     e.ep_ret = 0.f;
     e.prev_sh = c.reset_shaping;
@@ -786,151 +980,21 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
   out.did_reset = do_reset;
 }
 
-__device__ __forceinline__ uint32_t pack_meta(int steps, int fs, bool pend, bool reset_pending) {
-  return (uint32_t)steps | ((uint32_t)fs << kMetaStatusShift) | (pend ? kMetaPerturbPending : 0u) |
-         (reset_pending ? kMetaResetPending : 0u);
-}
-
 // ---------------------------------------------------------------------------------
-// the fused step kernel
+// the fused step kernel, one wavefront per tile
 // ---------------------------------------------------------------------------------
 // LEAN = the common configuration (auto-reset DISABLED or NEXT_STEP, no episode statistics,
-// no done list / final_obs, time limit folded into `terminated`): the optional features are
-// compiled out instead of being skipped by uniform branches.
-// What one env brings in from HBM for one step (first-round loads).
-template <int MODE>
-struct TileIn {
-  typename ModeOf<MODE>::T raw[12];
-  uint32_t g[3];
-  uint32_t meta;
-  float4 act;
-  double prev_sh;
-  float ep_ret;
-};
-
-// ---- loads: 4 x 16 B (state, guards + meta) + prev_shaping + the action row ----
-template <int TASK, int MODE, bool STREAM_ACT, class TILE>
-__device__ __forceinline__ void load_tile(const TILE& tile, const float* actions_dev,
-                                          uint32_t i, uint32_t n_envs, bool opt_stats,
-                                          TileIn<MODE>& in) {
-  const bool valid = i < n_envs;
-  tile.load_state(in.raw, in.g, in.meta);
-  in.act = load_action<TASK, STREAM_ACT>(actions_dev, valid ? i : 0u);
-  in.prev_sh = 0.0;
-  if constexpr (task_is_lander(TASK)) in.prev_sh = (double)tile.load_prev();
-  in.ep_ret = 0.f;
-  if (opt_stats) in.ep_ret = tile.load_ret();
-}
-
-// Everything after the first-round loads of one env: second-round load, decode, advance(), stores.
-template <int TASK, int MODE, bool LEAN, class TILE>
-__device__ __forceinline__ void run_tile(const DevConst& c, const DevState& s, const cs_step_io& io,
-                                         const StepOpts& o, const TileIn<MODE>& in, uint32_t i,
-                                         int lane, const TILE& tile, float* lds_wave) {
-  using T = typename ModeOf<MODE>::T;
-  constexpr int OBS = task_obs_dim(TASK);
-  const uint32_t n = s.n;
-  const uint32_t env0 = i - lane;
-  const bool valid = i < n;  // lanes past the end run on zeroed padding and never write out
-
-  // second-round load, issued as soon as the meta word is back and consumed late: the FE
-  // group (pending reset perturbation + episode number), only by lanes that need it
-  Env<MODE> e;
-  e.steps = (int)(in.meta & kMetaStepsMask);
-  e.fs = (int)((in.meta >> kMetaStatusShift) & 3u);
-  e.pend = (in.meta & kMetaPerturbPending) != 0;
-  e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && (in.meta & kMetaResetPending) != 0;
-#ifdef CS_STAMPS
-  asm volatile("" ::"v"(e.steps));  // the meta word (first load issued) has landed
-  CS_STAMP(2);
-#endif
-  e.fe_dirty = false;
-  e.prev_sh = in.prev_sh;
-  e.ep_ret = in.ep_ret;
-  // (a run-time zero, not a literal: a literal lets the compiler fold the float64
-  // conversion of `fe` into the branch below and wait for this load right there)
-  const T zero = (T)(c.nsub >> 30);
-  e.fe = {{zero, zero, zero, zero}};
-  if constexpr (TILE::kWholeRowFe) {
-    // HBM-resident batches: the FE group moves as whole 1 KiB rows whenever any lane of the
-    // wavefront needs it -- masked 16-byte writes cost read-modify-write cycles in ECC HBM
-    if (__any(e.pend || e.reset_pending || o.same_step)) e.fe = tile.load_fe();
-  } else {
-    if (e.pend || e.reset_pending || o.same_step) e.fe = tile.load_fe();
-  }
-
-#pragma unroll
-  for (int k = 0; k < 12; ++k) e.x[k] = decode_word<MODE>(in.raw[k], in.g[k >> 2], k, c.guard_mask);
-#ifdef CS_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  CS_STAMP(1);
-#ifdef CS_STAMPS
-  {  // probes: the same 16 bytes again (translation and L1 warm), then a line of this tile not touched yet
-    uint32_t probe;
-    asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)"
-                 : "=v"(probe)
-                 : "v"(tile.b16 - kBias + TILE::L.gm)
-                 : "memory");
-    CS_STAMP(3);
-    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)"
-                 : "=v"(probe)
-                 : "v"(tile.bg - kBias + TILE::L.fe)
-                 : "memory");
-    CS_STAMP(4);
-  }
-#endif
-
-  // vehicle / world coefficients: uniform, or this env's own (full-featured build only)
-  Coef q = uniform_coef(c);
-  if constexpr (!LEAN) {
-    if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
-  }
-  // Open-loop callers may name the NEXT step's action batch: touch this tile's rows of it (one
-  // dword per 16-byte row = every 128-byte line of the 1 KiB block) so that the next launch -- same
-  // tile, same XCD -- finds them in this XCD's L2 instead of waiting for the Infinity Cache / HBM.
-  // Issued behind the first-round loads' last wait (the fake operands tie it there: a wait counts
-  // loads in issue order, so an earlier position would make the physics wait for this one too);
-  // the destination stays reserved to the end of the kernel and is never read.
-  uint32_t prefetch_sink = 0;
-  if (io.next_actions_dev != nullptr) {
-    constexpr uint32_t row = (uint32_t)task_act_dim(TASK) * 4u;
-    asm volatile("global_load_dword %0, %1, %2"
-                 : "=v"(prefetch_sink)
-                 : "v"((valid ? i : 0u) * row), "s"(io.next_actions_dev), "v"(in.act.x), "v"(in.raw[0]),
-                   "v"(in.raw[4]), "v"(in.raw[8]), "v"(e.fe.v[0]), "v"(in.prev_sh)
-                 : "memory");
-  }
-  StepOut<OBS> out;
-  advance<TASK, MODE, OBS, true>(c, q, o, e, in.act, io, i, lane, valid, tile, out);
-
-  CS_STAMP(5);
-  if constexpr (TILE::kWholeRowFe) {
-    if (__any(e.fe_dirty)) tile.store_fe(e.fe);
-  }
-  // ---- stores: 4 x 16 B (state, guards + meta) + prev_shaping ----
-  tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
-  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
-  if (o.stats) tile.store_ret(e.ep_ret);
-  if (valid) {
-    if (io.reward_dev) CS_NT_STORE((float)out.reward, at32<float>(io.reward_dev, i << 2));
-    if (io.terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(io.terminated_dev, i));
-    if (io.truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(io.truncated_dev, i));
-  }
-  write_rows<OBS>(io.obs_dev, lds_wave, lane, env0, n, valid, out.row);
-  asm volatile("" ::"v"(prefetch_sink));  // the prefetch's landing register is live up to here
-  CS_STAMP(6);
-}
-
-// One wavefront = one tile = one workgroup.  (Giving each wavefront two tiles with both tiles'
-// loads issued up front was measured: +22 % time at 262 144 envs, neutral from 524 288 envs up.)
-template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE>
+// no done list / final_obs, time limit folded into `terminated`, uniform vehicle, float64 motor
+// model, no rotor-inertia term): the optional features are compiled out instead of being skipped
+// by uniform branches.  PREFETCH: cs_step_io.next_actions_dev is set.
+template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool PREFETCH>
 __global__ __launch_bounds__(kBlock) void step_kernel(
     // leading scalar arguments: preloaded into SGPRs with the wave (kernarg preload), so the
     // first loads do not wait for an s_load of the argument block
     char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
     const float* const next_actions_dev, const DevConst c, const DevState s_rest, const cs_step_io io_rest) {
+  using T = typename ModeOf<MODE>::T;
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
@@ -946,17 +1010,77 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
   o.trunc = !LEAN && c.tl_trunc;
   o.done_list = !LEAN && io.done_count_dev != nullptr;
   o.same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
+  o.gyro = !LEAN && c.gyro;
+  o.act_f32 = !LEAN && c.act_f32;
   constexpr int OBS = task_obs_dim(TASK);
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
-  const int lane = threadIdx.x & (kWave - 1);
-  float* lds_wave = lds + (threadIdx.x - lane) * OBS;
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const TileIO<MODE, STREAM_STATE> tile(s, i);
+  const int lane = threadIdx.x;
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
+  const uint32_t n = s.n;
+  const uint32_t env0 = i - lane;
+  const bool valid = i < n;  // lanes past the end run on zeroed padding and never write out
+  using TILE = TileIO<MODE, STREAM_STATE>;
+  const TILE tile(s, tile_index, lane);
   CS_STAMP(0);
-  TileIn<MODE> in;
-  load_tile<TASK, MODE, STREAM_ACT>(tile, io.actions_dev, i, s.n, o.stats, in);
-  run_tile<TASK, MODE, LEAN>(c, s, io, o, in, i, lane, tile, lds_wave);
+
+  // ---- loads: 4 x 16 B (state, guards, counters) + prev_shaping + the action row ----
+  // T2 first (status, flags, step counter: what the control flow needs), the attitude groups next
+  // (the physics starts from the angles)
+  const typename TILE::Group t2 = tile.load_group(1);
+  const typename TILE::Group r1 = tile.load_group(2);
+  const typename TILE::Group r2 = tile.load_group(3);
+  const float4 act = load_action<TASK, STREAM_ACT>(io.actions_dev, valid ? i : 0u);
+  const typename TILE::Group t1 = tile.load_group(0);
+  Env<MODE> e;
+  e.prev_sh = 0.0;
+  if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
+  e.ep_ret = 0.f;
+  if (o.stats) e.ep_ret = tile.load_ret();
+  unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
+#ifdef CS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  CS_STAMP(1);
+
+  // Open-loop callers may name the NEXT step's action batch: touch this tile's rows of it (one
+  // dword per 16-byte row = every 128-byte line of the 1 KiB block) so that the next launch -- same
+  // tile, same XCD -- may find them in this XCD's L2.  Issued behind the first-round loads' last wait
+  // (the fake operands tie it there: a wait counts loads in issue order, so an earlier position would
+  // make the physics wait for this one too); the destination stays reserved to the end of the kernel
+  // and is never read.
+  uint32_t prefetch_sink = 0;
+  if constexpr (PREFETCH) {
+    constexpr uint32_t row = (uint32_t)task_act_dim(TASK) * 4u;
+    asm volatile("global_load_dword %0, %1, %2"
+                 : "=v"(prefetch_sink)
+                 : "v"((valid ? i : 0u) * row), "s"(io.next_actions_dev), "v"(act.x), "v"(e.x[0]),
+                   "v"(e.x[4]), "v"(e.x[8]), "v"(e.x[10]), "v"(e.prev_sh)
+                 : "memory");
+  }
+
+  // vehicle / world coefficients: uniform, or this env's own (full-featured build only)
+  Coef q = uniform_coef(c);
+  if constexpr (!LEAN) {
+    if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
+  }
+  StepOut<OBS> out;
+  advance<TASK, MODE, OBS, LEAN>(c, q, o, e, act, io, i, lane, valid, tile, out);
+  CS_STAMP(5);
+
+  // ---- stores: 4 x 16 B (state, guards, counters) + prev_shaping ----
+  store_env<MODE, TILE>(tile, e);
+  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
+  if (o.stats) tile.store_ret(e.ep_ret);
+  if (valid) {
+    if (io.reward_dev) CS_NT_STORE((float)out.reward, at32<float>(io.reward_dev, i << 2));
+    if (io.terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(io.terminated_dev, i));
+    if (io.truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(io.truncated_dev, i));
+  }
+  write_rows<OBS>(io.obs_dev, lds, lane, env0, n, valid, out.row);
+  if constexpr (PREFETCH) asm volatile("" ::"v"(prefetch_sink));  // the landing register is live up to here
+  CS_STAMP(6);
 #ifdef CS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -983,7 +1107,6 @@ struct PidCtl {
 // _PidController.compute (pidcontrollers/__init__.py:33-63)
 __device__ __forceinline__ double pid_compute(PidCtl& s, double kp, double ki, double kd,
                                               double windup, double target, double actual) {
-#pragma clang fp contract(off)  // the controller arithmetic is reproduced bit for bit
   const double error = target - actual;
   double acc = error * kp;
   double iterm = 0.0;
@@ -1015,7 +1138,6 @@ __device__ __forceinline__ double pid_rate(const PidConst& p, PidCtl& s, double 
 
 // PositionHoldPidController.getDemand (:94-108): unit-gain position loop -> velocity loop
 __device__ __forceinline__ double pid_pos(const PidConst& p, PidCtl& s, double x, double dx) {
-#pragma clang fp contract(off)  // the controller arithmetic is reproduced bit for bit
   const double target_velocity = (p.pos_target - x) * 1.0;
   return pid_compute(s, p.pos_kp, p.pos_ki, p.pos_kd, p.pos_windup, target_velocity, dx);
 }
@@ -1026,7 +1148,6 @@ __device__ __forceinline__ double pid_pos(const PidConst& p, PidCtl& s, double x
 template <int OBS, bool HOVER, int NCTL>
 __device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[NCTL],
                                              const float (&obs)[OBS]) {
-#pragma clang fp contract(off)  // the controller arithmetic is reproduced bit for bit
   const double x = obs[0], dx = obs[1], y = obs[2], dy = obs[3], z = obs[4], dz = obs[5];
   const double dphi = obs[7], dtheta = obs[9];
   const double r = pid_rate(p, ctl[0], dphi) + pid_pos(p, ctl[2], y, dy);
@@ -1052,8 +1173,8 @@ __device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[NC
 
 // ---------------------------------------------------------------------------------
 // K consecutive steps in one launch (open-loop: the K action batches are resident).
-// The env stays in registers between steps: state, guards, meta, prev_shaping and the FE
-// group cross HBM once per launch instead of once per step; per step only the action row
+// The env stays in registers between steps: state, guards, counters and prev_shaping cross HBM
+// once per launch instead of once per step; per step only the action row
 // comes in and the observation row, reward and flags go out.  Bit-identical to K
 // launches of step_kernel (both call advance()).
 // ---------------------------------------------------------------------------------
@@ -1080,8 +1201,12 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // controller gains, reward constants) are made vector-resident up front instead.
   DevConst c = c_arg;
   PidConst pc = pc_arg;
+  constexpr bool FULL = MODE == CS_STATE_F64;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) c.trig[j] = in_vgpr(c.trig[j]);
+  for (int j = 0; j < 25; ++j) {
+    const bool used = j < 4 || (FULL ? j < 16 : j >= 16);
+    if (used) c.trig[j] = in_vgpr(c.trig[j]);
+  }
   c.xyz_pen = in_vgpr(c.xyz_pen);
   c.yaw_pen = in_vgpr(c.yaw_pen);
   c.dz_max = in_vgpr(c.dz_max);
@@ -1117,35 +1242,33 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
   const uint32_t n = s.n;
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
+  const int lane = threadIdx.x;
   const uint32_t env0 = i - lane;
   const bool valid = i < n;
-  const TileIO<MODE> tile(s, i);
-  float* lds_wave = lds + (threadIdx.x - lane) * OBS;
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, lane);
 
-  T raw[12];
-  uint32_t g[3];
-  uint32_t meta;
-  tile.load_state(raw, g, meta);
   Env<MODE> e;
-  e.steps = (int)(meta & kMetaStepsMask);
-  e.fs = (int)((meta >> kMetaStatusShift) & 3u);
-  e.pend = (meta & kMetaPerturbPending) != 0;
-  e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
-  e.fe_dirty = false;
+  {
+    const typename TILE::Group t2 = tile.load_group(1);
+    const typename TILE::Group r1 = tile.load_group(2);
+    const typename TILE::Group r2 = tile.load_group(3);
+    const typename TILE::Group t1 = tile.load_group(0);
+    unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
+  }
   e.prev_sh = 0.0;
   if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
   const bool opt_stats = !LEAN && c.stats;
   e.ep_ret = opt_stats ? tile.load_ret() : 0.f;
-  e.fe = tile.load_fe();
   StepOpts o;
   o.stats = opt_stats;
   o.trunc = !LEAN && c.tl_trunc;
   o.done_list = false;
   o.same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) e.x[k] = decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
+  o.gyro = !LEAN && c.gyro;
+  o.act_f32 = !LEAN && c.act_f32;
 
   cs_step_io io;  // no optional outputs in the K-step form
   io.actions_dev = io.next_actions_dev = nullptr;
@@ -1184,7 +1307,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL>(pc, ctl, seen);
       if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
     } else if constexpr (POLICY == kPolicyRandom) {
-      const float4 a = draw_action(c, i, TileIO<MODE>::episode_of(e.fe), (uint32_t)e.steps);
+      const float4 a = draw_action(c, i, e.episode, (uint32_t)e.steps);
       // the task's own action row (1, 2 or 4 values), then its motor fan-out
       if constexpr (ACT == 4) {
         act = a;
@@ -1202,7 +1325,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       act_next = load_action<TASK>(actions_dev + (size_t)kn * n * ACT, ia);  // prefetch
     }
     StepOut<OBS> out;
-    advance<TASK, MODE, OBS, false>(c, q, o, e, act, io, i, lane, valid, tile, out);
+    advance<TASK, MODE, OBS, LEAN>(c, q, o, e, act, io, i, lane, valid, tile, out);
     if constexpr (kPid) {
 #pragma unroll
       for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
@@ -1216,19 +1339,11 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       if (terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(terminated_dev + row, i));
       if (truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(truncated_dev + row, i));
     }
-    write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds_wave, lane, env0, n, valid, out.row);
+    write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
     act = act_next;
   }
 
-  if (e.fe_dirty) tile.store_fe(e.fe);
-  e.gs[0] = e.gs[1] = e.gs[2] = 0;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {  // words + guard bytes of the (already rounded) values
-    uint32_t guard;
-    split_stored<MODE>(e.x[k], e.xs[k], guard);
-    e.gs[k >> 2] |= guard << (8 * (k & 3));
-  }
-  tile.store_state(e.xs, e.gs, pack_meta(e.steps, e.fs, e.pend, e.reset_pending));
+  store_env<MODE, TILE>(tile, e);
   if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (opt_stats) tile.store_ret(e.ep_ret);
   if constexpr (kPid) {
@@ -1248,36 +1363,37 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, const DevState s,
                                                             const float* __restrict__ motors) {
-  using T = typename ModeOf<MODE>::T;
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  constexpr bool FULL = MODE == CS_STATE_F64;
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  const TileIO<MODE> tile(s, i);
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, threadIdx.x);
   const float4 mv = reinterpret_cast<const float4*>(motors)[i];
-  T raw[12];
-  uint32_t g[3];
-  uint32_t meta;
-  tile.load_state(raw, g, meta);
-  double x[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) x[k] = decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
-  int fs = (int)((meta >> kMetaStatusShift) & 3u);
-  bool pend = (meta & kMetaPerturbPending) != 0;
-  Vec4<T> fe = {{(T)0, (T)0, (T)0, (T)0}};
-  if (pend) fe = tile.load_fe();
+  Env<MODE> e;
+  unpack_env<MODE, TILE>(c, tile.load_group(0), tile.load_group(1), tile.load_group(2), tile.load_group(3), e);
   const Coef q = s.veh != nullptr ? load_coef(s.veh, s.veh_stride, i) : uniform_coef(c);
-  const Wrench w = motor_model(q, mv.x, mv.y, mv.z, mv.w);
-  physics_substeps(c, q, w, x, fs, pend, fe);
-  T xs[12];
-  uint32_t gs[3] = {0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const Stored<MODE> e = encode_word<MODE>(x[k]);
-    xs[k] = e.word;
-    gs[k >> 2] |= e.guard << (8 * (k & 3));
+  Wrench w;
+  if (c.act_f32) {
+    w = motor_model_f32(c, mv.x, mv.y, mv.z, mv.w);
+  } else {
+    w.bz = thrust_model(q, mv.x, mv.y, mv.z, mv.w);
+    torque_model(q, mv.x, mv.y, mv.z, mv.w, w);
   }
-  tile.store_state(xs, gs,
-                   (meta & ~((3u << kMetaStatusShift) | kMetaPerturbPending)) |
-                       ((uint32_t)fs << kMetaStatusShift) | (pend ? kMetaPerturbPending : 0u));
+  double px, py, pz;
+  pending_perturbation<MODE>(c, q, tile, i, e.episode, e.pend, e.expl, px, py, pz);
+  if (c.gyro) {
+    physics_substeps<FULL, true>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+  } else {
+    physics_substeps<FULL, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k) e.x[k] = round_stored<MODE>(e.x[k]);
+  // (meta: only the status and the pending flag change; unpack_env masked reset_pending by the
+  // auto-reset mode, so rebuild it from the stored word)
+  const uint32_t meta0 = TILE::int_hi(tile.load_group(1));
+  e.reset_pending = (meta0 & kMetaResetPending) != 0;
+  store_env<MODE, TILE>(tile, e);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1290,21 +1406,19 @@ __global__ __launch_bounds__(kBlock) void export_state_kernel(const DevConst c, 
                                                               float* __restrict__ x_out,
                                                               uint8_t* __restrict__ status_out,
                                                               int32_t* __restrict__ steps_out) {
-  using T = typename ModeOf<MODE>::T;
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
   if (i >= s.n) return;
-  const TileIO<MODE> tile(s, i);
-  T raw[12];
-  uint32_t g[3];
-  uint32_t meta;
-  tile.load_state(raw, g, meta);
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, threadIdx.x);
+  Env<MODE> e;
+  unpack_env<MODE, TILE>(c, tile.load_group(0), tile.load_group(1), tile.load_group(2), tile.load_group(3), e);
   if (x_out != nullptr) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k)
-      x_out[(size_t)k * s.n + i] = (float)decode_word<MODE>(raw[k], g[k >> 2], k, c.guard_mask);
+    for (int k = 0; k < 12; ++k) x_out[(size_t)k * s.n + i] = (float)e.x[k];
   }
-  if (status_out != nullptr) status_out[i] = (uint8_t)((meta >> kMetaStatusShift) & 3u);
-  if (steps_out != nullptr) steps_out[i] = (int32_t)(meta & kMetaStepsMask);
+  if (status_out != nullptr) status_out[i] = (uint8_t)e.fs;
+  if (steps_out != nullptr) steps_out[i] = (int32_t)e.steps;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1321,77 +1435,129 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
                                                        const int perturb) {
   using T = typename ModeOf<MODE>::T;
   constexpr int OBS = task_obs_dim(TASK);
+  constexpr int FIRST = task_obs_first(TASK);
   const uint32_t n = s.n;
-  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
   if (i >= n) return;
-  const TileIO<MODE> tile(s, i);
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, threadIdx.x);
+  Env<MODE> e;
+  unpack_env<MODE, TILE>(c, tile.load_group(0), tile.load_group(1), tile.load_group(2), tile.load_group(3), e);
   if (mask == nullptr || mask[i] != 0) {
     if (pid_state != nullptr) {  // a new episode flies with fresh controllers
 #pragma unroll
       for (int j = 0; j < kPidRows; ++j) pid_state[(size_t)j * pid_stride + i] = 0.0;
     }
-    double f[3];
-    const uint32_t episode = TileIO<MODE>::episode_of(tile.load_fe());
-    if (perturb == 0) {  // _reset(perturb=False), task.py:176
-      f[0] = f[1] = f[2] = 0.0;
-    } else if (force_xyz != nullptr) {
-      f[0] = (double)force_xyz[0 * (size_t)n + i];
-      f[1] = (double)force_xyz[1 * (size_t)n + i];
-      f[2] = (double)force_xyz[2 * (size_t)n + i];
-    } else {
-      draw_force(c, i, episode, f);
+    // perturb == 0: _reset(perturb=False), task.py:176.  An explicit force goes to the FE group;
+    // otherwise the perturbation is the Philox draw of the new episode number.
+    e.pend = perturb != 0;
+    e.expl = perturb != 0 && force_xyz != nullptr;
+    if (e.expl) {
+      Vec4<T> fe;
+      fe.v[0] = (T)force_xyz[0 * (size_t)n + i];
+      fe.v[1] = (T)force_xyz[1 * (size_t)n + i];
+      fe.v[2] = (T)force_xyz[2 * (size_t)n + i];
+      fe.v[3] = (T)0;
+      tile.store_fe(fe);
     }
-    const uint32_t pend = perturb != 0 ? kMetaPerturbPending : 0u;
-    if (pose == nullptr) {
-      T xs[12];
+    e.episode += 1u;
+    e.reset_pending = false;
+    e.steps = 1;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) xs[k] = (k == 4) ? (T)c.z0 : (T)0;
-      const uint32_t gs[3] = {0u, 0u, 0u};
-      tile.store_state(xs, gs, 1u | ((uint32_t)c.status0 << kMetaStatusShift) | pend);
+    for (int k = 0; k < 12; ++k) e.x[k] = 0.0;
+    if (pose == nullptr) {
+      e.x[4] = (double)(T)c.z0;
+      e.fs = c.status0;
       tile.store_prev((T)c.reset_shaping);  // NaN (= None) for Hover3D
     } else {
       // _reset(pose=(x, y, altitude, phi_deg, theta_deg)), task.py:163-170: NED z, np.radians
-      double x0[12];
-#pragma unroll
-      for (int k = 0; k < 12; ++k) x0[k] = 0.0;
       const double deg = 3.14159265358979323846 / 180.0;
-      x0[0] = (double)pose[0 * (size_t)n + i];
-      x0[2] = (double)pose[1 * (size_t)n + i];
-      x0[4] = -(double)pose[2 * (size_t)n + i];
-      x0[6] = (double)pose[3 * (size_t)n + i] * deg;
-      x0[8] = (double)pose[4 * (size_t)n + i] * deg;
-      T xs[12];
-      uint32_t gs[3] = {0u, 0u, 0u};
+      e.x[0] = (double)pose[0 * (size_t)n + i];
+      e.x[2] = (double)pose[1 * (size_t)n + i];
+      e.x[4] = -(double)pose[2 * (size_t)n + i];
+      e.x[6] = (double)pose[3 * (size_t)n + i] * deg;
+      e.x[8] = (double)pose[4 * (size_t)n + i] * deg;
 #pragma unroll
-      for (int k = 0; k < 12; ++k) {
-        const Stored<MODE> w = encode_word<MODE>(x0[k]);
-        xs[k] = w.word;
-        gs[k >> 2] |= w.guard << (8 * (k & 3));
-        x0[k] = w.value;
-      }
-      const uint32_t fs = x0[4] < 0.0 ? CS_STATUS_AIRBORNE : CS_STATUS_LANDED;  // setState, :215-217
-      tile.store_state(xs, gs, 1u | (fs << kMetaStatusShift) | pend);
+      for (int k = 0; k < 12; ++k) e.x[k] = round_stored<MODE>(e.x[k]);
+      e.fs = e.x[4] < 0.0 ? CS_STATUS_AIRBORNE : CS_STATUS_LANDED;  // setState, :215-217
       // the 'initializing' step's shaping (task.py:197 -> lander.py:48-57), NaN (= None) for Hover
       if constexpr (task_is_lander(TASK)) {
-        tile.store_prev((T)lander_shaping(c, x0));
+        tile.store_prev((T)lander_shaping(c, e.x));
       } else {
         tile.store_prev((T)c.reset_shaping);
       }
     }
-    tile.store_fe(TileIO<MODE>::make_fe(f, episode + 1));
+    store_env<MODE, TILE>(tile, e);
     tile.store_ret(0.f);
   }
   if (obs != nullptr) {
-    T raw[12];
-    uint32_t g[3];
-    uint32_t meta;
-    tile.load_state(raw, g, meta);
 #pragma unroll
-    for (int k = 0; k < OBS; ++k) {
-      constexpr int FIRST = task_obs_first(TASK);
-      obs[(size_t)i * OBS + k] =
-          (float)decode_word<MODE>(raw[FIRST + k], g[(FIRST + k) >> 2], FIRST + k, c.guard_mask);
-    }
+    for (int k = 0; k < OBS; ++k) obs[(size_t)i * OBS + k] = (float)e.x[FIRST + k];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Dynamics.perturb() (dynamics/__init__.py:227-229) for the envs with mask[i] != 0 (nullptr = all):
+// install force_xyz [3,N] newtons as the pending explicit perturbation of the current episode.
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void set_perturbation_kernel(const DevState s,
+                                                                  const uint8_t* __restrict__ mask,
+                                                                  const float* __restrict__ force_xyz) {
+  using T = typename ModeOf<MODE>::T;
+  const uint32_t n = s.n;
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
+  if (i >= n || (mask != nullptr && mask[i] == 0)) return;
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, threadIdx.x);
+  Vec4<T> fe;
+  fe.v[0] = (T)force_xyz[0 * (size_t)n + i];
+  fe.v[1] = (T)force_xyz[1 * (size_t)n + i];
+  fe.v[2] = (T)force_xyz[2 * (size_t)n + i];
+  fe.v[3] = (T)0;
+  tile.store_fe(fe);
+  typename TILE::Group t2 = tile.load_group(1);
+  TILE::set_ints(t2, TILE::int_lo(t2), TILE::int_hi(t2) | kMetaPerturbPending | kMetaExplicitForce);
+  tile.store_group(1, t2);
+}
+
+// ---------------------------------------------------------------------------------
+// Running statistics of the batch (include/copterstep.h: cs_episode_stats): wave reduction, then one
+// atomic per wavefront and statistic.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevState s, double* __restrict__ out) {
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, threadIdx.x);
+  const bool valid = i < s.n;
+  const typename TILE::Group t2 = tile.load_group(1), r2 = tile.load_group(3);
+  const uint32_t meta = TILE::int_hi(t2);
+  const double steps = valid ? (double)(meta & kMetaStepsMask) : 0.0;
+  const double air = valid && (TILE::int_lo(t2) >> kStatusShift) == CS_STATUS_AIRBORNE ? 1.0 : 0.0;
+  const double epi = valid ? (double)TILE::int_hi(r2) : 0.0;
+  const double ret = valid ? (double)tile.load_ret() : 0.0;
+  double mx = steps;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+  const double v[6] = {wave_sum(valid ? 1.0 : 0.0), wave_sum(air), wave_sum(steps), mx, wave_sum(epi),
+                       wave_sum(ret)};
+  if (threadIdx.x == 0) {
+    atomicAdd(out + 0, v[0]);
+    atomicAdd(out + 1, v[1]);
+    atomicAdd(out + 2, v[2]);
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(out + 3), (unsigned long long)__double_as_longlong(v[3]));
+    atomicAdd(out + 4, v[4]);
+    atomicAdd(out + 5, v[5]);
   }
 }
 
@@ -1419,26 +1585,49 @@ inline int grid_for(uint32_t n) { return (int)((n + kBlock - 1) / kBlock); }
       return hipErrorInvalidValue;                \
   }
 static_assert(CS_STATE_F32G == 0 && CS_STATE_F32_RN == 1 && CS_STATE_F64 == 2, "dispatch index");
+#define CS_MODE_LAUNCH(KERNEL, ...)                                                               \
+  do {                                                                                            \
+    const dim3 grid(grid_for(s.n)), block(kBlock);                                                \
+    if (mode == CS_STATE_F32G)                                                                    \
+      hipLaunchKernelGGL((KERNEL<CS_STATE_F32G>), grid, block, 0, stream, __VA_ARGS__);           \
+    else if (mode == CS_STATE_F32_RN)                                                             \
+      hipLaunchKernelGGL((KERNEL<CS_STATE_F32_RN>), grid, block, 0, stream, __VA_ARGS__);         \
+    else if (mode == CS_STATE_F64)                                                                \
+      hipLaunchKernelGGL((KERNEL<CS_STATE_F64>), grid, block, 0, stream, __VA_ARGS__);            \
+    else                                                                                          \
+      return hipErrorInvalidValue;                                                                \
+    return hipGetLastError();                                                                     \
+  } while (0)
 
 namespace {
 
+bool lean_config(const DevConst& c, const DevState& s) {
+  return c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc && s.veh == nullptr && !c.gyro &&
+         !c.act_f32;
+}
+
 template <int TASK, int MODE>
-hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, hipStream_t stream) {
+hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, const Tuning& tune,
+                  hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
-  const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc &&
-                    io.done_count_dev == nullptr && io.final_obs_dev == nullptr && s.veh == nullptr;
-#define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE)                                                  \
-  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE>), grid, block, 0,  \
-                     stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev,            \
+  const bool lean = lean_config(c, s) && io.done_count_dev == nullptr && io.final_obs_dev == nullptr;
+  const uint32_t nt_act_max = tune.nt_action_max_envs ? tune.nt_action_max_envs : kNtActionMaxEnvs;
+  const uint32_t nt_state_min = tune.nt_state_min_envs ? tune.nt_state_min_envs : kNtStateMinEnvs;
+#define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH)                                        \
+  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, PREFETCH>), grid,  \
+                     block, 0, stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev,  \
                      io.terminated_dev, io.truncated_dev, io.next_actions_dev, c, s, io)
   if (!lean)
-    CS_STEP(false, false, false);
-  else if (s.n <= kNtActionMaxEnvs)  // the state fits the L2s: keep the action stream out of them
-    CS_STEP(true, true, false);
-  else if (s.n >= kNtStateMinEnvs)  // the state exceeds the Infinity Cache: stream it past the caches
-    CS_STEP(true, false, true);
+    CS_STEP(false, false, false, false);
+  else if (s.n <= nt_act_max) {  // the state fits the L2s: keep the action stream out of them
+    if (io.next_actions_dev != nullptr)
+      CS_STEP(true, true, false, true);
+    else
+      CS_STEP(true, true, false, false);
+  } else if (s.n >= nt_state_min)  // the state exceeds the Infinity Cache: stream it past the caches
+    CS_STEP(true, false, true, false);
   else
-    CS_STEP(true, false, false);
+    CS_STEP(true, false, false, false);
 #undef CS_STEP
   return hipGetLastError();
 }
@@ -1449,7 +1638,7 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
                        int policy, const PidConst* pid, double* pid_state, uint32_t pid_stride,
                        hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
-  const bool lean = c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc && s.veh == nullptr;
+  const bool lean = lean_config(c, s);
   const PidConst pc = pid ? *pid : PidConst{};
 #define CS_MANY(LEAN, POLICY)                                                                   \
   hipLaunchKernelGGL((step_many_kernel<TASK, MODE, LEAN, POLICY>), grid, block, 0, stream,      \
@@ -1501,9 +1690,11 @@ hipError_t reset_t(const DevConst& c, const DevState& s, const uint8_t* mask, co
 
 }  // namespace
 
+Tuning default_tuning() { return Tuning{kSplitMaxEnvs, kNtActionMaxEnvs, kNtStateMinEnvs}; }
+
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
-                       const cs_step_io& io, hipStream_t stream) {
-  CS_DISPATCH(step_t, c, s, io, stream)
+                       const cs_step_io& io, const Tuning& tune, hipStream_t stream) {
+  CS_DISPATCH(step_t, c, s, io, tune, stream)
 }
 
 hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
@@ -1516,32 +1707,21 @@ hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevStat
 
 hipError_t launch_export_state(int mode, const DevConst& c, const DevState& s, float* x, uint8_t* status,
                                int32_t* steps, hipStream_t stream) {
-  const dim3 grid(grid_for(s.n)), block(kBlock);
-#define CS_LAUNCH(MODE)                                                                         \
-  if (mode == MODE) {                                                                           \
-    hipLaunchKernelGGL((export_state_kernel<MODE>), grid, block, 0, stream, c, s, x, status, steps); \
-    return hipGetLastError();                                                                   \
-  }
-  CS_LAUNCH(CS_STATE_F32G)
-  CS_LAUNCH(CS_STATE_F32_RN)
-  CS_LAUNCH(CS_STATE_F64)
-#undef CS_LAUNCH
-  return hipErrorInvalidValue;
+  CS_MODE_LAUNCH(export_state_kernel, c, s, x, status, steps);
 }
 
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,
                              hipStream_t stream) {
-  const dim3 grid(grid_for(s.n)), block(kBlock);
-#define CS_LAUNCH(MODE)                                                                \
-  if (mode == MODE) {                                                                  \
-    hipLaunchKernelGGL((set_motors_kernel<MODE>), grid, block, 0, stream, c, s, motors); \
-    return hipGetLastError();                                                          \
-  }
-  CS_LAUNCH(CS_STATE_F32G)
-  CS_LAUNCH(CS_STATE_F32_RN)
-  CS_LAUNCH(CS_STATE_F64)
-#undef CS_LAUNCH
-  return hipErrorInvalidValue;
+  CS_MODE_LAUNCH(set_motors_kernel, c, s, motors);
+}
+
+hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* mask, const float* force_xyz,
+                                   hipStream_t stream) {
+  CS_MODE_LAUNCH(set_perturbation_kernel, s, mask, force_xyz);
+}
+
+hipError_t launch_episode_stats(int mode, const DevState& s, double* stats_dev, hipStream_t stream) {
+  CS_MODE_LAUNCH(episode_stats_kernel, s, stats_dev);
 }
 
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,
@@ -1549,6 +1729,26 @@ hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s
                         double* pid_state, uint32_t pid_stride, const float* pose, int perturb,
                         hipStream_t stream) {
   CS_DISPATCH(reset_t, c, s, mask, force_xyz, obs, pid_state, pid_stride, pose, perturb, stream)
+}
+
+// ---------------------------------------------------------------------------------
+// host restatement of draw_force() (cs_get_state)
+// ---------------------------------------------------------------------------------
+void host_draw_force(uint32_t key, uint32_t env_id, uint32_t episode, double force_mag, bool f32_words,
+                     double (&f)[3]) {
+  uint32_t c0 = env_id, c1 = episode;
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p = (unsigned long long)0xD256D193U * c0;
+    c0 = (uint32_t)(p >> 32) ^ key ^ c1;
+    c1 = (uint32_t)p;
+    key += 0x9E3779B9U;
+  }
+  const uint32_t u[3] = {c0 >> 11, c1 >> 11, ((c0 & 0x7FFu) << 10) | (c1 & 0x3FFu)};
+  const double two_f = 2.0 * force_mag * 0x1.0p-21;
+  for (int k = 0; k < 3; ++k) {
+    const double v = (double)u[k] * two_f - force_mag;
+    f[k] = f32_words ? (double)(float)v : v;
+  }
 }
 
 }  // namespace cs

@@ -34,12 +34,17 @@ _TASK_NAMES = {_lib.TASK_LANDER3D: "lander3d", _lib.TASK_HOVER3D: "hover3d", _li
 # task -> (first observed state slot, observation size, action size)
 _TASK_SHAPES = {"lander3d": (0, 10, 4), "hover3d": (0, 12, 4), "lander2d": (2, 6, 2), "hover2d": (2, 6, 2),
                 "lander1d": (4, 2, 1), "hover1d": (4, 2, 1)}
-# float32 (default) = float32 state words + 8 guard bits; see DESIGN.md "state words"
+# float32 (default) = float32 state words + 5 guard bits; see DESIGN.md "state words"
 _STATE_MODES = {"float32": _lib.STATE_F32G, "float32_guard": _lib.STATE_F32G,
                 "float32_rn": _lib.STATE_F32_RN, "float64": _lib.STATE_F64}
 _AUTORESET = {"disabled": _lib.AUTORESET_DISABLED, "next_step": _lib.AUTORESET_NEXT_STEP,
               "same_step": _lib.AUTORESET_SAME_STEP}
 _VEHICLE_KEYS = ("B", "D", "M", "L", "Ix", "Iy", "Iz", "Jr", "maxrpm")   # dji_phantom.py:9-26
+# how the motor model is evaluated: float64 (Python-float / float64 actions upstream) or NumPy's
+# float32 path for float32 action arrays (dynamics/__init__.py:120-132 under NumPy >= 2 promotion)
+_ARITH = {"float64": _lib.ARITH_F64, "float32": _lib.ARITH_F32}
+# thrust law: live B*omega^2, or the retired Mars model's lift-coefficient law
+_THRUST = {"B": _lib.THRUST_B, "lift": _lib.THRUST_LIFT}
 _TASK_KEYS = {"initial_random_force": "initial_random_force",             # task.py:32-38
               "out_of_bounds_penalty": "out_of_bounds_penalty",
               "max_angle": "max_angle_deg", "bounds": "bounds",
@@ -59,7 +64,9 @@ class CopterVecEnv:
     def __init__(self, task="lander3d", num_envs=1, device=0, seed=0,
                  autoreset_mode="next_step", substeps=1, state_dtype="float32",
                  time_limit_truncates=False, episode_stats=False, env_id_base=0,
-                 max_steps=1000, vehicle_params=None, frames_per_second=None, **task_kwargs):
+                 max_steps=1000, vehicle_params=None, frames_per_second=None,
+                 action_arith="float64", thrust_model="B", rotor_gyro=False, world_params=None,
+                 **task_kwargs):
         lib = _lib.load()
         torch = _torch()
         if task not in _TASKS:
@@ -90,9 +97,20 @@ class CopterVecEnv:
             cfg.frames_per_second = float(frames_per_second)
             self.FRAMES_PER_SECOND = frames_per_second
         for k, v in (vehicle_params or {}).items():
-            if k not in _VEHICLE_KEYS:
+            if k not in _VEHICLE_KEYS + ("C_L",):
                 raise ValueError("unknown vehicle parameter %r" % k)
             setattr(cfg, k, float(v))
+        for k, v in (world_params or {}).items():      # attic/mars/dynamics/__init__.py:85-86
+            if k not in ("G", "rho"):
+                raise ValueError("unknown world parameter %r" % k)
+            setattr(cfg, k, float(v))
+        if action_arith not in _ARITH:
+            raise ValueError("action_arith must be one of %s" % sorted(_ARITH))
+        if thrust_model not in _THRUST:
+            raise ValueError("thrust_model must be one of %s" % sorted(_THRUST))
+        cfg.action_arith = _ARITH[action_arith]
+        cfg.thrust_model = _THRUST[thrust_model]
+        cfg.rotor_gyro = int(bool(rotor_gyro))
         for k, v in task_kwargs.items():
             if k not in _TASK_KEYS:
                 raise TypeError("unexpected keyword argument %r" % k)
@@ -339,13 +357,14 @@ class CopterVecEnv:
         return buf[0], buf[1], buf[2].view(torch.bool), buf[3].view(torch.bool)
 
     # -- per-env vehicles / worlds (domain randomisation) --------------------------------
-    VEHICLE_ROWS = _VEHICLE_KEYS + ("G",)
+    VEHICLE_ROWS = _VEHICLE_KEYS + ("G", "rho", "C_L")
 
     def set_vehicle_params(self, params=None, **columns):
-        """Give every env its own vehicle and gravity: `params` is [10, N] (rows B, D, M, L, Ix,
-        Iy, Iz, Jr, maxrpm, G -- the reference's `vehicle_params` keys, dji_phantom.py:9-26, plus
-        Dynamics.G), or pass columns by name (scalars or [N]); unnamed ones keep this env's
-        configured values.  set_vehicle_params(None) returns to the uniform vehicle."""
+        """Give every env its own vehicle and world: `params` is [12, N] (rows B, D, M, L, Ix,
+        Iy, Iz, Jr, maxrpm -- the reference's `vehicle_params` keys, dji_phantom.py:9-26 -- then G,
+        rho, C_L: Dynamics.G and the Mars model's air density and lift coefficient), or pass columns
+        by name (scalars or [N]); unnamed ones keep this env's configured values.
+        set_vehicle_params(None) returns to the uniform vehicle."""
         self._check_open()
         torch = _torch()
         if params is None and not columns:
@@ -361,7 +380,13 @@ class CopterVecEnv:
                     raise TypeError("unknown vehicle parameter %r (have %s)" % (k, self.VEHICLE_ROWS))
                 table[self.VEHICLE_ROWS.index(k)] = np.asarray(v, dtype=np.float64)
         else:
-            table = np.asarray(params, dtype=np.float64).reshape(len(self.VEHICLE_ROWS), n)
+            table = np.asarray(params, dtype=np.float64).reshape(-1, n)
+            if table.shape[0] == 10:      # vehicle + G only: the air of this env's configuration
+                air = np.repeat(np.array([[self.config.rho], [self.config.C_L]]), n, axis=1)
+                table = np.concatenate([table, air], axis=0)
+            if table.shape[0] != len(self.VEHICLE_ROWS):
+                raise ValueError("params must have %d rows %s (or the first 10), got %d"
+                                 % (len(self.VEHICLE_ROWS), self.VEHICLE_ROWS, table.shape[0]))
         table = np.ascontiguousarray(table)
         with torch.cuda.device(self.device):
             _lib.check(self._lib.cs_set_vehicle_params(self._ctx, table.ctypes.data_as(C.c_void_p)))
@@ -536,17 +561,53 @@ class CopterVecEnv:
         _lib.check(self._lib.cs_set_state(self._ctx, *ptrs, self._stream()))
 
 
-    def set_perturbation(self, force_xyz):
-        """Dynamics.perturb() (dynamics/__init__.py:227-229) for the batch: install a pending
-        force [3,N] in newtons that the next integrating physics call consumes (applied twice in
-        that call, as upstream does)."""
-        st = self.get_state()
-        if hasattr(force_xyz, "detach"):
-            force_xyz = force_xyz.detach().cpu().numpy()
-        f = np.asarray(force_xyz, dtype=np.float64).reshape(3, self.num_envs)
-        self.set_state(force=f, flags=st["flags"] | np.uint8(1))
+    def set_perturbation(self, force_xyz, mask=None):
+        """Dynamics.perturb() (dynamics/__init__.py:227-229) for the batch (or the envs of `mask`):
+        install a pending force [3,N] in newtons that the next integrating physics call consumes
+        (applied twice in that call, as upstream does).  One kernel launch on the current stream."""
+        self._check_open()
+        torch = _torch()
+        f, _ = self._dev_f32(force_xyz, (3, self.num_envs), "force_xyz")
+        mask_t, mask_p = None, None
+        if mask is not None:
+            mask_t = torch.as_tensor(np.asarray(mask) if not isinstance(mask, torch.Tensor) else mask)
+            mask_t = (mask_t != 0).to(device=self.device, dtype=torch.uint8).contiguous()
+            if tuple(mask_t.shape) != (self.num_envs,):
+                raise ValueError("mask must have shape (%d,)" % self.num_envs)
+            mask_p = C.c_void_p(mask_t.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_set_perturbation(self._ctx, mask_p, C.c_void_p(f.data_ptr()), self._stream()))
+        self._keep = (f, mask_t)
 
     perturb = set_perturbation
+
+    STATS_NAMES = ("envs", "airborne", "steps_sum", "steps_max", "episodes_started", "return_sum")
+
+    def episode_stats(self):
+        """Batch bookkeeping reduced on the device (cs_episode_stats): a float64 tensor [6] =
+        (envs, envs airborne, sum and max of the episode step counters, episodes started, sum of the
+        running episode returns), asynchronous on the current stream."""
+        self._check_open()
+        torch = _torch()
+        if getattr(self, "_stats_t", None) is None:
+            self._stats_t = torch.zeros(_lib.EPISODE_STATS, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_episode_stats(self._ctx, C.c_void_p(self._stats_t.data_ptr()), self._stream()))
+        return self._stats_t
+
+    def set_tuning(self, split_max_envs=0, nt_action_max_envs=0, nt_state_min_envs=0):
+        """Launcher thresholds (0 = built-in default; they pick between instantiations of the same
+        kernel and never change results).  Returns the values in effect."""
+        self._check_open()
+        t = _lib.Tuning(C.sizeof(_lib.Tuning), int(split_max_envs), int(nt_action_max_envs), int(nt_state_min_envs))
+        _lib.check(self._lib.cs_set_tuning(self._ctx, C.byref(t)))
+        return self.get_tuning()
+
+    def get_tuning(self):
+        t = _lib.Tuning()
+        _lib.check(self._lib.cs_get_tuning(self._ctx, C.byref(t)))
+        return {"split_max_envs": t.split_max_envs, "nt_action_max_envs": t.nt_action_max_envs,
+                "nt_state_min_envs": t.nt_state_min_envs}
 
 
 def _to_numpy(v):

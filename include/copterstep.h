@@ -23,6 +23,9 @@
  *   cs_get_state             Dynamics.getState / getStatus      dynamics/__init__.py:199-207,223-225
  *   cs_export_state          the same, to device tensors        dynamics/__init__.py:199-207,223-225
  *   cs_set_state             Dynamics.setState / perturb        dynamics/__init__.py:210-217,227-229
+ *   cs_set_perturbation      Dynamics.perturb (device, masked)  dynamics/__init__.py:227-229
+ *   cs_episode_stats         (no upstream counterpart: batch bookkeeping)
+ *   cs_comm_* / cs_allgather (no upstream counterpart: the concatenated return of a sharded batch)
  *   cs_set_altitude          _Task.set_altitude                 envs/task.py:67-69
  *   cs_obs_dim/cs_action_dim observation_space / action_space   envs/task.py:46-55 (attic variants: lander2d.py:43-50 ...)
  *   cs_set_vehicle_params    the vehicle_params dict + G        vehicles/dji_phantom.py:9-26, dynamics/__init__.py:76, envs/task.py:161
@@ -85,8 +88,8 @@ enum {
 /* How the 12 state words are kept in HBM.  Arithmetic is float64 in registers in
  * every mode; the mode only selects the stored word and its rounding. */
 enum {
-  CS_STATE_F32G = 0,    /* float32 words + 8 guard bits per component, packed four
-                           to a dword (default; +24 B per env-step of traffic)    */
+  CS_STATE_F32G = 0,    /* float32 words + 5 guard bits per component, packed six
+                           to a dword (default; 29 significant bits)              */
   CS_STATE_F32_RN = 1,  /* float32 words only, round-to-nearest-even              */
   CS_STATE_F64 = 2      /* float64 words                                          */
 };
@@ -97,6 +100,21 @@ enum {
   CS_AUTORESET_NEXT_STEP = 1, /* the step after a done resets (action ignored, reward 0) */
   CS_AUTORESET_SAME_STEP = 2  /* reset inside the finishing step; obs = reset obs        */
 };
+
+/* Arithmetic of the motor model (dynamics/__init__.py:120-132).  The state, the rotation and the
+ * integration are float64 in every case.
+ *   CS_ARITH_F64: float64 -- what upstream computes for float64 / Python-float actions (lander.py:42).
+ *   CS_ARITH_F32: what upstream computes when `action` is a float32 ndarray (the dtype of its
+ *                 action_space, task.py:52-55): under NumPy >= 2 promotion omegas, their squares,
+ *                 U1..U4 and the divisions by M, Ix, Iy, Iz all stay float32.  The two differ by
+ *                 ~1e-5 relative after 1000 steps (golden trace E10). */
+enum { CS_ARITH_F64 = 0, CS_ARITH_F32 = 1 };
+
+/* Thrust law.  CS_THRUST_B: U = B * omega^2 (live model, dynamics/__init__.py:127-132).
+ * CS_THRUST_LIFT: the retired Mars model's lift law, Lift_i = 0.5 * rho * S * C_L * (omega_i * L/2)^2
+ * with S = 0.05 * L * 4, U1 = sum(Lift), U2 = u2(Lift), U3 = u3(Lift), U4 = D * u4(omega^2)
+ * (attic/mars/dynamics/__init__.py:84-88, :135-164). */
+enum { CS_THRUST_B = 0, CS_THRUST_LIFT = 1 };
 
 /* Flight status codes, dynamics/__init__.py:65-68 */
 enum { CS_STATUS_CRASHED = 0, CS_STATUS_LANDED = 1, CS_STATUS_LEVELING = 2, CS_STATUS_AIRBORNE = 3 };
@@ -111,7 +129,7 @@ typedef struct cs_config {
   int32_t time_limit_truncates; /* 0 = upstream (step limit folded into `terminated`) */
   int32_t episode_stats;    /* 1 = keep per-env episode return on device */
   int32_t device;           /* HIP device ordinal */
-  int32_t max_steps;        /* task.py:35 */
+  int32_t max_steps;        /* task.py:35; at most 2^20 - 3 */
   int64_t num_envs;         /* environments held by this context (this shard) */
   int64_t env_id_base;      /* global id of local env 0: keys the RNG so that a batch
                                sharded over several contexts/GPUs is shard-invariant */
@@ -126,6 +144,14 @@ typedef struct cs_config {
   /* lander, lander.py:17-23 */
   double target_radius, yaw_penalty_factor, xyz_penalty_factor, dz_max, dz_penalty,
       inside_radius_bonus;
+  /* ---- model variants (defaults = the live upstream model) ---- */
+  int32_t action_arith;     /* CS_ARITH_*: how the motor model is evaluated */
+  int32_t thrust_model;     /* CS_THRUST_* */
+  int32_t rotor_gyro;       /* 0 = upstream's Omega = 0 (dynamics/__init__.py:135); 1 = the retired Mars
+                               model's Omega = u4(omegas) in the Jr terms (attic/mars/dynamics/__init__.py:143) */
+  int32_t reserved_;
+  double rho, C_L;          /* air density [kg/m^3] and lift coefficient of CS_THRUST_LIFT
+                               (attic/mars/dynamics/__init__.py:84-88, ingenuity.py:55,72-73) */
 } cs_config;
 
 typedef struct cs_ctx cs_ctx;
@@ -166,6 +192,10 @@ int cs_action_dim(const cs_ctx* ctx, int32_t* out); /* 4, 2 (2D variants) or 1 (
 /* Host-side settings: they take effect for launches enqueued afterwards.  A launch already
  * captured into a hipGraph carries the values of its capture time (the seed, the altitude and
  * every other cs_config value travel as kernel arguments): re-capture after changing them. */
+/* cs_seed re-keys the Philox streams: both 32-bit keys are halves of splitmix64(seed), so every bit
+ * of the 64-bit seed matters.  It does NOT touch the per-env episode counters (the other half of the
+ * Philox counter): seeding twice with the same value does not replay the same perturbations unless
+ * the counters are restored as well (cs_set_state(episode_host)). */
 int cs_seed(cs_ctx* ctx, uint64_t seed);
 int cs_set_altitude(cs_ctx* ctx, double altitude);
 /* Reset envs with mask_dev[i] != 0 (NULL = all).  force_xyz_dev: [3,N] perturbation
@@ -239,7 +269,7 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
 /* K steps in ONE launch under an on-device random policy -- the "random actions" workload
  * (lander.py --random / `env.action_space.sample()` loops) with no action tensor at all:
  * action ~ U[-1,1)^A on a 2^-15 grid from Philox2x32-10 with counter = (global env id, episode
- * number), key = (lo32(seed) ^ hi32(seed) ^ 0x5DEECE66) + step counter of the episode; four
+ * number), key = hi32(splitmix64(seed)) + step counter of the episode; four
  * 16-bit uniforms per draw, the task's A of them used.  Outputs as cs_rollout_pid
  * (actions_out_dev [K,N,A], nullable). */
 int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
@@ -249,12 +279,50 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
 /* Per-env vehicles and worlds (domain randomisation).  params_host: [CS_VEHICLE_ROWS, N] float64,
  * rows B, D, M, L, Ix, Iy, Iz, Jr, maxrpm -- the keys of the `vehicle_params` dict that
  * task.py:161 hands to Dynamics (dji_phantom.py:9-26; attic/mars/dynamics/ingenuity.py:46-75 for
- * another set) -- and G, the gravity constant (dynamics/__init__.py:76).  NULL returns to the
- * uniform values of cs_config.  Jr is accepted for completeness: upstream multiplies it by
- * Omega = 0 (:135).  Synchronous (first call allocates); call outside stream capture.  Steps then
- * read 72 more bytes per env. */
-enum { CS_VEHICLE_ROWS = 10 };
+ * another set) -- then the world: G, the gravity constant (dynamics/__init__.py:76), and rho, C_L
+ * (air density and lift coefficient; read only under CS_THRUST_LIFT).  NULL returns to the
+ * uniform values of cs_config.  Jr matters only with cfg.rotor_gyro (upstream multiplies it by
+ * Omega = 0, :135).  Synchronous (first call allocates); call outside stream capture.  Steps then
+ * read 88 more bytes per env. */
+enum { CS_VEHICLE_ROWS = 12 };
 int cs_set_vehicle_params(cs_ctx* ctx, const double* params_host);
+
+/* Dynamics.perturb(force) (dynamics/__init__.py:227-229) for the envs with mask_dev[i] != 0 (NULL =
+ * all): force_xyz_dev [3,N] float32 newtons becomes the pending perturbation, consumed (twice, as
+ * upstream applies it) by the next integrating Dynamics.setMotors call.  Enqueue only, graph-capturable. */
+int cs_set_perturbation(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, void* stream);
+
+/* Running statistics of the batch as CS_EPISODE_STATS float64 values on the DEVICE (enqueue only):
+ * [0] envs, [1] envs AIRBORNE, [2] sum and [3] max of the episode step counters, [4] episodes started
+ * (sum over envs), [5] sum of the running episode returns (0 without cfg.episode_stats). */
+enum { CS_EPISODE_STATS = 6 };
+int cs_episode_stats(cs_ctx* ctx, double* stats_dev, void* stream);
+
+/* Launcher thresholds that depend on the batch size (0 = built-in default).  They select between
+ * instantiations of the same step kernel and never change results.  cs_create also reads the
+ * environment variables COPTERSTEP_SPLIT_MAX_ENVS, COPTERSTEP_NT_ACTION_MAX_ENVS and
+ * COPTERSTEP_NT_STATE_MIN_ENVS. */
+typedef struct cs_tuning {
+  uint32_t struct_size;         /* sizeof(cs_tuning) */
+  uint32_t split_max_envs;      /* up to this many envs a tile is stepped by two wavefronts
+                                   (translational / rotational half); 1 disables the split */
+  uint32_t nt_action_max_envs;  /* up to this many envs the action rows are loaded non-temporally */
+  uint32_t nt_state_min_envs;   /* from this many envs the state is streamed past the caches */
+} cs_tuning;
+int cs_set_tuning(cs_ctx* ctx, const cs_tuning* tuning);
+int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out); /* the values in effect */
+
+/* ---- multi-GPU return path for C / C++ hosts: one RCCL all-gather over xGMI -------------------
+ * The env batch shards trivially (no collective in stepping); the only exchange is the optional
+ * concatenated return.  These wrap librccl (loaded on first use; CS_ERR_DEVICE if it is missing):
+ * one communicator per process and GPU, ncclAllGather on the caller's stream (graph-capturable). */
+typedef struct cs_comm cs_comm;
+enum { CS_COMM_ID_BYTES = 128 };
+int cs_comm_unique_id(void* id_out /* CS_COMM_ID_BYTES, from rank 0; ship it to the other ranks */);
+int cs_comm_create(const void* id, int32_t world_size, int32_t rank, cs_comm** out);
+int cs_comm_destroy(cs_comm* comm);
+/* recv_dev [world_size * bytes] <- every rank's send_dev [bytes], in rank order */
+int cs_allgather(cs_comm* comm, const void* send_dev, void* recv_dev, int64_t bytes, void* stream);
 
 /* Physics only: `substeps` x Dynamics.setMotors(motors[i]) on every env, raw motor
  * values (no clipping, no task logic). */
@@ -269,7 +337,10 @@ int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* ste
 /* Whole-batch state exchange with HOST buffers (parity tests, checkpoint/restore).
  * Any pointer may be NULL.  x_host is [12,N] float64 struct-of-arrays in upstream slot
  * order (x,dx,y,dy,z,dz,phi,dphi,theta,dtheta,psi,dpsi); force_xyz_host is [3,N] newtons;
- * flags_host bit0 = perturbation pending, bit1 = reset pending (NEXT_STEP);
+ * flags_host bit0 = perturbation pending, bit1 = reset pending (NEXT_STEP), bit2 (get only) = the
+ * episode's perturbation is an explicitly installed force rather than the Philox draw of
+ * (seed, global env id, episode - 1); force_xyz_host reports that force either way, and
+ * cs_set_state(force_xyz_host) installs an explicit one;
  * prev_shaping NaN = upstream's None; episode_host [N] = episodes started so far per env
  * (the Philox counter word of the next reset draw). */
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,

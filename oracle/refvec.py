@@ -53,10 +53,19 @@ def philox2x32_10(c0, c1, key):
     return c0, c1
 
 
+def splitmix64(z):
+    """The seed mix behind both Philox keys (every bit of the 64-bit seed matters)."""
+    m = (1 << 64) - 1
+    z = (int(z) + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
 def draw_forces(seed, env_ids, episode, magnitude):
     """Perturbation force draw shared (by specification) with the device kernel.
 
-    counter = (global env id, episode number of that env), key = lo32(seed) ^ hi32(seed);
+    counter = (global env id, episode number of that env), key = lo32(splitmix64(seed));
     the 64 output bits give three 21-bit uniforms u = bits * 2^-21 in [0,1);
     F = u * (2*magnitude) - magnitude, float64, un-fused multiply then add.
     Returns [3, n] float64.
@@ -64,8 +73,7 @@ def draw_forces(seed, env_ids, episode, magnitude):
     env_ids = np.asarray(env_ids, dtype=np.uint64)
     assert np.all(env_ids < (1 << 32))
     episode = np.broadcast_to(np.asarray(episode, dtype=np.uint32), env_ids.shape)
-    seed = int(seed) & ((1 << 64) - 1)
-    key = np.uint32((seed & 0xFFFFFFFF) ^ (seed >> 32))
+    key = np.uint32(splitmix64(int(seed) & ((1 << 64) - 1)) & 0xFFFFFFFF)
     r0, r1 = philox2x32_10(env_ids.astype(np.uint32), episode, key)
     bits = (r0 >> np.uint32(11), r1 >> np.uint32(11),
             ((r0 & np.uint32(0x7FF)) << np.uint32(10)) | (r1 & np.uint32(0x3FF)))
@@ -78,16 +86,15 @@ def draw_forces(seed, env_ids, episode, magnitude):
 
 def draw_actions(seed, env_ids, episode, steps, act_dim=4):
     """On-device random policy, shared (by specification) with the K-step kernel:
-    counter = (global env id, episode number), key = (lo32(seed) ^ hi32(seed) ^ 0x5DEECE66) +
+    counter = (global env id, episode number), key = hi32(splitmix64(seed)) +
     step counter of the episode; the 64 output bits give four 16-bit uniforms
     a = bits * 2^-15 - 1 in [-1, 1), exact in float32; the first `act_dim` are the action.
     Returns [n, act_dim] float32."""
     env_ids = np.asarray(env_ids, dtype=np.uint64)
     episode = np.broadcast_to(np.asarray(episode, dtype=np.uint32), env_ids.shape)
     steps = np.broadcast_to(np.asarray(steps).astype(np.uint32), env_ids.shape)
-    seed = int(seed) & ((1 << 64) - 1)
     with np.errstate(over="ignore"):
-        key = (np.uint32(((seed & 0xFFFFFFFF) ^ (seed >> 32) ^ 0x5DEECE66) & 0xFFFFFFFF) + steps).astype(np.uint32)
+        key = (np.uint32(splitmix64(int(seed) & ((1 << 64) - 1)) >> 32) + steps).astype(np.uint32)
     r0, r1 = philox2x32_10(env_ids.astype(np.uint32), episode, key)
     bits = np.stack([r0 >> np.uint32(16), r0 & np.uint32(0xFFFF), r1 >> np.uint32(16), r1 & np.uint32(0xFFFF)], axis=1)
     a = bits.astype(np.float32) * np.float32(2.0 ** -15) - np.float32(1.0)
@@ -100,12 +107,15 @@ def draw_actions(seed, env_ids, episode, steps, act_dim=4):
 _M64 = (1 << 64) - 1
 
 
+GUARD_BITS = 5
+
+
 def guard_round(x64):
-    """float64 -> the nearest value with 32 significant bits (a float32 word plus 8 guard
-    bits), as float64: add half of mantissa bit 21, clear bits 20..0."""
+    """float64 -> the nearest value with 29 significant bits (a float32 word plus 5 guard
+    bits), as float64: add half of mantissa bit 24, clear bits 23..0."""
     b = np.ascontiguousarray(x64, dtype=np.float64).view(np.uint64)
     with np.errstate(over="ignore"):
-        b = (b + np.uint64(1 << 20)) & np.uint64(~0x1FFFFF & _M64)
+        b = (b + np.uint64(1 << 23)) & np.uint64(~0xFFFFFF & _M64)
     return b.view(np.float64)
 
 

@@ -87,4 +87,4 @@ def assert_state_close(env, orc, x_tol, ctx=""):
 
 # tolerance of "device vs the oracle run in the SAME storage mode" (only float64 rounding
 # differences: fma contraction, reciprocal-multiply, sin/cos ulps) per mode
-MODE_TOL = {"float64": 1e-11, "float32": 2e-8, "float32_rn": 2e-6}
+MODE_TOL = {"float64": 1e-11, "float32": 2e-8, "float32_rn": 5e-6}
