@@ -629,11 +629,11 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, co
 // `nsub` x Dynamics.setMotors with one wrench.  The pending perturbation can only enter the FIRST
 // call: a call that freezes on ground contact keeps it, but the status it leaves (CRASHED / LEVELING)
 // makes the next call drop it.
-template <bool FULL, bool GYRO>
+template <bool FULL, bool GYRO, bool ONE_CALL>
 __device__ __forceinline__ void physics_substeps(const DevConst& c, const Coef& q, const Wrench& w,
                                                  double (&x)[12], int& fs, bool& pend, double px,
                                                  double py, double pz) {
-  if (c.nsub == 1) {  // upstream's own configuration: no loop
+  if constexpr (ONE_CALL) {  // upstream's own configuration (substeps = 1): no loop
     const int what = physics_call<FULL, GYRO>(c, q, w, x, fs, px, py, pz);
     pend = pend && what == kCallFroze;
     return;
@@ -768,7 +768,8 @@ template <int MODE, class TILE>
 __device__ __forceinline__ void store_env(const TILE& tile, const Env<MODE>& e) {
   using T = typename ModeOf<MODE>::T;
   T w[12];
-  words12<MODE>(e.x, w);
+  words6<MODE>(e.x, w);  // (two blocks of six: fewer registers live at once than one block of twelve)
+  words6<MODE>(e.x + 6, w + 6);
   const uint32_t gT = pack_guards6<MODE>(e.x) | ((uint32_t)e.fs << kStatusShift);
   const uint32_t gR = pack_guards6<MODE>(e.x + 6);
   typename TILE::Group t1, t2, r1, r2;
@@ -871,7 +872,7 @@ __device__ __forceinline__ Verdict judge_step(const DevConst& c, bool opt_trunc,
 // substeps -> stored-word rounding -> reward / termination -> optional done list and
 // final_obs -> masked auto-reset (task.py:145-197).  Shared by the one-step and the
 // K-step kernels, so both advance an env bit-identically.
-template <int TASK, int MODE, int OBS, bool LEAN, class TILE>
+template <int TASK, int MODE, int OBS, bool LEAN, bool ONE_CALL, class TILE>
 __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const StepOpts& o,
                                         Env<MODE>& e, const float4 act, const cs_step_io& io, uint32_t i,
                                         int lane, bool valid, const TILE& tile,
@@ -902,9 +903,9 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     bool gyro = false;
     if constexpr (!LEAN) gyro = o.gyro;
     if (gyro) {
-      physics_substeps<FULL, true>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+      physics_substeps<FULL, true, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
     } else {
-      physics_substeps<FULL, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+      physics_substeps<FULL, false, ONE_CALL>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
     }
   }
 
@@ -987,13 +988,11 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
 // no done list / final_obs, time limit folded into `terminated`, uniform vehicle, float64 motor
 // model, no rotor-inertia term): the optional features are compiled out instead of being skipped
 // by uniform branches.  PREFETCH: cs_step_io.next_actions_dev is set.
-template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool PREFETCH>
-__global__ __launch_bounds__(kBlock) void step_kernel(
-    // leading scalar arguments: preloaded into SGPRs with the wave (kernarg preload), so the
-    // first loads do not wait for an s_load of the argument block
+template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool PREFETCH, bool ONE_CALL>
+__device__ __forceinline__ void step_body(
     char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
-    const float* const next_actions_dev, const DevConst c, const DevState s_rest, const cs_step_io io_rest) {
+    const float* const next_actions_dev, const DevConst& c, const DevState& s_rest, const cs_step_io& io_rest) {
   using T = typename ModeOf<MODE>::T;
   DevState s = s_rest;
   s.tiles = tiles;
@@ -1066,7 +1065,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
     if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
   }
   StepOut<OBS> out;
-  advance<TASK, MODE, OBS, LEAN>(c, q, o, e, act, io, i, lane, valid, tile, out);
+  advance<TASK, MODE, OBS, LEAN, ONE_CALL>(c, q, o, e, act, io, i, lane, valid, tile, out);
   CS_STAMP(5);
 
   // ---- stores: 4 x 16 B (state, guards, counters) + prev_shaping ----
@@ -1085,6 +1084,19 @@ __global__ __launch_bounds__(kBlock) void step_kernel(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   CS_STAMP(7);
+}
+
+#define CS_STEP_ARGS                                                                                      \
+  /* leading scalar arguments: preloaded into SGPRs with the wave (kernarg preload), so the first loads  \
+     do not wait for an s_load of the argument block */                                                   \
+  char *const tiles, const uint32_t n_envs, const float *const actions_dev, float *const obs_dev,         \
+      float *const reward_dev, uint8_t *const terminated_dev, uint8_t *const truncated_dev,               \
+      const float *const next_actions_dev, const DevConst c, const DevState s_rest, const cs_step_io io_rest
+template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool PREFETCH, bool ONE_CALL>
+__global__ __launch_bounds__(kBlock) void step_kernel(CS_STEP_ARGS) {
+  step_body<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, ONE_CALL>(
+      tiles, n_envs, actions_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, next_actions_dev, c, s_rest,
+      io_rest);
 }
 
 // Pin a uniform value into vector registers (opaque to the optimiser).
@@ -1325,7 +1337,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       act_next = load_action<TASK>(actions_dev + (size_t)kn * n * ACT, ia);  // prefetch
     }
     StepOut<OBS> out;
-    advance<TASK, MODE, OBS, LEAN>(c, q, o, e, act, io, i, lane, valid, tile, out);
+    advance<TASK, MODE, OBS, LEAN, false>(c, q, o, e, act, io, i, lane, valid, tile, out);
     if constexpr (kPid) {
 #pragma unroll
       for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
@@ -1383,9 +1395,9 @@ __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, co
   double px, py, pz;
   pending_perturbation<MODE>(c, q, tile, i, e.episode, e.pend, e.expl, px, py, pz);
   if (c.gyro) {
-    physics_substeps<FULL, true>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+    physics_substeps<FULL, true, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
   } else {
-    physics_substeps<FULL, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+    physics_substeps<FULL, false, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
   }
 #pragma unroll
   for (int k = 0; k < 12; ++k) e.x[k] = round_stored<MODE>(e.x[k]);
@@ -1606,6 +1618,12 @@ bool lean_config(const DevConst& c, const DevState& s) {
          !c.act_f32;
 }
 
+// The headline combinations get every specialised instantiation of the lean kernel; the others one
+// generic lean build (keeps the code object and its build time in bounds).
+constexpr bool is_tuned(int task, int mode) {
+  return (task == CS_TASK_LANDER3D || task == CS_TASK_HOVER3D) && mode == CS_STATE_F32G;
+}
+
 template <int TASK, int MODE>
 hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, const Tuning& tune,
                   hipStream_t stream) {
@@ -1613,21 +1631,32 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, co
   const bool lean = lean_config(c, s) && io.done_count_dev == nullptr && io.final_obs_dev == nullptr;
   const uint32_t nt_act_max = tune.nt_action_max_envs ? tune.nt_action_max_envs : kNtActionMaxEnvs;
   const uint32_t nt_state_min = tune.nt_state_min_envs ? tune.nt_state_min_envs : kNtStateMinEnvs;
-#define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH)                                        \
-  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, PREFETCH>), grid,  \
-                     block, 0, stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev,  \
+#define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, ONE_CALL)                                        \
+  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, ONE_CALL>), grid, \
+                     block, 0, stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev,            \
                      io.terminated_dev, io.truncated_dev, io.next_actions_dev, c, s, io)
-  if (!lean)
-    CS_STEP(false, false, false, false);
-  else if (s.n <= nt_act_max) {  // the state fits the L2s: keep the action stream out of them
+#define CS_STEP_N(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH)       \
+  do {                                                            \
+    if (c.nsub == 1)                                              \
+      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, true);    \
+    else                                                          \
+      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, false);   \
+  } while (0)
+  if (!lean) {
+    CS_STEP(false, false, false, false, false);
+  } else if constexpr (!is_tuned(TASK, MODE)) {
+    CS_STEP(true, false, false, false, false);
+  } else if (s.n <= nt_act_max) {  // the state fits the L2s: keep the action stream out of them
     if (io.next_actions_dev != nullptr)
-      CS_STEP(true, true, false, true);
+      CS_STEP_N(true, true, false, true);
     else
-      CS_STEP(true, true, false, false);
-  } else if (s.n >= nt_state_min)  // the state exceeds the Infinity Cache: stream it past the caches
-    CS_STEP(true, false, true, false);
-  else
-    CS_STEP(true, false, false, false);
+      CS_STEP_N(true, true, false, false);
+  } else if (s.n >= nt_state_min) {  // the state exceeds the Infinity Cache: stream it past the caches
+    CS_STEP_N(true, false, true, false);
+  } else {
+    CS_STEP_N(true, false, false, false);
+  }
+#undef CS_STEP_N
 #undef CS_STEP
   return hipGetLastError();
 }
