@@ -305,7 +305,6 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   if (ctx == nullptr) return fail(CS_ERR_MEMORY, "cs_create: host allocation failed");
   std::memset(ctx, 0, sizeof *ctx);
   ctx->cfg = *cfg;
-  ctx->tune.split_max_envs = env_u32("COPTERSTEP_SPLIT_MAX_ENVS");
   ctx->tune.nt_action_max_envs = env_u32("COPTERSTEP_NT_ACTION_MAX_ENVS");
   ctx->tune.nt_state_min_envs = env_u32("COPTERSTEP_NT_STATE_MIN_ENVS");
   ctx->layout = cs::make_layout(cfg->state_mode);
@@ -666,7 +665,6 @@ int cs_set_tuning(cs_ctx* ctx, const cs_tuning* t) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (t == nullptr || t->struct_size != sizeof(cs_tuning))
     return fail(CS_ERR_ARG, "cs_set_tuning: tuning missing or struct_size mismatch");
-  ctx->tune.split_max_envs = t->split_max_envs;
   ctx->tune.nt_action_max_envs = t->nt_action_max_envs;
   ctx->tune.nt_state_min_envs = t->nt_state_min_envs;
   return CS_OK;
@@ -676,7 +674,6 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out) {
   if (check_ctx(ctx) || out == nullptr) return fail(CS_ERR_ARG, "cs_get_tuning: null argument");
   const cs::Tuning d = cs::default_tuning();
   out->struct_size = (uint32_t)sizeof(cs_tuning);
-  out->split_max_envs = ctx->tune.split_max_envs ? ctx->tune.split_max_envs : d.split_max_envs;
   out->nt_action_max_envs = ctx->tune.nt_action_max_envs ? ctx->tune.nt_action_max_envs : d.nt_action_max_envs;
   out->nt_state_min_envs = ctx->tune.nt_state_min_envs ? ctx->tune.nt_state_min_envs : d.nt_state_min_envs;
   return CS_OK;

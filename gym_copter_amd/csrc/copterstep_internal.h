@@ -37,10 +37,8 @@ namespace cs {
 // In the float64 mode a group's third 8-byte word carries (gT or gR) in its low and (meta or
 // episode) in its high dword and the fourth word is unused; there are no guard bits.
 //
-// The split into a translational and a rotational half is the split of the physics itself:
-// within one Dynamics.setMotors() the two halves only READ each other (attitude -> thrust
-// direction), so the small-batch kernel gives them to two wavefronts (copterstep_kernels.hip).
-// A wavefront touches one contiguous 5.5 KB region, and every field is reached from a per-lane
+// (The split into a translational and a rotational half is the split of the physics itself: within
+// one Dynamics.setMotors() the two halves only READ each other's old values.)  A wavefront touches one contiguous 5.5 KB region, and every field is reached from a per-lane
 // base address with an instruction immediate.
 // ---------------------------------------------------------------------------------
 constexpr int kTileEnvs = 64;
@@ -197,7 +195,6 @@ struct DevState {
 
 // Launcher choices that depend on the batch size (see launch_step); 0 = built-in default.
 struct Tuning {
-  uint32_t split_max_envs;      // <= this many envs: two wavefronts per tile (translational + rotational)
   uint32_t nt_action_max_envs;  // <= this many envs: action rows are loaded with the non-temporal hint
   uint32_t nt_state_min_envs;   // >= this many envs: the state is streamed past the caches
 };

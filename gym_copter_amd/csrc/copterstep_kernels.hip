@@ -9,15 +9,6 @@
 //   written through a per-wavefront LDS transpose as full 16-byte-per-lane stores ->
 //   wave-ballot compaction of the finished-episode list.
 //
-// Two forms of that kernel:
-//   step_kernel        one wavefront per tile.  Batches that give every SIMD two or more wavefronts.
-//   step_split_kernel  two wavefronts per tile, one integrating the translational half of the rigid
-//                      body (x..dz: thrust direction, ground contact, position shaping) and one the
-//                      rotational half (phi..dpsi: torques, tilt, yaw shaping); they meet once, through
-//                      LDS, for the reward.  A lone wavefront issues one instruction per ~5.5 cycles
-//                      whatever its type (tools/ubench.hip), a SIMD takes two such streams at once: at
-//                      65 536 envs (one tile per SIMD) the split halves the issue-bound part of the step.
-//
 // Upstream semantics followed (paths relative to the upstream checkout):
 //   dynamics/__init__.py:114-197 (setMotors), :249-290 (state derivative),
 //   :292-302 (_bodyZToInertial), envs/task.py:77-137 (step), :145-202 (reset),
@@ -100,10 +91,6 @@ constexpr uint32_t kNtActionMaxEnvs = 98304;
 // streaming it (non-temporal loads and stores) measured -17 % time at 4 M envs and -14 % at 16 M
 // under reset churn, but +7..25 % at 1 M envs and below, where the caches do hold it.
 constexpr uint32_t kNtStateMinEnvs = 3670016;  // 3.5 M (3 M envs still measured 5..10 % better un-streamed)
-// Up to this batch size a tile gets two wavefronts (step_split_kernel): beyond it every SIMD already
-// holds two or more one-wavefront tiles and the split only adds its hand-over.
-constexpr uint32_t kSplitMaxEnvs = 98304;
-
 template <bool STREAM, class V>
 __device__ __forceinline__ V load_maybe_stream(const V* p) {
   if constexpr (STREAM) {
@@ -296,25 +283,11 @@ __device__ __forceinline__ uint32_t guard_of(double value) {
   }
 }
 
-// The twelve float32 words of twelve stored values in one go (CS_STATE_F32G): a stored value has 29
+// The float32 words of six stored values in one go (CS_STATE_F32G): a stored value has 29
 // significant bits, its word is the value truncated to 24 -- v_cvt_f32_f64 under round-toward-zero
 // (the conversion follows MODE.fp_round[1:0], the float32 field: tools/ubench.hip), which saves the
-// and + register-pair copy per component that masking the low dword first would cost.
-__device__ __forceinline__ void words_of_rtz(const double (&v)[12], float (&w)[12]) {
-  asm volatile(
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
-      "s_nop 0\n\t"
-      "v_cvt_f32_f64 %0, %12\n\tv_cvt_f32_f64 %1, %13\n\tv_cvt_f32_f64 %2, %14\n\tv_cvt_f32_f64 %3, %15\n\t"
-      "v_cvt_f32_f64 %4, %16\n\tv_cvt_f32_f64 %5, %17\n\tv_cvt_f32_f64 %6, %18\n\tv_cvt_f32_f64 %7, %19\n\t"
-      "v_cvt_f32_f64 %8, %20\n\tv_cvt_f32_f64 %9, %21\n\tv_cvt_f32_f64 %10, %22\n\tv_cvt_f32_f64 %11, %23\n\t"
-      "s_nop 0\n\t"
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]),
-        "=&v"(w[7]), "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11])
-      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
-        "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]));
-}
-// six of them (one half of the rigid body)
+// and + register-pair copy per component that masking the low dword first would cost.  Six per block
+// (one half of the rigid body): fewer registers live at once than a block of twelve.
 __device__ __forceinline__ void words_of_rtz6(const double* v, float* w) {
   asm volatile(
       "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
@@ -328,15 +301,6 @@ __device__ __forceinline__ void words_of_rtz6(const double* v, float* w) {
 }
 
 // float32 / float64 words of already rounded values
-template <int MODE>
-__device__ __forceinline__ void words12(const double (&v)[12], typename ModeOf<MODE>::T (&w)[12]) {
-  if constexpr (MODE == CS_STATE_F32G) {
-    words_of_rtz(v, w);
-  } else {
-#pragma unroll
-    for (int k = 0; k < 12; ++k) w[k] = (typename ModeOf<MODE>::T)v[k];
-  }
-}
 template <int MODE>
 __device__ __forceinline__ void words6(const double* v, typename ModeOf<MODE>::T* w) {
   if constexpr (MODE == CS_STATE_F32G) {
@@ -768,7 +732,7 @@ template <int MODE, class TILE>
 __device__ __forceinline__ void store_env(const TILE& tile, const Env<MODE>& e) {
   using T = typename ModeOf<MODE>::T;
   T w[12];
-  words6<MODE>(e.x, w);  // (two blocks of six: fewer registers live at once than one block of twelve)
+  words6<MODE>(e.x, w);
   words6<MODE>(e.x + 6, w + 6);
   const uint32_t gT = pack_guards6<MODE>(e.x) | ((uint32_t)e.fs << kStatusShift);
   const uint32_t gR = pack_guards6<MODE>(e.x + 6);
@@ -831,30 +795,31 @@ __device__ __forceinline__ void pending_perturbation(const DevConst& c, const Co
   }
 }
 
-// reward / termination of one step (task.py:104-130, lander.py:58-74) from its ingredients
+// reward / termination of one step (task.py:104-130, lander.py:58-74) from its ingredients:
+// sh = shaping potential of the new state, inside = sqrt(x^2+y^2) < target radius, oob / tilt = the
+// bounds and angle tests on the new state
 struct Verdict {
   double reward;
   bool term, trunc;
 };
 template <int TASK>
 __device__ __forceinline__ Verdict judge_step(const DevConst& c, bool opt_trunc, int status0, int steps,
-                                              double sh, double prev_sh, double x, double y, double phi,
-                                              double the) {
+                                              double sh, double prev_sh, bool inside, bool oob, bool tilt) {
   double reward;
   bool done = false;
   if constexpr (task_is_lander(TASK)) {
     reward = (prev_sh != prev_sh) ? 0.0 : sh - prev_sh;  // NaN == None
     if (status0 == CS_STATUS_LANDED) {
       done = true;
-      if (fma(x, x, y * y) < c.target_r2) reward += c.bonus;
+      if (inside) reward += c.bonus;
     }
   } else {
     reward = 1.0;
   }
-  if (fabs(x) >= c.bounds || fabs(y) >= c.bounds) {
+  if (oob) {
     done = true;
     reward -= c.oob_penalty;
-  } else if (fabs(phi) >= c.max_angle || fabs(the) >= c.max_angle) {
+  } else if (tilt) {
     done = true;
     reward = -c.oob_penalty;
   } else if (status0 == CS_STATUS_CRASHED) {
@@ -866,6 +831,15 @@ __device__ __forceinline__ Verdict judge_step(const DevConst& c, bool opt_trunc,
   v.term = done || (!opt_trunc && limit);
   v.reward = reward;
   return v;
+}
+__device__ __forceinline__ bool test_inside(const DevConst& c, double x, double y) {
+  return fma(x, x, y * y) < c.target_r2;
+}
+__device__ __forceinline__ bool test_oob(const DevConst& c, double x, double y) {
+  return fabs(x) >= c.bounds || fabs(y) >= c.bounds;
+}
+__device__ __forceinline__ bool test_tilt(const DevConst& c, double phi, double the) {
+  return fabs(phi) >= c.max_angle || fabs(the) >= c.max_angle;
 }
 
 // _Task.step() (task.py:77-137) for one register-resident env: Dynamics.setMotors x
@@ -921,8 +895,9 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
   if (!resetting) {
     double sh = 0.0;
     if constexpr (task_is_lander(TASK)) sh = lander_shaping(c, e.x);
-    const Verdict v = judge_step<TASK>(c, o.trunc, status0, e.steps, sh, e.prev_sh, e.x[0], e.x[2],
-                                       e.x[6], e.x[8]);
+    const Verdict v = judge_step<TASK>(c, o.trunc, status0, e.steps, sh, e.prev_sh,
+                                       test_inside(c, e.x[0], e.x[2]), test_oob(c, e.x[0], e.x[2]),
+                                       test_tilt(c, e.x[6], e.x[8]));
     if constexpr (task_is_lander(TASK)) e.prev_sh = (double)(T)sh;
     reward = v.reward;
     term = v.term;
@@ -1719,7 +1694,7 @@ hipError_t reset_t(const DevConst& c, const DevState& s, const uint8_t* mask, co
 
 }  // namespace
 
-Tuning default_tuning() { return Tuning{kSplitMaxEnvs, kNtActionMaxEnvs, kNtStateMinEnvs}; }
+Tuning default_tuning() { return Tuning{kNtActionMaxEnvs, kNtStateMinEnvs}; }
 
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                        const cs_step_io& io, const Tuning& tune, hipStream_t stream) {

@@ -300,12 +300,9 @@ int cs_episode_stats(cs_ctx* ctx, double* stats_dev, void* stream);
 
 /* Launcher thresholds that depend on the batch size (0 = built-in default).  They select between
  * instantiations of the same step kernel and never change results.  cs_create also reads the
- * environment variables COPTERSTEP_SPLIT_MAX_ENVS, COPTERSTEP_NT_ACTION_MAX_ENVS and
- * COPTERSTEP_NT_STATE_MIN_ENVS. */
+ * environment variables COPTERSTEP_NT_ACTION_MAX_ENVS and COPTERSTEP_NT_STATE_MIN_ENVS. */
 typedef struct cs_tuning {
   uint32_t struct_size;         /* sizeof(cs_tuning) */
-  uint32_t split_max_envs;      /* up to this many envs a tile is stepped by two wavefronts
-                                   (translational / rotational half); 1 disables the split */
   uint32_t nt_action_max_envs;  /* up to this many envs the action rows are loaded non-temporally */
   uint32_t nt_state_min_envs;   /* from this many envs the state is streamed past the caches */
 } cs_tuning;

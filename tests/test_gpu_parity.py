@@ -1171,3 +1171,43 @@ def test_random_pose_resets_match_oracle(task, mode):
             got, want, _ = step_both(env, orc, a)
             assert_step_close(got, want, max(MODE_TOL[mode], 2e-6), r_abs=2e-3, r_rel=2e-6, ctx=(rnd, t))
     env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# launcher choices (stream hints by batch size) never change results
+# ---------------------------------------------------------------------------------------
+def test_tuning_overrides_from_the_environment(monkeypatch):
+    """COPTERSTEP_* environment variables are read by cs_create; cs_set_tuning overrides them;
+    zero returns to the built-in default."""
+    import gym_copter_amd
+    monkeypatch.setenv("COPTERSTEP_NT_ACTION_MAX_ENVS", "1234")
+    env = gym_copter_amd.CopterVecEnv("lander3d", 256)
+    t = env.get_tuning()
+    assert t["nt_action_max_envs"] == 1234 and t["nt_state_min_envs"] == 3670016
+    t = env.set_tuning(nt_state_min_envs=512)
+    assert t == {"nt_action_max_envs": 98304, "nt_state_min_envs": 512}
+    env.close()
+
+
+@pytest.mark.parametrize("tuning", [dict(nt_action_max_envs=1, nt_state_min_envs=1),      # streamed state
+                                    dict(nt_action_max_envs=1)])                           # plain (vs streamed actions)
+def test_stream_hint_instantiations_agree(tuning):
+    """The three instantiations of the lean kernel (streamed actions / plain / streamed state) produce
+    identical results on the same batch: the thresholds only choose cache hints."""
+    import torch
+    n = 3000
+    rng = np.random.default_rng(9)
+    ref, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=2)
+    alt, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=2)
+    alt.set_tuning(**tuning)
+    ref.reset()
+    alt.reset()
+    for t in range(50):
+        a = torch.from_numpy(rng.uniform(-1, 1, (n, 4)).astype(np.float32)).to(ref.device)
+        for u, v in zip(ref.step(a)[:4], alt.step(a)[:4]):
+            assert torch.equal(u, v), (tuning, t)
+    s1, s2 = ref.get_state(), alt.get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k], equal_nan=True), k
+    ref.close()
+    alt.close()

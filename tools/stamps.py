@@ -43,7 +43,7 @@ for rep in range(10):
     env.step(acts[rep % 8])
     torch.cuda.synchronize()
     lib.cs_debug_read_stamps(env._ctx, buf.ctypes.data_as(C.c_void_p), None)
-    b = buf[:N // 64].astype(np.int64)
+    b = buf[:max(1, N // 64)].astype(np.int64)
     # slots in use: 0 kernel entry, 1 loads landed, 5 step body done, 6 stores issued, 7 stores acknowledged
     res.append(np.stack([b[:, 1] - b[:, 0], b[:, 5] - b[:, 4], b[:, 6] - b[:, 5], b[:, 7] - b[:, 6],
                          b[:, 7] - b[:, 0], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1], b[:, 4] - b[:, 3]], axis=1))
