@@ -201,6 +201,30 @@ int check_ctx(const cs_ctx* ctx) {
 
 }  // namespace
 
+namespace cs {
+
+// Host restatement of the kernels' draw_force() (copterstep_kernels.hip): cs_get_state reports the
+// pending force of an env whose perturbation is the Philox draw.
+void host_draw_force(uint32_t key, uint32_t env_id, uint32_t episode, double force_mag, bool f32_words,
+                     double (&f)[3]) {
+  uint32_t c0 = env_id, c1 = episode;
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p = (unsigned long long)0xD256D193U * c0;
+    c0 = (uint32_t)(p >> 32) ^ key ^ c1;
+    c1 = (uint32_t)p;
+    key += 0x9E3779B9U;
+  }
+  const uint32_t u[3] = {c0 >> 11, c1 >> 11, ((c0 & 0x7FFu) << 10) | (c1 & 0x3FFu)};
+  const double two_f = 2.0 * force_mag * 0x1.0p-21;
+  for (int k = 0; k < 3; ++k) {
+    const double v = (double)u[k] * two_f - force_mag;
+    f[k] = f32_words ? (double)(float)v : v;
+  }
+}
+
+
+}  // namespace cs
+
 extern "C" {
 
 int cs_version(void) { return CS_ABI_VERSION; }

@@ -3,7 +3,11 @@
 // include/copterstep.h.
 #pragma once
 
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else  // host-only builds of the C-ABI layer (tests/host/host_logic_san.cpp: g++ -fsanitize=address,undefined)
+#include <hip/hip_runtime_api.h>
+#endif
 #include <stdint.h>
 
 #include "copterstep.h"

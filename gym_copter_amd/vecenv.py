@@ -583,7 +583,7 @@ class CopterVecEnv:
 
     STATS_NAMES = ("envs", "airborne", "steps_sum", "steps_max", "episodes_started", "return_sum")
 
-    def episode_stats(self):
+    def batch_stats(self):
         """Batch bookkeeping reduced on the device (cs_episode_stats): a float64 tensor [6] =
         (envs, envs airborne, sum and max of the episode step counters, episodes started, sum of the
         running episode returns), asynchronous on the current stream."""

@@ -80,8 +80,11 @@ class TaskParams:
 class RigidBody:
     """One quad-X rigid body, forward-Euler integrated in Euler angles."""
 
-    def __init__(self, vp=DJI_PHANTOM, frames_per_second=100, g=G):
+    def __init__(self, vp=DJI_PHANTOM, frames_per_second=100, g=G, mars=None):
+        """mars = (rho, C_L): the retired Mars model instead of the live one -- lift-coefficient
+        thrust law and a live rotor-inertia term (attic/mars/dynamics/__init__.py:78-164)."""
         self.vp = vp
+        self.mars = mars
         self.g = g                       # Dynamics.G (a class constant upstream, :76)
         self.dt = 1. / frames_per_second
         self.ticks = 0
@@ -129,11 +132,23 @@ class RigidBody:
         p = self.vp
         w = np.array(motorvals) * p.maxrpm * np.pi / 30       # rad/s
         w2 = w ** 2
-        U1 = p.B * np.sum(w2)
-        U2 = p.L * p.B * ((w2[1] + w2[2]) - (w2[0] + w2[3]))  # roll right
-        U3 = p.L * p.B * ((w2[1] + w2[3]) - (w2[0] + w2[2]))  # pitch forward
-        U4 = p.D * ((w2[0] + w2[1]) - (w2[2] + w2[3]))        # yaw cw
-        Omega = 0                                             # rotor-inertia term disabled upstream
+        if self.mars is None:
+            U1 = p.B * np.sum(w2)
+            U2 = p.L * p.B * ((w2[1] + w2[2]) - (w2[0] + w2[3]))  # roll right
+            U3 = p.L * p.B * ((w2[1] + w2[3]) - (w2[0] + w2[2]))  # pitch forward
+            U4 = p.D * ((w2[0] + w2[1]) - (w2[2] + w2[3]))        # yaw cw
+            Omega = 0                                             # rotor-inertia term disabled upstream
+        else:
+            # attic/mars/dynamics/__init__.py:135-164 (setMotors) with S from :88
+            rho, C_L = self.mars
+            S = .05 * p.L * 4
+            Omega = (w[0] + w[1]) - (w[2] + w[3])                 # u4(omegas), before squaring
+            velocity = w * p.L / 2
+            lift = 0.5 * rho * S * C_L * (velocity ** 2)
+            U1 = np.sum(lift)
+            U2 = (lift[1] + lift[2]) - (lift[0] + lift[3])
+            U3 = (lift[1] + lift[3]) - (lift[0] + lift[2])
+            U4 = p.D * ((w2[0] + w2[1]) - (w2[2] + w2[3]))
 
         acc = self._thrust_ned(-U1 / p.M, self.x[PHI], self.x[THETA], self.x[PSI])
         netz = acc[2] + self.g

@@ -132,11 +132,13 @@ class VecOracle:
 
     def __init__(self, task="lander3d", num_envs=1, tp=TaskParams(), vp=DJI_PHANTOM,
                  substeps=1, store_mode="float64", autoreset=AUTORESET_DISABLED,
-                 seed=0, env_id_base=0, time_limit_truncates=False, g=G):
-        # vp's fields and g may be arrays [n]: per-env vehicles / worlds (domain randomisation)
+                 seed=0, env_id_base=0, time_limit_truncates=False, g=G, mars=None):
+        # vp's fields and g may be arrays [n]: per-env vehicles / worlds (domain randomisation);
+        # mars = (rho, C_L) (scalars or arrays [n]): the retired Mars model, see refcpu.RigidBody
         assert task in TASKS
         self.task, self.n, self.tp, self.vp = task, int(num_envs), tp, vp
         self.g = g
+        self.mars = mars
         self.kind, self.obs_first, self.obs_dim, fan = TASKS[task]
         self.fan = np.array(fan)
         self.act_dim = task_action_dim(task)
@@ -173,11 +175,25 @@ class VecOracle:
         w = motors * (maxrpm[:, None] if maxrpm.ndim else maxrpm) * np.pi / 30
         w2 = w ** 2
         w0, w1, w2_, w3 = w2[:, 0], w2[:, 1], w2[:, 2], w2[:, 3]
-        U1 = p.B * (((w0 + w1) + w2_) + w3)
-        U2 = p.L * p.B * ((w1 + w2_) - (w0 + w3))
-        U3 = p.L * p.B * ((w1 + w3) - (w0 + w2_))
-        U4 = p.D * ((w0 + w1) - (w2_ + w3))
-        Omega = 0
+        if self.mars is None:
+            U1 = p.B * (((w0 + w1) + w2_) + w3)
+            U2 = p.L * p.B * ((w1 + w2_) - (w0 + w3))
+            U3 = p.L * p.B * ((w1 + w3) - (w0 + w2_))
+            U4 = p.D * ((w0 + w1) - (w2_ + w3))
+            Omega = 0
+        else:      # attic/mars/dynamics/__init__.py:135-164
+            rho, C_L = self.mars
+            L = np.asarray(p.L, dtype=np.float64)
+            S = .05 * L * 4
+            Omega = (w[:, 0] + w[:, 1]) - (w[:, 2] + w[:, 3])
+            velocity = w * (L[:, None] if L.ndim else L) / 2
+            kl = 0.5 * rho * S * C_L
+            lift = (kl[:, None] if np.ndim(kl) else kl) * (velocity ** 2)
+            l0, l1, l2, l3 = lift[:, 0], lift[:, 1], lift[:, 2], lift[:, 3]
+            U1 = ((l0 + l1) + l2) + l3
+            U2 = (l1 + l2) - (l0 + l3)
+            U3 = (l1 + l3) - (l0 + l2)
+            U4 = p.D * ((w0 + w1) - (w2_ + w3))
 
         phi, the, psi = x[6], x[8], x[10]
         cph, cth, cps = np.cos(phi), np.cos(the), np.cos(psi)

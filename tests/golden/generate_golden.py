@@ -31,7 +31,11 @@ Further series, all flown on the imported live classes:
     lander2d.py:43-50, hover1d.py:44-50, hover2d.py:44-50;
   * W (vehicle_traces.npz): the live Lander with other `vehicle_params` dicts and
     gravity constants (the module global of envs/task.py and Dynamics.G are
-    swapped for the duration of the run).
+    swapped for the duration of the run);
+  * M (mars_traces.npz): the retired Mars dynamics, attic/mars/dynamics/__init__.py +
+    ingenuity.py loaded by file path (NumPy only): the lift-coefficient thrust law
+    Lift = 0.5*rho*S*C_L*(omega*L/2)^2 with world parameters G / rho, and the
+    rotor-inertia term with Omega = u4(omegas); setMotors() + update() per tick.
 
 Inputs are made float32-representable (actions, perturbation forces, vehicle
 parameters) so that the fp32 device path can be fed bit-identical inputs; the
@@ -464,6 +468,7 @@ def main():
     save("variant_traces.npz", v_series(_Task, Lander, vp))
     save("vehicle_traces.npz", w_series(Dynamics, Lander, vp))
     save("pose_traces.npz", r_series(_Task, Lander, vp))
+    save("mars_traces.npz", m_series(*load_mars_dynamics()))
     # known-answer constants observed from the reference (used as spot checks)
     meta = dict(numpy_version=np.array(np.__version__), hover_motor=np.float64(hover_motor(vp)))
     np.savez(os.path.join(OUT, "meta.npz"), **meta)
@@ -612,6 +617,101 @@ def p_series(Lander, pid, HoverRef=None):
                      pos=dict(Kp=0.0002, Ki=0.0, Kd=0.0))
         cases["H03_hover_tuned"] = run_pid_hover_episode(HoverRef, pid, seed=42, steps=1100, gains=tuned)
         cases["H04_hover_tuned"] = run_pid_hover_episode(HoverRef, pid, seed=43, steps=1100, gains=tuned, altitude=5.0)
+    return cases
+
+
+# --------------------------------------------------------------------------
+# M-series: the retired Mars dynamics (lift-coefficient thrust law, air density, rotor-inertia term)
+# --------------------------------------------------------------------------
+def load_mars_dynamics():
+    """attic/mars/dynamics/__init__.py and ingenuity.py depend on NumPy only; ingenuity.py imports its
+    base class as `from dynamics import MultirotorDynamics`, so the package is registered under that name."""
+    d = os.path.join(REF, "attic", "mars", "dynamics")
+    spec = importlib.util.spec_from_file_location("dynamics", os.path.join(d, "__init__.py"),
+                                                  submodule_search_locations=[d])
+    pkg = importlib.util.module_from_spec(spec)
+    saved = sys.modules.get("dynamics")
+    sys.modules["dynamics"] = pkg
+    try:
+        spec.loader.exec_module(pkg)
+        ing = importlib.import_module("dynamics.ingenuity")
+    finally:
+        if saved is None:
+            sys.modules.pop("dynamics", None)
+        else:
+            sys.modules["dynamics"] = saved
+    return pkg.MultirotorDynamics, ing.CoaxialDynamics, ing.IngenuityDynamics
+
+
+def run_mars(dyn, x0, force, motors):
+    """motors [T,4]: setMotors(m); update() per tick (attic/mars/task.py's loop)."""
+    dyn.setState(np.array(x0, dtype=np.float64))
+    status0 = dyn.getStatus()
+    if force is not None:
+        dyn.perturb(np.array(force, dtype=np.float64))
+    T = motors.shape[0]
+    xs = np.zeros((T, 12))
+    st = np.zeros(T, dtype=np.int8)
+    for t in range(T):
+        dyn.setMotors(motors[t])
+        dyn.update()
+        xs[t] = dyn._x
+        st[t] = dyn.getStatus()
+    vehicle = np.array([dyn.B, dyn.D, dyn.M, dyn.L, dyn.Ix, dyn.Iy, dyn.Iz, dyn.Jr, dyn.maxrpm,
+                        dyn.G, dyn.rho, dyn.C_L], dtype=np.float64)
+    return dict(fps=np.int64(round(1.0 / dyn._dt)), x0=np.array(x0, dtype=np.float64), status0=np.int8(status0),
+                force=np.zeros(6) if force is None else np.array(force, dtype=np.float64),
+                motors=motors, x=xs, status=st, vehicle=vehicle)
+
+
+def m_series(MultirotorDynamics, CoaxialDynamics, IngenuityDynamics):
+    rng = np.random.default_rng(4242)
+    cases = {}
+
+    def lift_hover(d):      # 4 * 0.5*rho*S*C_L*(w*L/2)^2 = M*G
+        kl = 0.5 * d.rho * d.S * d.C_L * (d.L / 2) ** 2
+        return float(np.sqrt(d.M * d.G / (4 * kl)) / (d.maxrpm * np.pi / 30))
+
+    def airborne(alt=10.0, **kw):
+        x = np.zeros(12)
+        x[4] = -alt
+        for k, v in kw.items():
+            x[int(k[1:])] = v
+        return x
+
+    T = 1000
+    ones = np.ones((T, 4))
+    # Ingenuity on Mars (ingenuity.py:46-75): thin air, the hover motor value is ~0.73
+    d = IngenuityDynamics(100)
+    hov = lift_hover(d)
+    cases["M01_ingenuity_hover"] = run_mars(d, airborne(), f32r([4.5, -2.25, 1.0, 0, 0, 0]), f32r(hov) * ones)
+    d = IngenuityDynamics(100)
+    m = f32r(hov * np.array([1.0, 1.004, 0.998, 1.002]))          # all three torques and Omega != 0
+    cases["M02_ingenuity_asymmetric"] = run_mars(d, airborne(50.0, i7=0.02, i9=-0.01, i11=0.05), f32r([1, 2, 3, 0, 0, 0]), m * ones)
+    d = IngenuityDynamics(100)
+    mseq = f32r(np.clip(hov * (1.0 + 0.03 * rng.standard_normal((T, 4))), 0, 1))
+    cases["M03_ingenuity_random"] = run_mars(
+        d, airborne(200.0, i1=0.5, i3=-0.25, i6=0.05, i7=0.3, i8=-0.03, i9=-0.2, i10=0.3, i11=-0.4),
+        f32r([9.5, -9.5, 3.0, 0, 0, 0]), mseq)
+    # the same airframe in Earth's air and gravity (the module's default world parameters)
+    vp = dict(B=5.e-6, D=2.e-6, M=1.380, L=0.350, C_L=0.4, Ix=2, Iy=2, Iz=3, Jr=38e-4, maxrpm=15000)
+    d = CoaxialDynamics(vp, 100, {'G': 9.80655, 'rho': 1.225})
+    hov_e = lift_hover(d)
+    cases["M04_earth_hover"] = run_mars(d, airborne(), f32r([-3.5, 21.0, -9.75, 0, 0, 0]), f32r(hov_e) * ones)
+    # a heavier rotor (Jr x 5) and asymmetric inertia: the rotor-inertia term carries weight
+    vp2 = dict(vp, Jr=0.019, Ix=1.5, Iy=2.5, C_L=0.55, L=0.3)
+    d = CoaxialDynamics(vp2, 100, {'G': 3.721, 'rho': 0.25})
+    hov2 = lift_hover(d)
+    mseq = f32r(np.clip(hov2 * (1.0 + 0.02 * rng.standard_normal((500, 4))), 0, 1))
+    cases["M05_heavy_rotor"] = run_mars(d, airborne(300.0, i7=0.1, i9=0.08, i11=-0.1), None, mseq)
+    # take-off from LANDED, free-fall crash, soft landing: the flight-status machine of update()
+    d = IngenuityDynamics(100)
+    ramp = f32r(np.linspace(0.0, min(1.0, 1.3 * hov), 300))[:, None] * np.ones((300, 4))
+    cases["M06_takeoff"] = run_mars(d, np.zeros(12), None, ramp)
+    d = IngenuityDynamics(100)
+    cases["M07_crash"] = run_mars(d, airborne(3.0), None, np.zeros((300, 4)))
+    d = IngenuityDynamics(100)
+    cases["M08_soft_landing"] = run_mars(d, airborne(0.05, i6=0.01), None, f32r(0.97 * hov) * np.ones((400, 4)))
     return cases
 
 

@@ -142,6 +142,78 @@ int main() {
     CHECK(std::fabs(last[i * od + 5] - dz8) < 1e-6 && std::fabs(last[i * od + 4] - z8) < 1e-5);
   }
 
+  // ---- Dynamics.perturb on the device, masked: only env 7 gets a 13.8 N push along x ----
+  OK(cs_reset(ctx, nullptr, force, obs, stream));
+  {
+    std::vector<float> h_force(3 * n, 0.0f);
+    std::vector<uint8_t> h_mask(n, 0);
+    h_force[7] = 13.8f;  // row 0 = force_x, env 7
+    h_mask[7] = 1;
+    uint8_t* mask;
+    float* pf;
+    HIP(hipMalloc((void**)&mask, n));
+    HIP(hipMalloc((void**)&pf, 3 * n * sizeof(float)));
+    HIP(hipMemcpyAsync(mask, h_mask.data(), n, hipMemcpyHostToDevice, stream));
+    HIP(hipMemcpyAsync(pf, h_force.data(), 3 * n * sizeof(float), hipMemcpyHostToDevice, stream));
+    OK(cs_set_perturbation(ctx, mask, pf, stream));
+    OK(cs_step(ctx, act, obs, rew, term, trunc, stream));  // motors 0: free fall
+    if (fetch()) return 2;
+    // the perturbation enters the first integrated step twice (dynamics :263-271 and :183)
+    const double dx = 2.0 * ((double)13.8f / cfg.M) * dt;
+    CHECK(std::fabs(h_obs[7 * od + 1] - dx) <= 1e-6 * dx);
+    CHECK(h_obs[6 * od + 1] == 0.0f && h_obs[8 * od + 1] == 0.0f);
+    HIP(hipFree(mask));
+    HIP(hipFree(pf));
+  }
+
+  // ---- batch statistics reduced on the device ----
+  {
+    double* stats;
+    HIP(hipMalloc((void**)&stats, CS_EPISODE_STATS * sizeof(double)));
+    OK(cs_episode_stats(ctx, stats, stream));
+    double h_stats[CS_EPISODE_STATS];
+    HIP(hipMemcpyAsync(h_stats, stats, sizeof h_stats, hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    // after reset + one step: every env airborne, step counter 2, four episodes started so far (four cs_reset calls)
+    CHECK(h_stats[0] == (double)n && h_stats[1] == (double)n && h_stats[2] == 2.0 * n && h_stats[3] == 2.0);
+    CHECK(h_stats[4] == 4.0 * n && h_stats[5] == 0.0);
+    HIP(hipFree(stats));
+  }
+
+  // ---- launcher tuning: defaults, override, back to defaults ----
+  {
+    cs_tuning t;
+    OK(cs_get_tuning(ctx, &t));
+    CHECK(t.struct_size == sizeof(cs_tuning) && t.nt_action_max_envs == 98304 && t.nt_state_min_envs == 3670016);
+    t.nt_action_max_envs = 5;
+    t.nt_state_min_envs = 0;
+    OK(cs_set_tuning(ctx, &t));
+    OK(cs_get_tuning(ctx, &t));
+    CHECK(t.nt_action_max_envs == 5 && t.nt_state_min_envs == 3670016);
+    t.struct_size = 3;
+    CHECK(cs_set_tuning(ctx, &t) == CS_ERR_ARG);
+  }
+
+  // ---- the concatenated return for C / C++ hosts: RCCL all-gather, here with a world of one ----
+  {
+    char id[CS_COMM_ID_BYTES];
+    OK(cs_comm_unique_id(id));
+    cs_comm* comm = nullptr;
+    OK(cs_comm_create(id, 1, 0, &comm));
+    float* gathered;
+    HIP(hipMalloc((void**)&gathered, n * od * sizeof(float)));
+    HIP(hipMemsetAsync(gathered, 0xFF, n * od * sizeof(float), stream));
+    OK(cs_allgather(comm, obs, gathered, (int64_t)(n * od * sizeof(float)), stream));
+    std::vector<float> h_g(n * od);
+    HIP(hipMemcpyAsync(h_g.data(), gathered, h_g.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP(hipStreamSynchronize(stream));
+    for (size_t k = 0; k < h_g.size(); ++k) CHECK(h_g[k] == h_obs[k]);
+    cs_comm* bad = nullptr;
+    CHECK(cs_comm_create(id, 1, 1, &bad) == CS_ERR_ARG && bad == nullptr);  // rank out of range
+    OK(cs_comm_destroy(comm));
+    HIP(hipFree(gathered));
+  }
+
   // ---- errors come back as codes + messages, never as exceptions or aborts ----
   CHECK(cs_step(ctx, nullptr, obs, rew, term, trunc, stream) != 0);
   CHECK(cs_last_error()[0] != '\0');

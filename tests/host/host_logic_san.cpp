@@ -1,0 +1,153 @@
+// Host-only unit test of the C-ABI layer's CPU code paths (constant folding, configuration
+// validation, the tile codec, the host Philox restatement) under AddressSanitizer + UBSan:
+//   g++ -std=c++17 -x c++ -fsanitize=address,undefined -fno-sanitize-recover=all -I include -I /opt/rocm/include \
+//       tests/host/host_logic_san.cpp -L/opt/rocm/lib -lamdhip64 -ldl -o host_logic_san && ./host_logic_san
+// The kernels are not part of this build: the launchers are stubbed (no GPU is touched; cs_create fails
+// with CS_ERR_DEVICE on a machine without one, which is one of the paths under test).
+// Run by tests/test_host_sanitizers.py (-m "not gpu").
+#define __HIP_PLATFORM_AMD__ 1
+#include "../../gym_copter_amd/csrc/copterstep_api.hip"
+
+#include <cassert>
+#include <cinttypes>
+
+namespace cs {
+Tuning default_tuning() { return Tuning{98304u, 3670016u}; }
+hipError_t launch_step(int, int, const DevConst&, const DevState&, const cs_step_io&, const Tuning&, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_step_many(int, int, const DevConst&, const DevState&, int, float*, float*, float*, uint8_t*, uint8_t*, int,
+                            const PidConst*, double*, uint32_t, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_export_state(int, const DevConst&, const DevState&, float*, uint8_t*, int32_t*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_set_motors(int, const DevConst&, const DevState&, const float*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_reset(int, int, const DevConst&, const DevState&, const uint8_t*, const float*, float*, double*, uint32_t,
+                        const float*, int, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_set_perturbation(int, const DevState&, const uint8_t*, const float*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_episode_stats(int, const DevState&, double*, hipStream_t) { return hipErrorUnknown; }
+}  // namespace cs
+
+#define REQUIRE(cond)                                                        \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      std::fprintf(stderr, "REQUIRE failed line %d: %s\n", __LINE__, #cond); \
+      return 1;                                                              \
+    }                                                                        \
+  } while (0)
+
+int main() {
+  // ---- configuration defaults and validation (no device needed up to the device query) ----
+  cs_config cfg;
+  REQUIRE(cs_config_init(&cfg, CS_TASK_LANDER3D) == CS_OK);
+  REQUIRE(cs_config_init(nullptr, 0) == CS_ERR_ARG && cs_config_init(&cfg, 99) == CS_ERR_ARG);
+  REQUIRE(cs_config_init(&cfg, CS_TASK_HOVER3D) == CS_OK);
+  cs_ctx* ctx = nullptr;
+  cs_config bad = cfg;
+  bad.struct_size += 4;
+  REQUIRE(cs_create(&bad, &ctx) == CS_ERR_ABI && ctx == nullptr);
+  bad = cfg;
+  bad.num_envs = 0;
+  REQUIRE(cs_create(&bad, &ctx) == CS_ERR_ARG);
+  bad = cfg;
+  bad.max_steps = 1 << 20;
+  REQUIRE(cs_create(&bad, &ctx) == CS_ERR_ARG);
+  bad = cfg;
+  bad.action_arith = CS_ARITH_F32;
+  bad.thrust_model = CS_THRUST_LIFT;
+  REQUIRE(cs_create(&bad, &ctx) == CS_ERR_ARG && std::strstr(cs_last_error(), "float32 motor model") != nullptr);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    REQUIRE(cs_create(&cfg, &ctx) == CS_ERR_DEVICE && std::strstr(cs_last_error(), "no CPU fallback") != nullptr);
+  REQUIRE(cs_step(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) == CS_ERR_ARG);
+  REQUIRE(cs_destroy(nullptr) == CS_OK && cs_comm_destroy(nullptr) == CS_OK);
+  REQUIRE(cs_comm_create(nullptr, 1, 0, nullptr) == CS_ERR_ARG);
+
+  // ---- constant folding: the live model and the Mars model, all tasks and state modes ----
+  for (int task = 0; task < CS_TASK_COUNT; ++task) {
+    for (int mode = CS_STATE_F32G; mode <= CS_STATE_F64; ++mode) {
+      cs_ctx fake;
+      std::memset(&fake, 0, sizeof fake);
+      REQUIRE(cs_config_init(&fake.cfg, task) == CS_OK);
+      fake.cfg.state_mode = mode;
+      fake.cfg.seed = 0x0123456789ABCDEFull * (uint64_t)(task + 1);
+      fake.cfg.env_id_base = ((int64_t)1 << 32) - 5;
+      fake.layout = cs::make_layout(mode);
+      const cs::DevConst c = make_const(&fake);
+      REQUIRE(c.k_thrust < 0 && c.k_roll > 0 && c.k_yaw > 0 && c.dt == 0.01 && c.two_inv_M == 2.0 / 1.380);
+      REQUIRE(std::isnan(c.reset_shaping) == !cs::task_is_lander(task));
+      REQUIRE(c.gyro == 0 && c.act_f32 == 0 && c.key_force != c.key_action);
+      REQUIRE(c.f32_pi == 3.14159274101257324f && c.f32_LB == (float)(0.35 * 5e-3));
+      fake.cfg.thrust_model = CS_THRUST_LIFT;
+      fake.cfg.rotor_gyro = 1;
+      fake.cfg.rho = 0.017;
+      fake.cfg.G = 3.721;
+      const cs::DevConst m = make_const(&fake);
+      // Lift = 0.5*rho*S*C_L*(omega*L/2)^2 with S = 0.05*L*4: thrust per unit sum(m^2)
+      const double ws = 15000 * kPi / 30, KL = 0.5 * 0.017 * (0.05 * 0.35 * 4) * 0.4 * (0.35 / 2) * (0.35 / 2) * ws * ws;
+      REQUIRE(std::fabs(m.k_thrust + KL / 1.380) < 1e-12 * KL && std::fabs(m.k_roll - KL / 2) < 1e-12 * KL);
+      REQUIRE(m.gyro == 1 && m.g_phi == 38e-4 / 2 * ws && m.G == 3.721);
+      // ---- tile layout: every field of every env of a few tiles inside the slab, no two fields overlap ----
+      fake.st.n = 200;
+      fake.st.ntiles = 4;
+      HostTiles h;
+      h.ctx = &fake;
+      h.buf.assign((size_t)fake.st.ntiles * fake.layout.tile_bytes, 0);
+      const cs::Layout& L = fake.layout;
+      for (size_t i = 0; i < fake.st.n; ++i) {
+        for (int k = 0; k < 12; ++k) h.set_word(i, L.x(k), 1000.0 * (double)i + k);
+        h.set_u32(i, L.gT(), 0xA0000000u + (uint32_t)i);
+        h.set_u32(i, L.gR(), 0xB0000000u + (uint32_t)i);
+        h.set_u32(i, L.meta(), 0xC0000000u + (uint32_t)i);
+        h.set_u32(i, L.epi(), 0xD0000000u + (uint32_t)i);
+        h.set_word(i, L.prev(), -1.0 - (double)i);
+        for (int j = 0; j < 3; ++j) h.set_word(i, L.f(j), 0.5 * (double)i + j);
+        const float r = (float)i;
+        std::memcpy(h.at(i, L.ret_()), &r, 4);
+      }
+      for (size_t i = 0; i < fake.st.n; ++i) {
+        for (int k = 0; k < 12; ++k) REQUIRE(h.get_word(i, L.x(k)) == 1000.0 * (double)i + k);
+        REQUIRE(h.get_u32(i, L.gT()) == 0xA0000000u + i && h.get_u32(i, L.gR()) == 0xB0000000u + i);
+        REQUIRE(h.get_u32(i, L.meta()) == 0xC0000000u + i && h.get_u32(i, L.epi()) == 0xD0000000u + i);
+        REQUIRE(h.get_word(i, L.prev()) == -1.0 - (double)i);
+        for (int j = 0; j < 3; ++j) REQUIRE(h.get_word(i, L.f(j)) == 0.5 * (double)i + j);
+      }
+    }
+  }
+
+  // ---- the 29-significant-bit word codec: round trip, rounding, carries, special values ----
+  const double samples[] = {0.0,      -0.0,        1.0,       -10.0,          0.1,       1.0 / 3.0, 123456.789,
+                            1e-30,    -7.25e-12,   3.5e37,    0x1.fffffffffffffp0, 0x1.ffffffep0, 0x1.fffffffp3,
+                            5e-324,   1e-310,      2.2250738585072014e-308};
+  for (double v : samples) {
+    float w;
+    uint32_t g;
+    f32g_encode(v, &w, &g);
+    REQUIRE(g <= cs::kGuardFieldMask);
+    const double back = f32g_decode(w, g);
+    if (std::fabs(v) > 1e-30 && std::fabs(v) < 1e38) {
+      REQUIRE(std::fabs(back - v) <= std::ldexp(std::fabs(v), -29));  // half a unit of the 29th bit
+      float w2;
+      uint32_t g2;
+      f32g_encode(back, &w2, &g2);
+      REQUIRE(w2 == w && g2 == g);  // a stored value is a fixed point of the codec
+    }
+  }
+  {
+    float w;
+    uint32_t g;
+    f32g_encode(std::numeric_limits<double>::infinity(), &w, &g);
+    REQUIRE(std::isinf(w));
+    f32g_encode(std::numeric_limits<double>::quiet_NaN(), &w, &g);
+    REQUIRE(std::isnan(w));
+  }
+
+  // ---- the host Philox restatement: in range, on the 21-bit grid, keyed by every input ----
+  double f[3], g2[3];
+  cs::host_draw_force(123u, 7u, 3u, 30.0, false, f);
+  for (double v : f) REQUIRE(v >= -30.0 && v < 30.0 && std::floor(v * 2097152.0 / 60.0) == v * 2097152.0 / 60.0);
+  cs::host_draw_force(123u, 7u, 4u, 30.0, false, g2);
+  REQUIRE(f[0] != g2[0] || f[1] != g2[1]);
+  cs::host_draw_force(123u, 7u, 3u, 30.0, true, g2);
+  for (int k = 0; k < 3; ++k) REQUIRE(g2[k] == (double)(float)f[k]);
+  REQUIRE(splitmix64(0) == 0xE220A8397B1DCDAFull && splitmix64(1) != splitmix64(0x100000000ull));
+  REQUIRE(env_u32("COPTERSTEP_SURELY_UNSET_VARIABLE") == 0);
+  std::printf("host_logic_san: OK\n");
+  return 0;
+}

@@ -1,0 +1,364 @@
+"""-m gpu parity tests added in round 2: the float32 motor-model path of the reference (golden E10),
+BASELINE configs 4 and 5 at their real sizes, the retired Mars model (lift-coefficient thrust law,
+air density, rotor-inertia term), the device-side Dynamics.perturb / batch statistics entry points,
+the 64-bit tile addressing at the context size limit, odd batch sizes in the K-step kernels, and the
+sharded env under RCCL in a spawned process group."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_cases
+from gpu_util import MODE_TOL, assert_state_close, assert_step_close, have_gpu, make_pair, scaled_err, step_both, to_np
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENV = load_cases("env_traces.npz")
+MARS = load_cases("mars_traces.npz")
+HOVER = float(np.load(os.path.join(os.path.dirname(__file__), "golden", "meta.npz"))["hover_motor"])
+BAR = 1e-5   # BASELINE.json: <= 1e-5 relative fp32 per state component over 1000 steps
+
+
+# ---------------------------------------------------------------------------------------
+# float32 action arrays: the reference evaluates the motor model in float32 (golden E10)
+# ---------------------------------------------------------------------------------------
+def _fly_e10(**kw):
+    import torch
+    g = ENV["E10_lander_f32_actions"]
+    env, _ = make_pair("lander3d", 1, "float32", **kw)
+    env.reset(options={"forces": g["force"][:3].astype(np.float32).reshape(3, 1)})
+    T = int(g["first_done"]) + 1
+    worst, worst_r = 0.0, 0.0
+    for t in range(T):
+        obs, r, term, _, _ = env.step(torch.from_numpy(g["actions"][t].astype(np.float32)[None]).to(env.device))
+        worst = max(worst, scaled_err(to_np(obs)[0], g["obs"][t]))
+        assert bool(to_np(term)[0]) == bool(g["done"][t]), t
+        if t % 100 == 0 or t == T - 1:
+            st = env.get_state()
+            worst = max(worst, scaled_err(st["x"][:, 0], g["x"][t]))
+        sh = abs(g["prev_shaping"][t]) if np.isfinite(g["prev_shaping"][t]) else 0.0
+        worst_r = max(worst_r, abs(float(to_np(r)[0]) - g["reward"][t]) / (5e-5 + 1e-5 * abs(g["reward"][t]) + 6e-7 * sh))
+    env.close()
+    return worst, worst_r, T
+
+
+def test_float32_motor_model_matches_the_reference_on_float32_actions():
+    """action_arith="float32" restates NumPy's float32 evaluation of dynamics/__init__.py:120-132 (what
+    the reference computes when `action` is a float32 ndarray): the reference's own float32-action
+    episode (1001 steps to the step limit) inside the 1e-5 bar, rewards inside their tolerance."""
+    worst, worst_r, T = _fly_e10(action_arith="float32")
+    print("E10, float32 motor model: worst scaled error %.3e over %d steps" % (worst, T))
+    assert T >= 1000 and worst <= BAR and worst_r <= 1.0
+
+
+def test_float64_motor_model_on_float32_actions_stays_within_a_stated_bound():
+    """The default float64 motor model against the same float32-action episode: a KNOWN deviation of
+    the default mode -- the two arithmetics part by ~1e-5 over 1000 steps.
+    Measured here and held to 3e-5."""
+    worst, _, T = _fly_e10()
+    print("E10, float64 motor model: worst scaled error %.3e over %d steps" % (worst, T))
+    assert worst <= 3e-5
+
+
+def test_float32_motor_model_vs_scalar_oracle_batch():
+    """The float32 motor model over a batch with reset churn against the scalar oracle's passthrough
+    mode (real NumPy float32 arithmetic), env by env."""
+    import torch
+    from oracle.refcpu import TaskOracle
+    n, T = 24, 120
+    rng = np.random.default_rng(3)
+    env, _ = make_pair("lander3d", n, "float64", action_arith="float32")
+    forces = rng.uniform(-30, 30, (3, n)).astype(np.float32)
+    env.reset(options={"forces": forces})
+    orcs = [TaskOracle("lander3d", action_dtype_passthrough=True) for _ in range(n)]
+    for i, o in enumerate(orcs):
+        o.reset(force_xyz=forces[:, i].astype(np.float64))
+    acts = (HOVER * (1 + 0.2 * rng.standard_normal((T, n, 4)))).astype(np.float32)
+    for t in range(T):
+        obs, r, term, _, _ = env.step(torch.from_numpy(acts[t]).to(env.device))
+        obs, r, term = to_np(obs), to_np(r), to_np(term)
+        for i, o in enumerate(orcs):
+            wobs, wr, wdone, _, _ = o.step(acts[t, i])
+            assert scaled_err(obs[i], wobs) <= 1e-9, (t, i)
+            assert bool(term[i]) == bool(wdone) and abs(float(r[i]) - wr) <= 5e-5 + 1e-5 * abs(wr), (t, i)
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE config 4 (524 288 envs as 8 shards of 65 536) and config 5 (10 substeps) at size
+# ---------------------------------------------------------------------------------------
+def test_config4_eight_shards_equal_one_batch():
+    """Eight 65 536-env contexts with env_id_base = r * 65 536 (the per-GPU shards of BASELINE config 4,
+    here on one GPU) against ONE 524 288-env context: identical observations, rewards, flags and final
+    state through reset churn -- trajectories do not depend on how the batch is sharded."""
+    import torch
+    import gym_copter_amd
+    n, G, T = 65536, 8, 40
+    mk = lambda num, base: gym_copter_amd.CopterVecEnv("lander3d", num, seed=2026, autoreset_mode="next_step",
+                                                        env_id_base=base)
+    whole = mk(n * G, 0)
+    shards = [mk(n, r * n) for r in range(G)]
+    o_w = whole.reset()[0]
+    for r, e in enumerate(shards):
+        assert torch.equal(e.reset()[0], o_w[r * n:(r + 1) * n])
+    gen = torch.Generator(device=whole.device)
+    gen.manual_seed(5)
+    for t in range(T):
+        a = torch.rand((n * G, 4), generator=gen, device=whole.device) * 2 - 1
+        ow, rw, tw, uw, _ = whole.step(a)
+        for r, e in enumerate(shards):
+            sl = slice(r * n, (r + 1) * n)
+            os_, rs, ts, us, _ = e.step(a[sl].contiguous())
+            assert torch.equal(os_, ow[sl]) and torch.equal(rs, rw[sl]), (t, r)
+            assert torch.equal(ts, tw[sl]) and torch.equal(us, uw[sl]), (t, r)
+    sw = whole.get_state()
+    assert sw["episode"].max() >= 3           # several auto-resets per env on average
+    for r in (0, 3, 7):
+        ss = shards[r].get_state()
+        for k in ss:
+            assert np.array_equal(ss[k], sw[k][..., r * n:(r + 1) * n], equal_nan=True), (r, k)
+    for e in shards + [whole]:
+        e.close()
+
+
+def test_config5_ten_substeps_at_65536_envs_vs_oracle():
+    """BASELINE config 5 at its real size: Lander3D, 65 536 envs, dt = 1e-3 x 10 Dynamics.setMotors calls
+    per step, near-hover actions, 100 steps, every 20th step and the final state against the oracle."""
+    n, T = 65536, 100
+    rng = np.random.default_rng(11)
+    env, orc = make_pair("lander3d", n, "float32", substeps=10, seed=4)
+    env.reset()
+    orc.reset()
+    for t in range(T):
+        a = (HOVER * (1 + 0.01 * rng.standard_normal((n, 4)))).astype(np.float32)
+        got, want, _ = step_both(env, orc, a)
+        if t % 20 == 0 or t == T - 1:
+            assert_step_close(got, want, MODE_TOL["float32"], ctx="t=%d" % t)
+    worst = assert_state_close(env, orc, MODE_TOL["float32"])
+    print("config 5 at 65 536 envs: worst scaled state error vs the oracle after %d steps %.3e" % (T, worst))
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# the retired Mars model: lift-coefficient thrust law, air density, live rotor-inertia term
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["float32", "float64"])
+def test_golden_mars_dynamics_as_one_batch(mode):
+    """attic/mars/dynamics (setMotors + update per tick) flown by the reference for eight vehicles /
+    worlds (Ingenuity on Mars, the same airframe in Earth's air, a heavy rotor, take-off, crash, soft
+    landing), replayed as ONE device batch through cs_set_motors with per-env parameter columns."""
+    import torch
+    cs = MARS.names()
+    n = len(cs)
+    T = max(len(MARS[c]["status"]) for c in cs)
+    env, _ = make_pair("lander3d", n, mode, thrust_model="lift", rotor_gyro=True)
+    env.set_vehicle_params(np.stack([MARS[c]["vehicle"] for c in cs], axis=1))
+    x0 = np.stack([MARS[c]["x0"] for c in cs], axis=1)
+    status0 = np.array([int(MARS[c]["status0"]) for c in cs], np.uint8)
+    force = np.stack([MARS[c]["force"][:3] for c in cs], axis=1)
+    flags = np.array([1 if np.any(MARS[c]["force"]) else 0 for c in cs], np.uint8)
+    env.set_state(x=x0, status=status0, force=force, flags=flags, steps=np.ones(n, np.int32))
+    motors = np.zeros((T, n, 4), dtype=np.float32)
+    for i, c in enumerate(cs):
+        m = MARS[c]["motors"]
+        motors[:len(m), i] = m
+        motors[len(m):, i] = m[-1]
+    tol = 1e-9 if mode == "float64" else BAR
+    worst = 0.0
+    for t in range(T):
+        env.set_motors(torch.from_numpy(motors[t]).to(env.device))
+        if t % 10 and t != T - 1:
+            continue
+        st = env.get_state()
+        for i, c in enumerate(cs):
+            g = MARS[c]
+            if t < len(g["status"]):
+                e = scaled_err(st["x"][:, i], g["x"][t])
+                worst = max(worst, e)
+                assert e <= tol, (c, t, e)
+                assert st["status"][i] == g["status"][t], (c, t)
+    print("Mars model, %s: worst scaled error vs the reference %.3e" % (mode, worst))
+    env.close()
+
+
+@pytest.mark.parametrize("mode,autoreset", [("float32", "next_step"), ("float64", "same_step")])
+def test_mars_model_steps_match_oracle(mode, autoreset):
+    """The full step (task logic, auto-reset, cs_step_many) on the Mars model, uniform Ingenuity
+    parameters from cs_config, against the oracle with the same model."""
+    import torch
+    import gym_copter_amd
+    from gpu_util import AUTORESET
+    from oracle.refcpu import TaskParams, VehicleParams
+    from oracle.refvec import VecOracle
+    n, K = 1500, 20
+    rng = np.random.default_rng(8)
+    vp = dict(B=5.e-6, D=2.e-6, M=1.380, L=0.350, Ix=2, Iy=2, Iz=3, Jr=38e-4, maxrpm=15000)
+    kw = dict(task="lander3d", num_envs=n, state_dtype=mode, autoreset_mode=autoreset, seed=6,
+              vehicle_params=dict(vp, C_L=0.4), world_params=dict(G=3.721, rho=0.017), thrust_model="lift",
+              rotor_gyro=True)
+    env, many = gym_copter_amd.CopterVecEnv(**kw), gym_copter_amd.CopterVecEnv(**kw)
+    orc = VecOracle("lander3d", n, TaskParams(), vp=VehicleParams(**vp), store_mode=mode,
+                    autoreset=AUTORESET[autoreset], seed=6, g=3.721, mars=(0.017, 0.4))
+    assert np.array_equal(to_np(env.reset()[0]), orc.reset())
+    many.reset()
+    hover = 0.26717326
+    tol = max(MODE_TOL[mode], 2e-6)
+    for chunk in range(3):
+        law = rng.uniform(-1, 1, (K, n, 4)) if chunk == 0 else hover * (1 + 0.05 * rng.standard_normal((K, n, 4)))
+        acts = law.astype(np.float32)
+        obs_m, rew_m, term_m, _ = many.step_many(torch.from_numpy(acts).to(many.device))
+        for k in range(K):
+            got, want, _ = step_both(env, orc, acts[k])
+            assert_step_close(got, want, tol, r_abs=2e-3, r_rel=2e-6, ctx=(mode, chunk, k))
+            assert np.array_equal(to_np(obs_m[k]), got[0]) and np.array_equal(to_np(rew_m[k]), got[1])
+            assert np.array_equal(to_np(term_m[k]), got[2])
+        assert_state_close(env, orc, tol)
+    env.close()
+    many.close()
+
+
+# ---------------------------------------------------------------------------------------
+# device-side Dynamics.perturb (masked) and batch statistics
+# ---------------------------------------------------------------------------------------
+def test_set_perturbation_is_masked_and_graph_capturable():
+    import torch
+    n = 777
+    rng = np.random.default_rng(1)
+    env, orc = make_pair("lander3d", n, "float32", seed=3)
+    env.reset()
+    orc.reset()
+    a = (HOVER * np.ones((n, 4))).astype(np.float32)
+    for _ in range(3):
+        step_both(env, orc, a)                       # the reset perturbation is consumed
+    f = rng.uniform(-20, 20, (3, n)).astype(np.float32)
+    mask = rng.random(n) < 0.4
+    ft, mt = torch.from_numpy(f).to(env.device), torch.from_numpy(mask).to(env.device)
+    g = torch.cuda.CUDAGraph()                       # cs_set_perturbation only enqueues: capturable
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        env.set_perturbation(ft, mask=mt)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        env.set_perturbation(ft, mask=mt)
+    g.replay()
+    orc.force[:, mask] = f[:, mask].astype(orc.T)
+    orc.pending[mask] = True
+    st = env.get_state()
+    assert np.array_equal((st["flags"] & 1).astype(bool), mask)
+    assert np.array_equal((st["flags"] & 4) != 0, mask)            # explicitly installed forces
+    assert np.array_equal(st["force"][:, mask], f[:, mask].astype(np.float64))
+    for _ in range(3):
+        got, want, _ = step_both(env, orc, a)
+        assert_step_close(got, want, MODE_TOL["float32"])
+    assert_state_close(env, orc, MODE_TOL["float32"])
+    env.close()
+
+
+def test_episode_stats_match_the_state():
+    n = 5000
+    rng = np.random.default_rng(2)
+    env, _ = make_pair("hover3d", n, "float32", autoreset="next_step", seed=1, episode_stats=True)
+    env.reset()
+    import torch
+    for _ in range(25):
+        env.step(torch.from_numpy(rng.uniform(-1, 1, (n, 4)).astype(np.float32)).to(env.device))
+    s = to_np(env.batch_stats())
+    st = env.get_state()
+    assert s[0] == n and s[1] == np.sum(st["status"] == 3)
+    assert s[2] == st["steps"].sum() and s[3] == st["steps"].max() and s[4] == st["episode"].sum()
+    assert abs(s[5] - st["episode_return"].sum()) <= 1e-6 * max(1.0, abs(s[5]))
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# sizes: odd batches in the K-step kernels (8-byte aligned row blocks), the context size limit
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task,n", [("lander3d", 4131), ("hover2d", 1023), ("lander1d", 63)])
+def test_step_many_on_odd_batch_sizes(task, n):
+    """With an odd n the row block of step k >= 1 (obs_dev + k*n*OBS floats) is only 8-byte aligned: the
+    K-step kernels then store rows without the 16-byte vector path.  Bit-identical to single steps."""
+    import torch
+    K = 7
+    rng = np.random.default_rng(n)
+    many, _ = make_pair(task, n, "float32", autoreset="next_step", seed=3)
+    one, _ = make_pair(task, n, "float32", autoreset="next_step", seed=3)
+    many.reset()
+    one.reset()
+    for chunk in range(3):
+        acts = torch.from_numpy(rng.uniform(-1, 1, (K, n, many.action_dim)).astype(np.float32)).to(many.device)
+        obs, rew, term, trunc = many.step_many(acts)
+        for k in range(K):
+            o, r, t, u, _ = one.step(acts[k])
+            assert torch.equal(obs[k], o) and torch.equal(rew[k], r) and torch.equal(term[k], t), (chunk, k)
+    many.close()
+    one.close()
+
+
+def test_float64_mode_at_the_context_size_limit():
+    """2^25 envs in float64 words: 5.8 GB of tiles, byte offsets past 2^32 (the tile base is 64-bit).
+    Every env gets the same inputs, so the last tile must equal the first after reset + steps."""
+    import torch
+    import gym_copter_amd
+    n = 1 << 25
+    env = gym_copter_amd.CopterVecEnv("lander3d", n, state_dtype="float64", seed=0)
+    z = torch.zeros((3, n), dtype=torch.float32, device=env.device)
+    z[0] = 7.5
+    env.reset(options={"forces": z})
+    a = torch.full((n, 4), 1.7e-2, dtype=torch.float32, device=env.device)
+    for _ in range(3):
+        obs, r, term, _, _ = env.step(a)
+    assert torch.equal(obs[:64], obs[-64:]) and torch.equal(obs[0], obs[n // 2 + 12345])
+    assert float(obs[0, 1]) != 0.0 and float(obs[-1, 4]) < -9.9
+    t = env.state_tensors()
+    assert torch.equal(t["x"][:, :64], t["x"][:, -64:]) and int(t["steps"][-1]) == 4
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# the sharded env in its own process group under RCCL (world 1: what one GPU allows)
+# ---------------------------------------------------------------------------------------
+_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from gym_copter_amd.sharded import ShardedCopterVecEnv
+import gym_copter_amd
+n = 4096
+for gather in ("none", "obs", "all"):
+    plain = gym_copter_amd.CopterVecEnv("lander3d", n, seed=5, autoreset_mode="next_step")
+    env = ShardedCopterVecEnv("lander3d", total_envs=n, gather=gather, seed=5, autoreset_mode="next_step")
+    assert env.world == 1 and env.n_local == n
+    o, _ = env.reset()
+    op, _ = plain.reset()
+    assert torch.equal(o, op)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    graph = None
+    for t in range(30):
+        a = torch.rand((n, 4), generator=g, device="cuda") * 2 - 1
+        got = env.step(a)
+        want = plain.step(a)
+        for u, v in zip(got[:4], want[:4]):
+            assert torch.equal(u.reshape(v.shape), v), (gather, t)
+    env.close()
+    plain.close()
+dist.barrier()
+dist.destroy_process_group()
+print("SHARDED_OK")
+"""
+
+
+def test_sharded_env_in_a_spawned_nccl_process_group(tmp_path):
+    """ShardedCopterVecEnv (the real CopterVecEnv underneath, gather none / obs / all) in a child process
+    that initialises torch.distributed with the nccl (= RCCL) backend, world size 1."""
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "SHARDED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

@@ -138,3 +138,31 @@ def test_pose_reset_bit_exact(name):
         assert np.array_equal(obs, g["obs"][t]) and r == g["reward"][t] and done == g["done"][t], (name, t)
         assert o.body.status == g["status"][t] and o.steps == g["steps"][t], (name, t)
         assert np.array_equal(o.body.x, g["x"][t]), (name, t)
+
+
+MARS = load_cases("mars_traces.npz")
+
+
+def mars_body(g):
+    """RigidBody configured as the retired Mars model from a golden case's `vehicle` row
+    (B, D, M, L, Ix, Iy, Iz, Jr, maxrpm, G, rho, C_L)."""
+    from oracle.refcpu import VehicleParams
+    v = g["vehicle"]
+    return RigidBody(VehicleParams(*[float(x) for x in v[:9]]), int(g["fps"]), g=float(v[9]),
+                     mars=(float(v[10]), float(v[11])))
+
+
+@pytest.mark.parametrize("name", MARS.names())
+def test_mars_dynamics_trace_bit_exact(name):
+    """The lift-coefficient thrust law, air density and the live rotor-inertia term of
+    attic/mars/dynamics (setMotors + update per tick), bit for bit."""
+    g = MARS[name]
+    b = mars_body(g)
+    b.set_state(g["x0"])
+    assert b.status == g["status0"]
+    if np.any(g["force"]):
+        b.perturb(g["force"])
+    for t, m in enumerate(g["motors"]):
+        b.set_motors(m)
+        assert np.array_equal(b.x, g["x"][t]), (name, t)
+        assert b.status == g["status"][t], (name, t)

@@ -323,3 +323,29 @@ def test_vec_pose_resets_bit_exact_in_batch():
                         assert np.array_equal(obs[i], g["obs"][t]) and r[i] == g["reward"][t], (c, t)
                         assert term[i] == g["done"][t] and o.status[i] == g["status"][t], (c, t)
                         assert np.array_equal(o.x[:, i], g["x"][t]), (c, t)
+
+
+def test_vec_mars_dynamics_bit_exact_in_batch():
+    """All Mars-model golden traces (lift-coefficient thrust law, per-env air density / gravity,
+    live rotor-inertia term) as ONE batch with per-env parameter arrays."""
+    from conftest import load_cases
+    from oracle.refcpu import VehicleParams
+    M = load_cases("mars_traces.npz")
+    cs = M.names()
+    n = len(cs)
+    veh = np.stack([M[c]["vehicle"] for c in cs], axis=1)            # [12, n]
+    o = VecOracle("lander3d", n, vp=VehicleParams(*[veh[j].copy() for j in range(9)]), g=veh[9].copy(),
+                  mars=(veh[10].copy(), veh[11].copy()))
+    o.x[:] = np.stack([M[c]["x0"] for c in cs], axis=1)
+    o.status[:] = [int(M[c]["status0"]) for c in cs]
+    o.force[:] = np.stack([M[c]["force"][:3] for c in cs], axis=1)
+    o.pending[:] = [bool(np.any(M[c]["force"])) for c in cs]
+    T = max(len(M[c]["motors"]) for c in cs)
+    for t in range(T):
+        m = np.stack([M[c]["motors"][min(t, len(M[c]["motors"]) - 1)] for c in cs])
+        o.set_motors(m)
+        for i, c in enumerate(cs):
+            g = M[c]
+            if t < len(g["status"]):
+                assert np.array_equal(o.x[:, i], g["x"][t]), (c, t)
+                assert o.status[i] == g["status"][t], (c, t)
