@@ -252,8 +252,12 @@ __device__ __forceinline__ double decode_word(typename ModeOf<MODE>::T w, uint32
     const int sh = kGuardLsb - kGuardBits * j;  // field j -> bits 28..24: one shift and one and-or
     const uint32_t moved = sh >= 0 ? (gword << sh) : (gword >> -sh);
     const double d = (double)w;
-    // the low dword of a converted float32 has only bits 31..29 possibly set
-    const uint32_t lo = (moved & kGuardMaskLo) | (uint32_t)__double2loint(d);
+    // lo |= moved & 0x1F000000 as ONE instruction: the mask has to sit in an SGPR (VOP3 takes no
+    // literal on gfx9), which the compiler does not arrange by itself -- it emits v_and + v_or.  The
+    // low dword of a converted float32 has only bits 31..29 possibly set.
+    uint32_t mask, lo;
+    asm("s_mov_b32 %0, 0x1f000000" : "=s"(mask));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(moved), "s"(mask), "v"((uint32_t)__double2loint(d)));
     return __hiloint2double(__double2hiint(d), (int)lo);
   } else {
     return (double)w;
@@ -1005,7 +1009,7 @@ __device__ __forceinline__ void step_body(
   const typename TILE::Group t2 = tile.load_group(1);
   const typename TILE::Group r1 = tile.load_group(2);
   const typename TILE::Group r2 = tile.load_group(3);
-  const float4 act = load_action<TASK, STREAM_ACT>(io.actions_dev, valid ? i : 0u);
+  float4 act = load_action<TASK, STREAM_ACT>(io.actions_dev, valid ? i : 0u);
   const typename TILE::Group t1 = tile.load_group(0);
   Env<MODE> e;
   e.prev_sh = 0.0;
@@ -1013,6 +1017,10 @@ __device__ __forceinline__ void step_body(
   e.ep_ret = 0.f;
   if (o.stats) e.ep_ret = tile.load_ret();
   unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
+  // The action row is used only by lanes that fly, i.e. inside a branch: left to itself the compiler
+  // sinks the LOAD into that branch, behind the wait for the state -- two memory round trips in a
+  // row.  Naming the registers here keeps the load up front with the others.
+  asm volatile("" : "+v"(act.x), "+v"(act.y), "+v"(act.z), "+v"(act.w));
 #ifdef CS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Copy the judged evidence of a profiling run from gpurun_out/ (scratch) into profiles/ (tracked).
 
-  python scripts/collect_profiles.py <prof_tag> <sweep_tag>     # e.g. prof_r01h sweep_r01h
+  python scripts/collect_profiles.py <prof_tag> <round>     # e.g. prof_r02a r02
 
-expects gpurun_out/<prof_tag>/ (scripts/profile_gpu.sh), gpurun_out/<sweep_tag>.txt (stdout of
-scripts/sweep_gpu.sh) and gpurun_out/bench_default.json (python bench.py)."""
+expects gpurun_out/<prof_tag>/ as written by scripts/profile_gpu.sh (incl. bench_unprofiled.json, the
+bench line of the same build taken without a profiler)."""
 import csv
 import glob
 import json
@@ -16,7 +16,7 @@ import sys
 import numpy as np
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prof, sweep = sys.argv[1], sys.argv[2]
+prof, RND = sys.argv[1], sys.argv[2]
 P = os.path.join(R, "gpurun_out", prof)
 
 
@@ -24,14 +24,13 @@ def one(pat):
     return glob.glob(P + pat)[0]
 
 
-shutil.copy(one("/trace/runc/*_kernel_stats.csv"), R + "/profiles/r01_kernel_stats_bench_default.csv")
-shutil.copy(one("/trace_4m/runc/*_kernel_stats.csv"), R + "/profiles/r01_kernel_stats_4m_envs.csv")
-shutil.copy(P + "/summary.txt", R + "/profiles/r01_summary.txt")
-shutil.copy(P + "/summary.json", R + "/profiles/r01_summary.json")
-shutil.copy(os.path.join(R, "gpurun_out", sweep + ".txt"), R + "/profiles/r01_sweep.txt")
-shutil.copy(R + "/gpurun_out/bench_default.json", R + "/profiles/r01_bench_default.json")
+shutil.copy(one("/trace/*/*_kernel_stats.csv"), R + "/profiles/%s_kernel_stats_bench_default.csv" % RND)
+shutil.copy(one("/trace_4m/*/*_kernel_stats.csv"), R + "/profiles/%s_kernel_stats_4m_envs.csv" % RND)
+shutil.copy(P + "/summary.txt", R + "/profiles/%s_summary.txt" % RND)
+shutil.copy(P + "/summary.json", R + "/profiles/%s_summary.json" % RND)
+shutil.copy(P + "/bench_unprofiled.json", R + "/profiles/%s_bench_default.json" % RND)
 
-rows = list(csv.DictReader(open(one("/trace/runc/*_kernel_trace.csv"))))
+rows = list(csv.DictReader(open(one("/trace/*/*_kernel_trace.csv"))))
 
 
 def durations(name):
@@ -39,7 +38,7 @@ def durations(name):
     return rr, np.array([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rr])
 
 
-rr, d = durations("step_kernel")
+rr, d = durations("step_kernel<0, 0, true, true, false, false, true>")
 line = ("step_kernel<Lander3D,F32G,LEAN,stream actions> dispatch durations from rocprofv3 --kernel-trace, "
         "65 536 envs (ns): n=%d mean=%.1f median=%.1f min=%d max=%d p10=%d p90=%d\n"
         % (len(d), d.mean(), np.median(d), d.min(), d.max(), np.percentile(d, 10), np.percentile(d, 90)))
@@ -53,7 +52,7 @@ for name, desc in (("step_many_kernel<0, 0, true, 0>", "open loop, 64 steps per 
     if len(dd):
         line += "%s (%s): n=%d mean=%.0f ns  VGPR=%s SGPR=%s\n" % (name, desc, len(dd), dd.mean(),
                                                                   rr[0]["VGPR_Count"], rr[0]["SGPR_Count"])
-open(R + "/profiles/r01_step_kernel_durations.txt", "w").write(line)
+open(R + "/profiles/%s_step_kernel_durations.txt" % RND, "w").write(line)
 print(line)
 
 txt = open(P + "/summary.txt").read()
@@ -64,7 +63,7 @@ json.dump(t, open(R + "/profiles/traffic.json", "w"), indent=1)
 for ln in txt.splitlines():
     if "step_kernel" in ln or "HIP-event" in ln or "FETCH" in ln or "step_many" in ln:
         print(ln[:48], "...", ln[-74:])
-b = json.load(open(R + "/gpurun_out/bench_default.json"))
+b = json.load(open(P + "/bench_unprofiled.json"))
 print("bench default: %.2f G env-steps/s, %.3f us/step, frac %.3f" % (b["value"] / 1e9, b["ms_per_step"] * 1e3,
                                                                     b["roofline"]["frac"]),
       [(k, round(b[k]["value"] / 1e9, 2), round(b[k]["us_per_step"], 3)) for k in ("step_many", "rollout_pid", "rollout_random")])

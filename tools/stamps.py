@@ -45,12 +45,11 @@ for rep in range(10):
     lib.cs_debug_read_stamps(env._ctx, buf.ctypes.data_as(C.c_void_p), None)
     b = buf[:max(1, N // 64)].astype(np.int64)
     # slots in use: 0 kernel entry, 1 loads landed, 5 step body done, 6 stores issued, 7 stores acknowledged
-    res.append(np.stack([b[:, 1] - b[:, 0], b[:, 5] - b[:, 4], b[:, 6] - b[:, 5], b[:, 7] - b[:, 6],
-                         b[:, 7] - b[:, 0], b[:, 2] - b[:, 0], b[:, 3] - b[:, 1], b[:, 4] - b[:, 3]], axis=1))
+    res.append(np.stack([b[:, 1] - b[:, 0], b[:, 5] - b[:, 1], b[:, 6] - b[:, 5], b[:, 7] - b[:, 6],
+                         b[:, 7] - b[:, 0]], axis=1))
 d = np.median(np.stack(res), axis=0)
 names = ["loads issued -> landed", "decode + step body", "stores issued (+ LDS transpose)", "stores acknowledged",
-         "whole wavefront (incl. probes)", "  first load issued -> landed", "  probe: same 16 B again (glc)",
-         "  probe: untouched line of the tile"]
+         "whole wavefront"]
 print("N", N, law, "- shader-clock cycles per phase, median over wavefronts and 10 steps")
-for k in range(8):
+for k in range(5):
     print("%-32s %8.0f" % (names[k], np.median(d[:, k])))
