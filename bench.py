@@ -429,7 +429,7 @@ def main(argv=None):
         # K steps per launch (env state stays in registers): same envs, same resident action ring
         k = min(a.many, actions.shape[0])
         block = actions[:k].contiguous()
-        k_step_leg("step_many", k, lambda: env.step_many(block), 16 + 4 * od + 4 + 2 + 200.0 / k,
+        k_step_leg("step_many", k, lambda: env.step_many(block), 16 + 4 * od + 4 + 2 + 136.0 / k,
                    "cs_step_many: bit-identical to K single-step launches "
                    "(tests/test_gpu_parity.py::test_step_many_is_bit_identical_to_single_steps); "
                    "open-loop actions only, so it is reported beside, not as, the headline value")
@@ -438,7 +438,7 @@ def main(argv=None):
         k = a.pid
         env.configure_pid()
         env.reset()
-        k_step_leg("rollout_pid", k, lambda: env.rollout_pid(k), 4 * od + 4 + 2 + (200.0 + 384.0) / k,
+        k_step_leg("rollout_pid", k, lambda: env.rollout_pid(k), 4 * od + 4 + 2 + (136.0 + 384.0) / k,
                    "cs_rollout_pid: closed loop, upstream's PID landing heuristic evaluated on device "
                    "(tests/test_gpu_parity.py::test_rollout_pid_policy_is_bit_exact); episodes under "
                    "upstream's gains end by tilt after ~130 steps and auto-reset")
@@ -446,7 +446,7 @@ def main(argv=None):
         # random policy on device: the headline's action law with no action tensor, K steps per launch
         k = a.pid
         env.reset()
-        k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 200.0 / k,
+        k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 136.0 / k,
                    "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
                    "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)")
     env.close()
