@@ -77,6 +77,9 @@ def parse(argv=None):
     p.add_argument("--ring", type=int, default=64, help="resident action batches cycled through")
     p.add_argument("--prefetch", type=int, default=0,
                    help="1 = hand the kernel the NEXT action batch of the ring as well (cs_step_io.next_actions_dev)")
+    p.add_argument("--produce-actions", action="store_true",
+                   help="A/B workload: every step's action batch is WRITTEN by a preceding kernel (a device copy "
+                        "from the ring into one buffer) instead of being read from the resident ring")
     p.add_argument("--min-region-ms", type=float, default=50.0, help="GPU work per timed region")
     p.add_argument("--regions", type=int, default=5, help="timed regions (the median is reported)")
     p.add_argument("--gather", action="store_true", help="also time with the RCCL obs all-gather")
@@ -137,9 +140,11 @@ class Stepper:
     """Runs `count` consecutive env steps, as hipGraph replays of `chunk` captured
     launches plus eager launches for the remainder."""
 
-    def __init__(self, torch, env, actions, use_graph, chunk, post=None, prefetch=True):
+    def __init__(self, torch, env, actions, use_graph, chunk, post=None, prefetch=True, produce=False):
         self.torch, self.env, self.actions, self.post = torch, env, actions, post
         self.ring = actions.shape[0]
+        # produce: the action row is written by a kernel right before the step, as a policy would
+        self.produced = torch.empty_like(actions[0]) if produce else None
         self.pos = 0
         self.graph = None
         self.chunk = chunk
@@ -157,7 +162,10 @@ class Stepper:
                     self._one(j)
 
     def _one(self, j):
-        if self.prefetch:   # the open-loop workload knows the next batch: let the kernel pull it towards its L2
+        if self.produced is not None:
+            self.produced.copy_(self.actions[j % self.ring])
+            self.env.step(self.produced)
+        elif self.prefetch:   # the open-loop workload knows the next batch: let the kernel pull it towards its L2
             self.env.step_prefetch(self.actions[j % self.ring], self.actions[(j + 1) % self.ring])
         else:
             self.env.step(self.actions[j % self.ring])
@@ -378,7 +386,7 @@ def main(argv=None):
     env.reset()
     use_graph = not a.no_graph
     chunk = min(a.graph_chunk, max(1, a.steps))
-    stepper = Stepper(torch, env, actions, use_graph, chunk, prefetch=bool(a.prefetch))
+    stepper = Stepper(torch, env, actions, use_graph, chunk, prefetch=bool(a.prefetch), produce=a.produce_actions)
     m = timer.measure(stepper, a.steps, a.warmup, min_region_s, a.regions, quantum=chunk if use_graph else 1)
     total_envs = n * world
     value = total_envs / m["s_per_step"]
@@ -527,6 +535,7 @@ def main(argv=None):
                    "envs_per_gpu": n, "total_envs": total_envs, "task": a.task,
                    "actions": a.actions, "state_words": a.state, "substeps": a.substeps,
                    "action_ring": a.ring, "next_action_prefetch": bool(a.prefetch),
+                   "actions_produced_by_a_preceding_kernel": bool(a.produce_actions),
                    "parallelism": "env-shard x%d" % world},
         "roofline": roofline_block(a.task, n, m["launch_s"], a.state, traffic, tsrc),
     }
