@@ -194,36 +194,43 @@ uint32_t env_u32(const char* name) {
   return (end != nullptr && *end == 0 && x <= 0xFFFFFFFFull) ? (uint32_t)x : 0u;
 }
 
+// one device allocation holding the requested staging arrays
+struct Staging {
+  char* base = nullptr;
+  size_t bytes = 0;
+  size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool want[8] = {false, false, false, false, false, false, false, false};
+  size_t size[8];
+  Staging(size_t n, const bool (&w)[8]) {
+    const size_t sz[8] = {12 * n * 8, n, n * 4, n * 8, 3 * n * 8, n, n * 8, n * 4};
+    for (int k = 0; k < 8; ++k) {
+      want[k] = w[k];
+      size[k] = sz[k];
+      if (w[k]) {
+        off[k] = bytes;
+        bytes += (sz[k] + 255) & ~(size_t)255;
+      }
+    }
+  }
+  ~Staging() {
+    if (base) (void)hipFree(base);
+  }
+  template <class U>
+  U* at(int k) const {
+    return want[k] ? reinterpret_cast<U*>(base + off[k]) : nullptr;
+  }
+  cs::StateArrays arrays() const {
+    return cs::StateArrays{at<double>(0), at<uint8_t>(1), at<int32_t>(2), at<double>(3),
+                           at<double>(4), at<uint8_t>(5), at<double>(6), at<uint32_t>(7)};
+  }
+};
+
 int check_ctx(const cs_ctx* ctx) {
   if (ctx == nullptr) return fail(CS_ERR_ARG, "null context");
   return CS_OK;
 }
 
 }  // namespace
-
-namespace cs {
-
-// Host restatement of the kernels' draw_force() (copterstep_kernels.hip): cs_get_state reports the
-// pending force of an env whose perturbation is the Philox draw.
-void host_draw_force(uint32_t key, uint32_t env_id, uint32_t episode, double force_mag, bool f32_words,
-                     double (&f)[3]) {
-  uint32_t c0 = env_id, c1 = episode;
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p = (unsigned long long)0xD256D193U * c0;
-    c0 = (uint32_t)(p >> 32) ^ key ^ c1;
-    c1 = (uint32_t)p;
-    key += 0x9E3779B9U;
-  }
-  const uint32_t u[3] = {c0 >> 11, c1 >> 11, ((c0 & 0x7FFu) << 10) | (c1 & 0x3FFu)};
-  const double two_f = 2.0 * force_mag * 0x1.0p-21;
-  for (int k = 0; k < 3; ++k) {
-    const double v = (double)u[k] * two_f - force_mag;
-    f[k] = f32_words ? (double)(float)v : v;
-  }
-}
-
-
-}  // namespace cs
 
 extern "C" {
 
@@ -799,68 +806,9 @@ int cs_allgather(cs_comm* comm, const void* send_dev, void* recv_dev, int64_t by
   return rc == 0 ? CS_OK : rccl_fail(r, rc, "ncclAllGather");
 }
 
-// ---- host <-> device state exchange (not a hot path): the whole tile slab is staged on
-// the host and (de)tiled there --------------------------------------------------------
-
-// CS_STATE_F32G host codec: same bit manipulation as the kernels (copterstep_kernels.hip).
-static double f32g_decode(float w, uint32_t guard) {
-  double d = (double)w;
-  uint64_t b;
-  std::memcpy(&b, &d, sizeof b);
-  b |= (uint64_t)guard << cs::kGuardLsb;
-  std::memcpy(&d, &b, sizeof b);
-  return d;
-}
-
-static void f32g_encode(double v, float* w, uint32_t* guard) {
-  uint64_t b;
-  std::memcpy(&b, &v, sizeof b);
-  b += 1ULL << (cs::kGuardLsb - 1);
-  *guard = (uint32_t)(b >> cs::kGuardLsb) & cs::kGuardFieldMask;
-  const uint64_t t = b & ~0x1FFFFFFFULL;
-  double d;
-  std::memcpy(&d, &t, sizeof d);
-  *w = (float)d;
-}
-
-namespace {
-
-struct HostTiles {
-  std::vector<char> buf;
-  const cs_ctx* ctx;
-  char* at(size_t i, cs::Field f) {
-    return buf.data() + (i >> 6) * ctx->layout.tile_bytes + f.off + (i & 63) * f.stride;
-  }
-  double get_word(size_t i, cs::Field f) {
-    if (ctx->layout.word == 8) {
-      double d;
-      std::memcpy(&d, at(i, f), 8);
-      return d;
-    }
-    float v;
-    std::memcpy(&v, at(i, f), 4);
-    return (double)v;
-  }
-  void set_word(size_t i, cs::Field f, double v) {
-    if (ctx->layout.word == 8) {
-      std::memcpy(at(i, f), &v, 8);
-    } else {
-      const float w = (float)v;
-      std::memcpy(at(i, f), &w, 4);
-    }
-  }
-  uint32_t get_u32(size_t i, cs::Field f) {
-    uint32_t u;
-    std::memcpy(&u, at(i, f), 4);
-    return u;
-  }
-  void set_u32(size_t i, cs::Field f, uint32_t u) { std::memcpy(at(i, f), &u, 4); }
-  // guard word of state slot k and the field's position in it
-  cs::Field gword(int k) const { return k < 6 ? ctx->layout.gT() : ctx->layout.gR(); }
-  static int gshift(int k) { return cs::kGuardBits * (k < 6 ? k : k - 6); }
-};
-
-}  // namespace
+// ---- host <-> device state exchange (parity tests, checkpoint / restore; not a hot path): the tiles are
+// (de)tiled by a kernel into / from plain struct-of-arrays staging buffers on the device, and only the
+// arrays the caller asked for cross PCIe ---------------------------------------------------------------
 
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
@@ -869,55 +817,25 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_get_state: episode_stats is disabled");
   DeviceGuard guard_dev(ctx->cfg.device);
+  void* host[8] = {x_host, status_host, steps_host, prev_shaping_host, force_xyz_host, flags_host,
+                   episode_return_host, episode_host};
+  bool want[8];
+  for (int k = 0; k < 8; ++k) want[k] = host[k] != nullptr;
+  Staging st((size_t)ctx->st.n, want);
+  if (st.bytes == 0) {
+    CS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return CS_OK;
+  }
+  if (hipMalloc((void**)&st.base, st.bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(CS_ERR_MEMORY, "cs_get_state: device staging allocation failed");
+  }
+  hipError_t e = cs::launch_state_gather(ctx->cfg.state_mode, constants(ctx), ctx->st, st.arrays(), (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_get_state: kernel launch");
+  for (int k = 0; k < 8; ++k)
+    if (want[k])
+      CS_HIP(hipMemcpyAsync(host[k], st.base + st.off[k], st.size[k], hipMemcpyDeviceToHost, (hipStream_t)stream));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
-  const cs::Layout& L = ctx->layout;
-  const size_t n = ctx->st.n;
-  HostTiles h;
-  h.ctx = ctx;
-  try {
-    h.buf.resize((size_t)ctx->st.ntiles * L.tile_bytes);
-  } catch (...) {
-    return fail(CS_ERR_MEMORY, "cs_get_state: host staging allocation failed");
-  }
-  CS_HIP(hipMemcpy(h.buf.data(), ctx->st.tiles, h.buf.size(), hipMemcpyDeviceToHost));
-  const bool guard = ctx->cfg.state_mode == CS_STATE_F32G;
-  const cs::DevConst& c = constants(ctx);
-  for (size_t i = 0; i < n; ++i) {
-    const uint32_t meta = h.get_u32(i, L.meta());
-    const uint32_t episode = h.get_u32(i, L.epi());
-    if (x_host) {
-      for (int k = 0; k < 12; ++k) {
-        double v = h.get_word(i, L.x(k));
-        if (guard)
-          v = f32g_decode((float)v, (h.get_u32(i, h.gword(k)) >> HostTiles::gshift(k)) & cs::kGuardFieldMask);
-        x_host[(size_t)k * n + i] = v;
-      }
-    }
-    if (status_host) status_host[i] = (uint8_t)(h.get_u32(i, L.gT()) >> cs::kStatusShift);
-    if (steps_host) steps_host[i] = (int32_t)(meta & cs::kMetaStepsMask);
-    if (flags_host)
-      flags_host[i] = (uint8_t)(((meta & cs::kMetaPerturbPending) ? 1 : 0) |
-                                ((meta & cs::kMetaResetPending) ? 2 : 0) |
-                                ((meta & cs::kMetaExplicitForce) ? 4 : 0));
-    if (prev_shaping_host) prev_shaping_host[i] = h.get_word(i, L.prev());
-    if (force_xyz_host) {
-      // this episode's reset perturbation: the explicit force of the FE group, or the Philox draw
-      // of (seed, global env id, episode - 1), restated on the host; zero before the first reset
-      double f[3] = {0.0, 0.0, 0.0};
-      if (meta & cs::kMetaExplicitForce) {
-        for (int j = 0; j < 3; ++j) f[j] = h.get_word(i, L.f(j));
-      } else if (episode != 0) {
-        cs::host_draw_force(c.key_force, c.id_lo + (uint32_t)i, episode - 1u, c.force_mag, L.word == 4, f);
-      }
-      for (int j = 0; j < 3; ++j) force_xyz_host[(size_t)j * n + i] = f[j];
-    }
-    if (episode_host) episode_host[i] = episode;
-    if (episode_return_host) {
-      float f;
-      std::memcpy(&f, h.at(i, L.ret_()), 4);
-      episode_return_host[i] = (double)f;
-    }
-  }
   return CS_OK;
 }
 
@@ -928,66 +846,31 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_set_state: episode_stats is disabled");
-  DeviceGuard guard_dev(ctx->cfg.device);
-  CS_HIP(hipStreamSynchronize((hipStream_t)stream));
-  const cs::Layout& L = ctx->layout;
   const size_t n = ctx->st.n;
-  HostTiles h;
-  h.ctx = ctx;
-  try {
-    h.buf.resize((size_t)ctx->st.ntiles * L.tile_bytes);
-  } catch (...) {
-    return fail(CS_ERR_MEMORY, "cs_set_state: host staging allocation failed");
-  }
-  CS_HIP(hipMemcpy(h.buf.data(), ctx->st.tiles, h.buf.size(), hipMemcpyDeviceToHost));
-  const bool guard = ctx->cfg.state_mode == CS_STATE_F32G;
-  for (size_t i = 0; i < n; ++i) {
-    uint32_t meta = h.get_u32(i, L.meta());
-    uint32_t gT = h.get_u32(i, L.gT()), gR = h.get_u32(i, L.gR());
-    if (x_host) {
-      gT &= 3u << cs::kStatusShift;
-      gR = 0;
-      for (int k = 0; k < 12; ++k) {
-        const double v = x_host[(size_t)k * n + i];
-        if (guard) {
-          float w;
-          uint32_t gb;
-          f32g_encode(v, &w, &gb);
-          std::memcpy(h.at(i, L.x(k)), &w, 4);
-          (k < 6 ? gT : gR) |= gb << HostTiles::gshift(k);
-        } else {
-          h.set_word(i, L.x(k), v);
-        }
-      }
-    }
-    if (status_host) {
+  if (status_host)
+    for (size_t i = 0; i < n; ++i)
       if (status_host[i] > 3) return fail(CS_ERR_ARG, "cs_set_state: status out of range");
-      gT = (gT & ~(3u << cs::kStatusShift)) | ((uint32_t)status_host[i] << cs::kStatusShift);
-    }
-    if (steps_host) {
+  if (steps_host)
+    for (size_t i = 0; i < n; ++i)
       if (steps_host[i] < 0 || steps_host[i] > (int32_t)cs::kMetaStepsMask)
         return fail(CS_ERR_ARG, "cs_set_state: steps out of range");
-      meta = (meta & ~cs::kMetaStepsMask) | (uint32_t)steps_host[i];
-    }
-    if (flags_host)
-      meta = (meta & ~(cs::kMetaPerturbPending | cs::kMetaResetPending)) |
-             ((flags_host[i] & 1) ? cs::kMetaPerturbPending : 0u) |
-             ((flags_host[i] & 2) ? cs::kMetaResetPending : 0u);
-    if (force_xyz_host) {  // an explicitly installed force (Dynamics.perturb)
-      for (int j = 0; j < 3; ++j) h.set_word(i, L.f(j), force_xyz_host[(size_t)j * n + i]);
-      meta |= cs::kMetaExplicitForce;
-    }
-    h.set_u32(i, L.gT(), gT);
-    h.set_u32(i, L.gR(), gR);
-    h.set_u32(i, L.meta(), meta);
-    if (prev_shaping_host) h.set_word(i, L.prev(), prev_shaping_host[i]);
-    if (episode_host) h.set_u32(i, L.epi(), episode_host[i]);
-    if (episode_return_host) {
-      const float f = (float)episode_return_host[i];
-      std::memcpy(h.at(i, L.ret_()), &f, 4);
-    }
+  DeviceGuard guard_dev(ctx->cfg.device);
+  const void* host[8] = {x_host, status_host, steps_host, prev_shaping_host, force_xyz_host, flags_host,
+                         episode_return_host, episode_host};
+  bool want[8];
+  for (int k = 0; k < 8; ++k) want[k] = host[k] != nullptr;
+  Staging st(n, want);
+  if (st.bytes == 0) return CS_OK;
+  if (hipMalloc((void**)&st.base, st.bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(CS_ERR_MEMORY, "cs_set_state: device staging allocation failed");
   }
-  CS_HIP(hipMemcpy(ctx->st.tiles, h.buf.data(), h.buf.size(), hipMemcpyHostToDevice));
+  for (int k = 0; k < 8; ++k)
+    if (want[k])
+      CS_HIP(hipMemcpyAsync(st.base + st.off[k], host[k], st.size[k], hipMemcpyHostToDevice, (hipStream_t)stream));
+  hipError_t e = cs::launch_state_scatter(ctx->cfg.state_mode, constants(ctx), ctx->st, st.arrays(), (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_set_state: kernel launch");
+  CS_HIP(hipStreamSynchronize((hipStream_t)stream));  // the staging buffers are freed on return
   return CS_OK;
 }
 

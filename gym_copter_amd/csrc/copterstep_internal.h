@@ -52,30 +52,12 @@ constexpr int kGuardLsb = 24;                    // guard = bits 28..24 of the f
 constexpr uint32_t kGuardMaskLo = 0x1F000000u;   // those bits, as a mask of the low dword
 constexpr int kStatusShift = 30;                 // in gT
 
-struct Field {
-  uint32_t off, stride;
-};
-
 struct Layout {
   uint32_t word;          // bytes per float word (4 or 8)
   bool guard;             // guard bits kept (CS_STATE_F32G)
   uint32_t grp[4];        // offsets of T1, T2, R1, R2 (lane stride 4*word)
   uint32_t ps, fe, ret;   // PS row (stride word), FE group (stride 4*word), RET row (stride 4)
   uint32_t tile_bytes;
-  // state slot k (0..11, upstream order) -> its word
-  constexpr Field x(int k) const {
-    const int grp_of[12] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 3, 3};
-    const int pos_of[12] = {0, 1, 2, 3, 0, 1, 0, 1, 2, 3, 0, 1};
-    return {grp[grp_of[k]] + (uint32_t)pos_of[k] * word, 4 * word};
-  }
-  // the four 32-bit integer words: gT, meta (T2), gR, episode (R2)
-  constexpr Field gT() const { return {grp[1] + 2 * word, 4 * word}; }
-  constexpr Field meta() const { return {grp[1] + (word == 4 ? 12u : 20u), 4 * word}; }
-  constexpr Field gR() const { return {grp[3] + 2 * word, 4 * word}; }
-  constexpr Field epi() const { return {grp[3] + (word == 4 ? 12u : 20u), 4 * word}; }
-  constexpr Field prev() const { return {ps, word}; }
-  constexpr Field f(int j) const { return {fe + (uint32_t)j * word, 4 * word}; }
-  constexpr Field ret_() const { return {ret, 4u}; }
 };
 
 constexpr Layout make_layout(int mode) {
@@ -231,9 +213,21 @@ hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* m
 // [4] = episodes started (sum), [5] = running episode return (sum; needs episode_stats), as float64.
 hipError_t launch_episode_stats(int mode, const DevState& s, double* stats_dev, hipStream_t stream);
 
-// The Philox2x32-10 reset-force draw, restated for the host (cs_get_state reports the pending force
-// of an env whose perturbation is the Philox one).
-void host_draw_force(uint32_t key, uint32_t env_id, uint32_t episode, double force_mag, bool f32_words,
-                     double (&f)[3]);
+// cs_get_state / cs_set_state: plain struct-of-arrays staging buffers on the DEVICE (any may be nullptr):
+// x [12,N] float64 in upstream slot order, force [3,N] newtons, the rest [N].
+struct StateArrays {
+  double* x;
+  uint8_t* status;
+  int32_t* steps;
+  double* prev;
+  double* force;
+  uint8_t* flags;
+  double* ret;
+  uint32_t* episode;
+};
+hipError_t launch_state_gather(int mode, const DevConst& c, const DevState& s, const StateArrays& a,
+                               hipStream_t stream);
+hipError_t launch_state_scatter(int mode, const DevConst& c, const DevState& s, const StateArrays& a,
+                                hipStream_t stream);
 
 }  // namespace cs

@@ -1519,6 +1519,92 @@ __global__ __launch_bounds__(kBlock) void set_perturbation_kernel(const DevState
 }
 
 // ---------------------------------------------------------------------------------
+// Whole-batch state exchange (cs_get_state / cs_set_state: parity tests, checkpoint / restore): the tiles
+// <-> plain struct-of-arrays staging buffers on the device, which the C-ABI layer copies to / from the
+// host.  Any array may be absent (nullptr).
+// ---------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void state_gather_kernel(const DevConst c, const DevState s,
+                                                              const StateArrays a) {
+  using T = typename ModeOf<MODE>::T;
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
+  const size_t n = s.n;
+  if (i >= n) return;
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, threadIdx.x);
+  const typename TILE::Group t2 = tile.load_group(1);
+  Env<MODE> e;
+  unpack_env<MODE, TILE>(c, tile.load_group(0), t2, tile.load_group(2), tile.load_group(3), e);
+  const uint32_t meta = TILE::int_hi(t2);
+  if (a.x) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) a.x[(size_t)k * n + i] = e.x[k];
+  }
+  if (a.status) a.status[i] = (uint8_t)e.fs;
+  if (a.steps) a.steps[i] = (int32_t)e.steps;
+  if (a.flags)
+    a.flags[i] = (uint8_t)((e.pend ? 1 : 0) | ((meta & kMetaResetPending) ? 2 : 0) | (e.expl ? 4 : 0));
+  if (a.prev) a.prev[i] = (double)tile.load_prev();
+  if (a.force) {
+    // this episode's reset perturbation: the explicit force of the FE group, or the Philox draw of
+    // (seed, global env id, episode - 1); zero before the first reset
+    double f[3] = {0.0, 0.0, 0.0};
+    if (e.expl) {
+      const Vec4<T> fe = tile.load_fe();
+      f[0] = (double)fe.v[0];
+      f[1] = (double)fe.v[1];
+      f[2] = (double)fe.v[2];
+    } else if (e.episode != 0u) {
+      draw_force<T>(c, i, e.episode - 1u, f);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a.force[(size_t)j * n + i] = f[j];
+  }
+  if (a.ret) a.ret[i] = (double)tile.load_ret();
+  if (a.episode) a.episode[i] = e.episode;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void state_scatter_kernel(const DevConst c, const DevState s,
+                                                               const StateArrays a) {
+  using T = typename ModeOf<MODE>::T;
+  const uint32_t tile_index = blockIdx.x;
+  const uint32_t i = tile_index * kBlock + threadIdx.x;
+  const size_t n = s.n;
+  if (i >= n) return;
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, threadIdx.x);
+  const typename TILE::Group t2 = tile.load_group(1);
+  Env<MODE> e;
+  unpack_env<MODE, TILE>(c, tile.load_group(0), t2, tile.load_group(2), tile.load_group(3), e);
+  e.reset_pending = (TILE::int_hi(t2) & kMetaResetPending) != 0;  // (unpack masks it by the auto-reset mode)
+  if (a.x) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) e.x[k] = round_stored<MODE>(a.x[(size_t)k * n + i]);
+  }
+  if (a.status) e.fs = (int)a.status[i];
+  if (a.steps) e.steps = (int)a.steps[i];
+  if (a.flags) {
+    e.pend = (a.flags[i] & 1) != 0;
+    e.reset_pending = (a.flags[i] & 2) != 0;
+  }
+  if (a.force) {  // an explicitly installed force (Dynamics.perturb)
+    Vec4<T> fe;
+    fe.v[0] = (T)a.force[0 * n + i];
+    fe.v[1] = (T)a.force[1 * n + i];
+    fe.v[2] = (T)a.force[2 * n + i];
+    fe.v[3] = (T)0;
+    tile.store_fe(fe);
+    e.expl = true;
+  }
+  if (a.episode) e.episode = a.episode[i];
+  store_env<MODE, TILE>(tile, e);
+  if (a.prev) tile.store_prev((T)a.prev[i]);
+  if (a.ret) tile.store_ret((float)a.ret[i]);
+}
+
+// ---------------------------------------------------------------------------------
 // Running statistics of the batch (include/copterstep.h: cs_episode_stats): wave reduction, then one
 // atomic per wavefront and statistic.
 // ---------------------------------------------------------------------------------
@@ -1734,6 +1820,16 @@ hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* m
 
 hipError_t launch_episode_stats(int mode, const DevState& s, double* stats_dev, hipStream_t stream) {
   CS_MODE_LAUNCH(episode_stats_kernel, s, stats_dev);
+}
+
+hipError_t launch_state_gather(int mode, const DevConst& c, const DevState& s, const StateArrays& a,
+                               hipStream_t stream) {
+  CS_MODE_LAUNCH(state_gather_kernel, c, s, a);
+}
+
+hipError_t launch_state_scatter(int mode, const DevConst& c, const DevState& s, const StateArrays& a,
+                                hipStream_t stream) {
+  CS_MODE_LAUNCH(state_scatter_kernel, c, s, a);
 }
 
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,

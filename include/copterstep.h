@@ -331,7 +331,9 @@ int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream);
  * status_dev [N] (CS_STATUS_*), steps_dev [N].  Each pointer may be NULL. */
 int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, void* stream);
 
-/* Whole-batch state exchange with HOST buffers (parity tests, checkpoint/restore).
+/* Whole-batch state exchange with HOST buffers (parity tests, checkpoint/restore): a kernel (de)tiles
+ * the state into / from struct-of-arrays staging buffers on the device, and only the arrays asked for
+ * cross PCIe.
  * Any pointer may be NULL.  x_host is [12,N] float64 struct-of-arrays in upstream slot
  * order (x,dx,y,dy,z,dz,phi,dphi,theta,dtheta,psi,dpsi); force_xyz_host is [3,N] newtons;
  * flags_host bit0 = perturbation pending, bit1 = reset pending (NEXT_STEP), bit2 (get only) = the

@@ -1,5 +1,5 @@
 // Host-only unit test of the C-ABI layer's CPU code paths (constant folding, configuration
-// validation, the tile codec, the host Philox restatement) under AddressSanitizer + UBSan:
+// validation, the tile layout, the staging plan of the state exchange) under AddressSanitizer + UBSan:
 //   g++ -std=c++17 -x c++ -fsanitize=address,undefined -fno-sanitize-recover=all -I include -I /opt/rocm/include \
 //       tests/host/host_logic_san.cpp -L/opt/rocm/lib -lamdhip64 -ldl -o host_logic_san && ./host_logic_san
 // The kernels are not part of this build: the launchers are stubbed (no GPU is touched; cs_create fails
@@ -22,6 +22,8 @@ hipError_t launch_reset(int, int, const DevConst&, const DevState&, const uint8_
                         const float*, int, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_set_perturbation(int, const DevState&, const uint8_t*, const float*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_episode_stats(int, const DevState&, double*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_state_gather(int, const DevConst&, const DevState&, const StateArrays&, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_state_scatter(int, const DevConst&, const DevState&, const StateArrays&, hipStream_t) { return hipErrorUnknown; }
 }  // namespace cs
 
 #define REQUIRE(cond)                                                        \
@@ -83,69 +85,25 @@ int main() {
       const double ws = 15000 * kPi / 30, KL = 0.5 * 0.017 * (0.05 * 0.35 * 4) * 0.4 * (0.35 / 2) * (0.35 / 2) * ws * ws;
       REQUIRE(std::fabs(m.k_thrust + KL / 1.380) < 1e-12 * KL && std::fabs(m.k_roll - KL / 2) < 1e-12 * KL);
       REQUIRE(m.gyro == 1 && m.g_phi == 38e-4 / 2 * ws && m.G == 3.721);
-      // ---- tile layout: every field of every env of a few tiles inside the slab, no two fields overlap ----
-      fake.st.n = 200;
-      fake.st.ntiles = 4;
-      HostTiles h;
-      h.ctx = &fake;
-      h.buf.assign((size_t)fake.st.ntiles * fake.layout.tile_bytes, 0);
+      // ---- tile layout: the groups and rows of a tile follow each other without overlap ----
       const cs::Layout& L = fake.layout;
-      for (size_t i = 0; i < fake.st.n; ++i) {
-        for (int k = 0; k < 12; ++k) h.set_word(i, L.x(k), 1000.0 * (double)i + k);
-        h.set_u32(i, L.gT(), 0xA0000000u + (uint32_t)i);
-        h.set_u32(i, L.gR(), 0xB0000000u + (uint32_t)i);
-        h.set_u32(i, L.meta(), 0xC0000000u + (uint32_t)i);
-        h.set_u32(i, L.epi(), 0xD0000000u + (uint32_t)i);
-        h.set_word(i, L.prev(), -1.0 - (double)i);
-        for (int j = 0; j < 3; ++j) h.set_word(i, L.f(j), 0.5 * (double)i + j);
-        const float r = (float)i;
-        std::memcpy(h.at(i, L.ret_()), &r, 4);
-      }
-      for (size_t i = 0; i < fake.st.n; ++i) {
-        for (int k = 0; k < 12; ++k) REQUIRE(h.get_word(i, L.x(k)) == 1000.0 * (double)i + k);
-        REQUIRE(h.get_u32(i, L.gT()) == 0xA0000000u + i && h.get_u32(i, L.gR()) == 0xB0000000u + i);
-        REQUIRE(h.get_u32(i, L.meta()) == 0xC0000000u + i && h.get_u32(i, L.epi()) == 0xD0000000u + i);
-        REQUIRE(h.get_word(i, L.prev()) == -1.0 - (double)i);
-        for (int j = 0; j < 3; ++j) REQUIRE(h.get_word(i, L.f(j)) == 0.5 * (double)i + j);
-      }
+      const uint32_t gsz = 64u * 4u * L.word;
+      REQUIRE(L.grp[0] == 0 && L.grp[1] == gsz && L.grp[2] == 2 * gsz && L.grp[3] == 3 * gsz && L.ps == 4 * gsz);
+      REQUIRE(L.fe == L.ps + 64u * L.word && L.ret == L.fe + gsz && L.tile_bytes >= L.ret + 256u && L.tile_bytes % 256u == 0);
     }
   }
 
-  // ---- the 29-significant-bit word codec: round trip, rounding, carries, special values ----
-  const double samples[] = {0.0,      -0.0,        1.0,       -10.0,          0.1,       1.0 / 3.0, 123456.789,
-                            1e-30,    -7.25e-12,   3.5e37,    0x1.fffffffffffffp0, 0x1.ffffffep0, 0x1.fffffffp3,
-                            5e-324,   1e-310,      2.2250738585072014e-308};
-  for (double v : samples) {
-    float w;
-    uint32_t g;
-    f32g_encode(v, &w, &g);
-    REQUIRE(g <= cs::kGuardFieldMask);
-    const double back = f32g_decode(w, g);
-    if (std::fabs(v) > 1e-30 && std::fabs(v) < 1e38) {
-      REQUIRE(std::fabs(back - v) <= std::ldexp(std::fabs(v), -29));  // half a unit of the 29th bit
-      float w2;
-      uint32_t g2;
-      f32g_encode(back, &w2, &g2);
-      REQUIRE(w2 == w && g2 == g);  // a stored value is a fixed point of the codec
-    }
-  }
+  // ---- the staging plan of cs_get_state / cs_set_state: requested arrays only, 256-byte aligned, disjoint ----
   {
-    float w;
-    uint32_t g;
-    f32g_encode(std::numeric_limits<double>::infinity(), &w, &g);
-    REQUIRE(std::isinf(w));
-    f32g_encode(std::numeric_limits<double>::quiet_NaN(), &w, &g);
-    REQUIRE(std::isnan(w));
+    const bool want[8] = {true, false, true, true, false, true, false, true};
+    const Staging st(1000, want);
+    REQUIRE(st.off[0] == 0 && st.size[0] == 96000 && st.off[2] == 96000 && st.off[3] == 96000 + 4096);
+    REQUIRE(st.bytes % 256 == 0 && st.at<double>(1) == nullptr && st.arrays().status == nullptr);
+    const bool none[8] = {false, false, false, false, false, false, false, false};
+    REQUIRE(Staging(5, none).bytes == 0);
   }
 
-  // ---- the host Philox restatement: in range, on the 21-bit grid, keyed by every input ----
-  double f[3], g2[3];
-  cs::host_draw_force(123u, 7u, 3u, 30.0, false, f);
-  for (double v : f) REQUIRE(v >= -30.0 && v < 30.0 && std::floor(v * 2097152.0 / 60.0) == v * 2097152.0 / 60.0);
-  cs::host_draw_force(123u, 7u, 4u, 30.0, false, g2);
-  REQUIRE(f[0] != g2[0] || f[1] != g2[1]);
-  cs::host_draw_force(123u, 7u, 3u, 30.0, true, g2);
-  for (int k = 0; k < 3; ++k) REQUIRE(g2[k] == (double)(float)f[k]);
+  // ---- seed mixing, environment overrides ----
   REQUIRE(splitmix64(0) == 0xE220A8397B1DCDAFull && splitmix64(1) != splitmix64(0x100000000ull));
   REQUIRE(env_u32("COPTERSTEP_SURELY_UNSET_VARIABLE") == 0);
   std::printf("host_logic_san: OK\n");

@@ -1,6 +1,6 @@
 """CPU sanitizer build of the C-ABI layer's host-only code paths: configuration
-validation, constant folding (live and Mars models), the tile codec and layout, the host Philox
-restatement -- compiled with g++ -fsanitize=address,undefined and run without a GPU."""
+validation, constant folding (live and Mars models), the tile layout, the staging plan of the state
+exchange -- compiled with g++ -fsanitize=address,undefined and run without a GPU."""
 import os
 import shutil
 import subprocess
