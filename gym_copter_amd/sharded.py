@@ -47,7 +47,7 @@ class ShardGather:
             out = torch.empty((self.world * self.n_local,) + tuple(local.shape[1:]),
                               dtype=local.dtype, device=local.device)
             self._out[key] = out
-        dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(out, local if local.is_contiguous() else local.contiguous(), group=self.group)
         return out
 
 
@@ -97,7 +97,7 @@ class ShardedCopterVecEnv:
     group.  step()/reset() take and return LOCAL rows unless gather is enabled."""
 
     def __init__(self, task="lander3d", total_envs=1, gather="none", group=None, device=None,
-                 local_env_factory=None, **env_kwargs):
+                 **env_kwargs):
         import torch.distributed as dist
         if gather not in ("none", "obs", "all"):
             raise ValueError("gather must be 'none', 'obs' or 'all'")
@@ -107,14 +107,12 @@ class ShardedCopterVecEnv:
             self.rank, self.world = 0, 1
         self.total_envs = int(total_envs)
         self.env_id_base, self.n_local = shard_bounds(self.total_envs, self.world, self.rank)
-        if local_env_factory is None:
-            from .vecenv import CopterVecEnv
-            local_env_factory = CopterVecEnv
+        from . import vecenv
         if device is None:
             import os
             device = int(os.environ.get("LOCAL_RANK", 0))
-        self.local = local_env_factory(task=task, num_envs=self.n_local, device=device,
-                                       env_id_base=self.env_id_base, **env_kwargs)
+        self.local = vecenv.CopterVecEnv(task=task, num_envs=self.n_local, device=device,
+                                         env_id_base=self.env_id_base, **env_kwargs)
         self.gather = gather
         self._gather = ShardGather(self.n_local, self.world, group)
         self._packed = None

@@ -1,7 +1,8 @@
 """N>1 path on CPU: world_size-2 gloo process group.  The product's sharding host code
 (shard arithmetic, global-id keyed seeding, all-gather ordering) runs unmodified; the local
-stepper is replaced -- in this test only -- by a stand-in backed by the CPU oracle, because
-the HIP stepper needs a GPU.  The sharded result must equal the unsharded oracle batch."""
+stepper class it instantiates (gym_copter_amd.vecenv.CopterVecEnv, which needs a GPU) is swapped --
+inside this test's worker processes only -- for a stand-in backed by the CPU oracle.  The sharded
+result must equal the unsharded oracle batch."""
 import os
 import socket
 
@@ -51,9 +52,10 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gym_copter_amd.vecenv as vecenv
+    vecenv.CopterVecEnv = OracleLocalEnv          # this worker process only
     try:
-        env = ShardedCopterVecEnv("lander3d", TOTAL, gather="all", seed=77,
-                                  local_env_factory=OracleLocalEnv)
+        env = ShardedCopterVecEnv("lander3d", TOTAL, gather="all", seed=77)
         assert (env.env_id_base, env.n_local) == (rank * TOTAL // world, TOTAL // world)
         acts = torch.from_numpy(_actions())
         obs, _ = env.reset()
