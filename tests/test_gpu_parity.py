@@ -709,9 +709,20 @@ def test_c_host_known_answers():
     import subprocess
     exe = os.path.join(os.path.dirname(__file__), "host", "abi_host")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
     assert "abi_host: OK" in p.stdout
+
+
+def test_c_host_rccl_allgather():
+    """The same program with the RCCL wrappers (cs_comm_unique_id / cs_comm_create / cs_allgather with a world
+    of one).  Communicator set-up probes network interfaces: pinned to the loopback here."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "host", "abi_host")
+    env = dict(os.environ, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([exe, "rccl"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    assert "RCCL all-gather" in p.stdout
 
 
 # ---------------------------------------------------------------------------------------
@@ -1211,3 +1222,4 @@ def test_stream_hint_instantiations_agree(tuning):
         assert np.array_equal(s1[k], s2[k], equal_nan=True), k
     ref.close()
     alt.close()
+

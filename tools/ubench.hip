@@ -119,7 +119,7 @@ int main() {
   }
   // ---- 2. issue cost ----
   unsigned long long* dev; CK(hipMalloc(&dev, 64));
-  for (int w : {1, 2}) {
+  for (int w : {1, 2, 4, 8}) {
     run<OP_F64>("f64 fma", dev, w);
     run<OP_F64_DEP>("f64 dep", dev, w);
     run<OP_F32>("f32 fma", dev, w);
