@@ -13,13 +13,14 @@ workload = BASELINE.json configs[1]: Lander3D, 65 536 envs, uniform random actio
              BEFORE it touches the GPU, relays their output and exits with their code.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
-How the K steps are timed.  The K steps are captured as one hipGraph (chunks of at most
---graph-chunk launches).  A timed REGION is R back-to-back passes of those K steps, bracketed by
+How the K steps are timed.  The K steps are captured as hipGraphs of at most --graph-chunk launches
+(several passes of the K steps per graph when K is small).  A timed REGION is R back-to-back passes of
+those K steps, bracketed by
 barrier + torch.cuda.synchronize() on both sides and timed with the host clock; R ("repeats") is
 chosen so that a region holds >= --min-region-ms of GPU work (a single 20-step pass is 0.1 ms:
 graph-launch and synchronisation overhead would be a third of it).  --regions such regions are timed,
 each reduced with MAX over ranks; the MEDIAN region gives ms_per_step = wall / (R * K) and
-value = total envs * R * K / wall.  `single_pass` reports the bare K-step pass for comparison.
+value = total envs * R * K / wall.  `single_pass` reports one bare pass for comparison.
 
 Rank 0 prints ONE JSON line (see the task contract) with, besides the contract keys,
   roofline     : algorithmic bytes (176 B/env-step) per launch over the
@@ -237,7 +238,8 @@ class Timer:
                 "s_per_step": walls[k] / total, "launch_s": evs[k] / total,
                 "launch_s_best": min(evs) / total,
                 "single_pass": {"steps": steps, "wall_ms": w1 * 1e3, "ms_per_step": w1 / steps * 1e3,
-                                "note": "one bare K-step pass incl. graph-launch + synchronisation overhead"}}
+                                "note": "one bare pass (the K steps, or one hipGraph of them) incl. graph-launch + "
+                                        "synchronisation overhead"}}
 
 
 def _cpu_model():
@@ -323,6 +325,13 @@ def cpu_baseline(task, law, seconds):
                                  "sample": "oracle/refvec.py VecOracle, %d envs x %d steps" % (nv, k)}}
 
 
+def graph_chunk_for(steps, graph_chunk):
+    """Launches per captured hipGraph: whole passes of the K steps, as many as fit `graph_chunk`
+    (a 20-step graph pays its ~4 us replay boundary every 20 launches: 0.2 us per step)."""
+    steps = max(1, steps)
+    return steps * max(1, graph_chunk // steps) if steps < graph_chunk else graph_chunk
+
+
 def roofline_block(task, n, launch_s, state, traffic=None, traffic_source=None):
     achieved = ALGO_BYTES[task] * n / launch_s / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -339,7 +348,7 @@ def run_config(torch, timer, gca, a, task, n, law, substeps, device, rank, steps
                            env_id_base=rank * n)
     actions = make_actions(torch, law, ring, n, device, 1234 + rank)
     env.reset()
-    chunk = min(a.graph_chunk, max(1, steps))
+    chunk = graph_chunk_for(steps, a.graph_chunk)
     st = Stepper(torch, env, actions, use_graph, chunk, prefetch=prefetch)
     m = timer.measure(st, steps, warmup, min_region_s, regions, quantum=chunk if use_graph else 1)
     env.close()
@@ -385,7 +394,7 @@ def main(argv=None):
     actions = make_actions(torch, a.actions, a.ring, n, device, 1234 + rank)
     env.reset()
     use_graph = not a.no_graph
-    chunk = min(a.graph_chunk, max(1, a.steps))
+    chunk = graph_chunk_for(a.steps, a.graph_chunk)
     stepper = Stepper(torch, env, actions, use_graph, chunk, prefetch=bool(a.prefetch), produce=a.produce_actions)
     m = timer.measure(stepper, a.steps, a.warmup, min_region_s, a.regions, quantum=chunk if use_graph else 1)
     total_envs = n * world
@@ -524,8 +533,8 @@ def main(argv=None):
         "warmup": a.warmup, "ms_per_step": m["s_per_step"] * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "repeats": m["repeats"], "regions": m["regions"], "timed_steps_per_region": m["steps"] * m["repeats"],
-        "timing": "median of %d regions of %d x %d steps, each bracketed by barrier + synchronize, MAX over ranks"
-                  % (m["regions"], m["repeats"], m["steps"]),
+        "timing": "median of %d regions of %d x %d steps (hipGraphs of %d launches), each bracketed by barrier + "
+                  "synchronize, MAX over ranks" % (m["regions"], m["repeats"], m["steps"], chunk),
         "single_pass": m["single_pass"],
         "config": {"workload": "%s, %d envs/GPU, %s actions, auto-reset NEXT_STEP, %s state words, "
                                "dt=%g x %d substeps, %s" % (a.task, n, a.actions, a.state,
