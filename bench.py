@@ -386,6 +386,7 @@ def main(argv=None):
 
     import gym_copter_amd as gca
     timer = Timer(torch, dist, device)
+    timer.barrier()          # (N > 1: the communicator is set up here, outside every timed region)
     n = a.envs
     min_region_s = a.min_region_ms * 1e-3
     env = gca.CopterVecEnv(task=a.task, num_envs=n, device=local, seed=1234,
