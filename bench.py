@@ -126,6 +126,21 @@ def self_launch(a, argv):
     return subprocess.call(cmd, env=env)       # a child process: this one never initialises the GPU
 
 
+class stdout_to_stderr:
+    """File descriptor 1 -> 2 for the duration: RCCL prints a version banner on stdout when its first
+    communicator is set up, and stdout is where the ONE JSON line goes."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 # ------------------------------------------------------------------------------------------
 def make_actions(torch, law, ring, n, device, seed):
     g = torch.Generator(device=device)
@@ -379,14 +394,16 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
+    timer = Timer(torch, dist, device)
+    with stdout_to_stderr():
+        if dist is not None:
+            dist.init_process_group("nccl", device_id=device)
+        timer.barrier()      # (N > 1: the communicator is set up here, outside every timed region)
 
     import gym_copter_amd as gca
-    timer = Timer(torch, dist, device)
-    timer.barrier()          # (N > 1: the communicator is set up here, outside every timed region)
     n = a.envs
     min_region_s = a.min_region_ms * 1e-3
     env = gca.CopterVecEnv(task=a.task, num_envs=n, device=local, seed=1234,
