@@ -526,7 +526,9 @@ class CopterVecEnv:
 
     def get_state(self):
         """Whole-batch state as NumPy (synchronises): dict with x[12,N] f64, status, steps,
-        prev_shaping (NaN = None), force[3,N] newtons, flags, (episode_return)."""
+        prev_shaping (NaN = None), force[3,N] newtons (this episode's reset perturbation: an installed one, or
+        the Philox draw of (seed, global env id, episode - 1)), flags (bit 0 perturbation pending, bit 1 reset
+        pending, bit 2 the perturbation was installed explicitly), episode, (episode_return)."""
         self._check_open()
         n = self.num_envs
         out = {"x": np.empty((12, n)), "status": np.empty(n, np.uint8), "steps": np.empty(n, np.int32),

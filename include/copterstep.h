@@ -195,7 +195,9 @@ int cs_action_dim(const cs_ctx* ctx, int32_t* out); /* 4, 2 (2D variants) or 1 (
 /* cs_seed re-keys the Philox streams: both 32-bit keys are halves of splitmix64(seed), so every bit
  * of the 64-bit seed matters.  It does NOT touch the per-env episode counters (the other half of the
  * Philox counter): seeding twice with the same value does not replay the same perturbations unless
- * the counters are restored as well (cs_set_state(episode_host)). */
+ * the counters are restored as well (cs_set_state(episode_host)).  The Philox perturbation of an episode
+ * is evaluated when the physics consumes it (the first integrating step after the reset), so one that is
+ * still pending when the seed changes is drawn under the NEW key. */
 int cs_seed(cs_ctx* ctx, uint64_t seed);
 int cs_set_altitude(cs_ctx* ctx, double altitude);
 /* Reset envs with mask_dev[i] != 0 (NULL = all).  force_xyz_dev: [3,N] perturbation
