@@ -25,9 +25,8 @@
 
 #include "copterstep_internal.h"
 
-// every multiply-add below is written out (fma / explicit products): the one-step, the split and the
-// K-step kernels must round identically, which an optimiser's per-context choice of fused operations
-// would break
+// every multiply-add below is written out (fma / explicit products): the one-step and the K-step
+// kernels must round identically, which an optimiser's per-context choice of fused operations would break
 #pragma clang fp contract(off)
 
 namespace cs {
@@ -77,12 +76,13 @@ __device__ __forceinline__ U* at32(P* base, uint32_t byte_off) {
 }
 
 // Streaming accesses (non-temporal hint).  The per-step outputs (observation rows, reward,
-// flags) pass through once: stored as streams they do not displace the env state, which the
-// same XCD re-reads every step (workgroup -> XCD assignment is the same in every launch), from
-// that XCD's L2 -- measured -5 % time from 131 072 to 1 M envs.  Action rows are loaded as
-// streams only for batches whose state fits the L2s (Tuning::nt_action_max_envs): there it keeps a
-// long ring of action tensors from evicting the state (-5 % at 65 536 envs with a 64-deep ring); for
-// larger batches a non-temporal load is slower than a plain one (+2..7 %).  tools/ab.sh.
+// flags) pass through once: stored as streams they do not displace the env state in the caches
+// (the per-XCD L2s are written back and invalidated at every kernel boundary; what carries the
+// state from one launch to the next is the 256 MiB Infinity Cache) -- measured -5 % time from
+// 131 072 to 1 M envs.  Action rows are loaded as streams only for small batches
+// (Tuning::nt_action_max_envs): -3 % at 65 536 envs, whether the actions come from a long resident
+// ring or were just written by a kernel (scripts/ab_action_source.sh); for larger batches a
+// non-temporal load is slower than a plain one (+2..7 %).  tools/ab.sh.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define CS_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
@@ -243,7 +243,7 @@ __device__ __forceinline__ float4 draw_action(const DevConst& c, uint32_t i, uin
 // guard field holds significant bits 25..29, i.e. bits 28..24 of the float64 mantissa's low dword
 // (field j of a packed guard word sits at bit 5j).  round_stored() = float64 register -> the
 // float64 value the stored representation decodes to (what the next step and this step's
-// reward / termination logic see); split_stored() = that value -> word + guard field;
+// reward / termination logic see); words6() / pack_guards6() = such values -> words + guard fields;
 // decode_word() the inverse.
 // ---------------------------------------------------------------------------------
 template <int MODE>
