@@ -2,6 +2,9 @@
 // hipGraph replay of a captured chunk (every entry point only enqueues on the given stream, so
 // a chunk of steps is capturable as is).  Usage: abi_bench [num_envs] [steps]
 // Prints one line per mode; used for the numbers in INTEGRATION.md, not by the test-suite.
+// Third mode: the SAME batch as two half-batch contexts stepped by an explicit TWO-BRANCH hipGraph --
+// two chains of kernel nodes (chain A: half A's steps, chain B: half B's) with no edge between the
+// chains, built with hipGraphAddKernelNode-equivalent stream capture on two forked streams.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -86,5 +89,72 @@ int main(int argc, char** argv) {
   us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (reps * chunk);
   std::printf("hipGraph   %8lld envs  %8.3f us/step  %8.2f G env-steps/s\n", (long long)n, us, n / us * 1e-3);
   OK(cs_destroy(ctx));
+
+  // ---- two half-batches, one graph with two independent chains ----
+  if (n % 2 == 0) {
+    const int64_t h2 = n / 2;
+    cs_ctx* half[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) {
+      cfg.num_envs = h2;
+      cfg.env_id_base = k * h2;
+      OK(cs_create(&cfg, &half[k]));
+    }
+    hipStream_t side;
+    HIP(hipStreamCreate(&side));
+    hipEvent_t fork, join;
+    HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    HIP(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    for (int k = 0; k < 2; ++k) OK(cs_reset(half[k], nullptr, nullptr, obs + k * h2 * 10, stream));
+    HIP(hipStreamSynchronize(stream));
+    auto half_step = [&](int k, int j, hipStream_t st) {
+      return cs_step(half[k], act + (size_t)(j % ring) * n * 4 + k * h2 * 4, obs + k * h2 * 10, rew + k * h2,
+                     term + k * h2, trunc + k * h2, st);
+    };
+    hipGraph_t g2;
+    hipGraphExec_t e2;
+    HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeGlobal));
+    HIP(hipEventRecord(fork, stream));
+    HIP(hipStreamWaitEvent(side, fork, 0));  // the side stream joins the capture: second branch
+    for (int j = 0; j < chunk; ++j) {
+      OK(half_step(0, j, stream));
+      OK(half_step(1, j, side));
+    }
+    HIP(hipEventRecord(join, side));
+    HIP(hipStreamWaitEvent(stream, join, 0));
+    HIP(hipStreamEndCapture(stream, &g2));
+    HIP(hipGraphInstantiate(&e2, g2, nullptr, nullptr, 0));
+    HIP(hipGraphLaunch(e2, stream));
+    HIP(hipStreamSynchronize(stream));
+    t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) HIP(hipGraphLaunch(e2, stream));
+    HIP(hipStreamSynchronize(stream));
+    us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (reps * chunk);
+    std::printf("two-branch %8lld envs  %8.3f us/step  %8.2f G env-steps/s  (2 x %lld envs, independent chains)\n",
+                (long long)n, us, n / us * 1e-3, (long long)h2);
+    // and the two halves as two graphs replayed on two streams (no graph-level join per chunk)
+    hipGraph_t ga, gb;
+    hipGraphExec_t ea, eb;
+    HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    for (int j = 0; j < chunk; ++j) OK(half_step(0, j, stream));
+    HIP(hipStreamEndCapture(stream, &ga));
+    HIP(hipStreamBeginCapture(side, hipStreamCaptureModeThreadLocal));
+    for (int j = 0; j < chunk; ++j) OK(half_step(1, j, side));
+    HIP(hipStreamEndCapture(side, &gb));
+    HIP(hipGraphInstantiate(&ea, ga, nullptr, nullptr, 0));
+    HIP(hipGraphInstantiate(&eb, gb, nullptr, nullptr, 0));
+    HIP(hipGraphLaunch(ea, stream));
+    HIP(hipGraphLaunch(eb, side));
+    HIP(hipDeviceSynchronize());
+    t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; ++r) {
+      HIP(hipGraphLaunch(ea, stream));
+      HIP(hipGraphLaunch(eb, side));
+    }
+    HIP(hipDeviceSynchronize());
+    us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (reps * chunk);
+    std::printf("two-stream %8lld envs  %8.3f us/step  %8.2f G env-steps/s  (2 x %lld envs, two graphs on two streams)\n",
+                (long long)n, us, n / us * 1e-3, (long long)h2);
+    for (int k = 0; k < 2; ++k) OK(cs_destroy(half[k]));
+  }
   return 0;
 }
