@@ -446,7 +446,65 @@ def main(argv=None):
         g3, mode3 = gather_leg(pk.all_gather, bind=lambda: env.bind_outputs(pk.obs, pk.reward, pk.term, pk.trunc))
         extra["value_with_packed_allgather"] = total_envs / g3["s_per_step"]
         extra["ms_per_step_with_packed_allgather"] = g3["s_per_step"] * 1e3
-        extra["allgather_launch_mode"] = {"obs": mode2, "packed": mode3}
+        modes = {"obs": mode2, "packed": mode3}
+        if n % 2 == 0:
+            # double-buffered half-batches: each half's step + packed all-gather on its own
+            # stream, so one half's collective is on the links while the other half steps
+            from gym_copter_amd.sharded import HalfBatchPipeline
+            pipe = HalfBatchPipeline(task=a.task, total_envs=total_envs, gather="all", device=local, seed=1234,
+                                     autoreset_mode="next_step", state_dtype=a.state, substeps=a.substeps)
+            pipe.reset()
+            hn, ring = n // 2, actions.shape[0]
+
+            class PipeRunner:
+                def __init__(self, graph):
+                    self.graph, self.pos = None, 0
+                    if graph:
+                        cur = torch.cuda.current_stream(device)
+                        s = torch.cuda.Stream(device=device)
+                        s.wait_stream(cur)
+                        with torch.cuda.stream(s):
+                            self.chunk(3)
+                        cur.wait_stream(s)
+                        self.graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.graph):
+                            self.chunk(chunk)
+
+                def chunk(self, count, start=0):
+                    for j in range(count):
+                        row = actions[(start + j) % ring]
+                        for h in (0, 1):
+                            if j:
+                                pipe.wait(h)          # where a learner would consume half h's rows
+                            pipe.step_async(h, row[h * hn:(h + 1) * hn])
+                    pipe.wait(0)
+                    pipe.wait(1)
+
+                def run(self, count):
+                    done = 0
+                    if self.graph is not None:
+                        while count - done >= chunk:
+                            self.graph.replay()
+                            done += chunk
+                    if done < count:
+                        self.chunk(count - done, self.pos)
+                        self.pos += count - done
+
+            mode4 = "graph"
+            try:
+                pr = PipeRunner(use_graph)
+            except Exception as e:
+                torch.cuda.synchronize()
+                mode4 = "eager (capture failed: %s)" % type(e).__name__
+                pr = PipeRunner(False)
+            g4 = timer.measure(pr, a.steps, min(a.warmup, 50), min_region_s, a.regions,
+                               quantum=chunk if mode4 == "graph" else 1)
+            extra["value_with_pipelined_allgather"] = total_envs / g4["s_per_step"]
+            extra["ms_per_step_with_pipelined_allgather"] = g4["s_per_step"] * 1e3
+            modes["pipelined"] = mode4
+            del pr
+            pipe.close()
+        extra["allgather_launch_mode"] = modes
 
     def k_step_leg(name, k, call, bytes_step, note):
         class Runner:

@@ -97,7 +97,7 @@ class ShardedCopterVecEnv:
     group.  step()/reset() take and return LOCAL rows unless gather is enabled."""
 
     def __init__(self, task="lander3d", total_envs=1, gather="none", group=None, device=None,
-                 **env_kwargs):
+                 env_id_offset=0, **env_kwargs):
         import torch.distributed as dist
         if gather not in ("none", "obs", "all"):
             raise ValueError("gather must be 'none', 'obs' or 'all'")
@@ -106,7 +106,9 @@ class ShardedCopterVecEnv:
         else:
             self.rank, self.world = 0, 1
         self.total_envs = int(total_envs)
-        self.env_id_base, self.n_local = shard_bounds(self.total_envs, self.world, self.rank)
+        first, self.n_local = shard_bounds(self.total_envs, self.world, self.rank)
+        self.env_id_base = int(env_id_offset) + first    # global id of local row 0 (keys every random draw)
+        self.first_row = first                           # row of local row 0 in this env's gathered outputs
         from . import vecenv
         if device is None:
             import os
@@ -129,7 +131,7 @@ class ShardedCopterVecEnv:
         self.single_action_space = self.local.single_action_space
 
     def local_slice(self):
-        return slice(self.env_id_base, self.env_id_base + self.n_local)
+        return slice(self.first_row, self.first_row + self.n_local)
 
     def _local_actions(self, actions):
         if actions.shape[0] == self.n_local:
@@ -165,3 +167,79 @@ class ShardedCopterVecEnv:
 
     def close(self):
         self.local.close()
+
+
+class HalfBatchPipeline:
+    """Double-buffered half-batches: the global batch is two halves, each sharded
+    over the ranks, each with its own stream.  step_async(h, actions) enqueues half h's step kernel
+    and its packed all-gather on stream h and returns at once; wait(h) orders the caller's stream
+    behind them.  While half h's collective is on the links the caller evaluates its policy on the
+    other half and steps it -- the schedule
+
+        a0 = policy(obs0); step_async(0, a0)
+        loop:  a1 = policy(obs1); step_async(1, a1); obs0.. = wait(0)
+               a0 = policy(obs0); step_async(0, a0); obs1.. = wait(1)
+
+    Global env ids are half-major: half h owns [h*T/2, (h+1)*T/2), rank r the r-th contiguous
+    shard of it, so every env keeps the id (hence the random draws) it has in one T-env batch
+    and the rows of half h come back in global order."""
+
+    def __init__(self, task="lander3d", total_envs=2, gather="all", group=None, device=None, **env_kwargs):
+        if total_envs % 2:
+            raise ValueError("total_envs (%d) must be even" % total_envs)
+        half = total_envs // 2
+        self.total_envs, self.half_envs = int(total_envs), half
+        self.halves = [ShardedCopterVecEnv(task=task, total_envs=half, gather=gather, group=group,
+                                           device=device, env_id_offset=h * half, **env_kwargs)
+                       for h in (0, 1)]
+        self.n_local = self.halves[0].n_local
+        self.obs_dim = self.halves[0].obs_dim
+        self.single_observation_space = self.halves[0].single_observation_space
+        self.single_action_space = self.halves[0].single_action_space
+        self._streams = self._events = None
+        dev = getattr(self.halves[0].local, "device", None)
+        if dev is not None and getattr(dev, "type", "cpu") == "cuda":
+            import torch
+            self._dev = dev
+            self._streams = [torch.cuda.Stream(device=dev) for _ in (0, 1)]
+            self._events = [torch.cuda.Event() for _ in (0, 1)]
+        self._out = [None, None]
+
+    def reset(self, seed=None, options=None):
+        """-> ([obs half 0, obs half 1], {}); `options` is one dict per half (or None)."""
+        options = options or (None, None)
+        obs = [self.halves[h].reset(seed=seed, options=options[h])[0] for h in (0, 1)]
+        return obs, {}
+
+    def step_async(self, half, actions):
+        """Enqueue half `half`'s step (+ gather) behind everything already on the caller's stream;
+        the returned tensors are valid for the caller's stream after wait(half)."""
+        env = self.halves[half]
+        if self._streams is None:                      # host tensors (tests): nothing to overlap
+            self._out[half] = env.step(actions)
+            return self._out[half]
+        import torch
+        s = self._streams[half]
+        s.wait_stream(torch.cuda.current_stream(self._dev))   # the actions, and the last readers of the outputs
+        with torch.cuda.stream(s):
+            self._out[half] = env.step(actions)
+            self._events[half].record(s)
+        return self._out[half]
+
+    def wait(self, half):
+        """Order the caller's current stream behind half `half`'s last step_async; -> its outputs."""
+        if self._streams is not None:
+            import torch
+            torch.cuda.current_stream(self._dev).wait_event(self._events[half])
+        return self._out[half]
+
+    def step(self, actions):
+        """Both halves, pipelined against each other: `actions` = (half 0 rows, half 1 rows);
+        -> [outputs of half 0, outputs of half 1]."""
+        self.step_async(0, actions[0])
+        self.step_async(1, actions[1])
+        return [self.wait(0), self.wait(1)]
+
+    def close(self):
+        for e in self.halves:
+            e.close()

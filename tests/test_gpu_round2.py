@@ -347,6 +347,35 @@ for gather in ("none", "obs", "all"):
             assert torch.equal(u.reshape(v.shape), v), (gather, t)
     env.close()
     plain.close()
+# double-buffered half-batches, closed loop: each half's actions are computed on the caller's stream from
+# that half's gathered observations while the other half is stepping on its own stream
+from gym_copter_amd.sharded import HalfBatchPipeline
+policy = lambda o: torch.tanh(o[:, :4] * 0.3 + 0.1)
+plain = gym_copter_amd.CopterVecEnv("lander3d", n, seed=9, autoreset_mode="next_step")
+pipe = HalfBatchPipeline("lander3d", total_envs=n, gather="all", seed=9, autoreset_mode="next_step")
+assert [e.env_id_base for e in pipe.halves] == [0, n // 2]
+(o0, o1), _ = pipe.reset()
+op, _ = plain.reset()
+assert torch.equal(torch.cat([o0, o1]), op)
+pipe.step_async(0, policy(o0))
+ends = 0
+for t in range(200):
+    want = [x.clone() for x in plain.step(policy(op))[:4]]
+    op = want[0]
+    pipe.step_async(1, policy(o1))
+    got0 = [x.clone() for x in pipe.wait(0)[:4]]
+    o0 = got0[0]
+    pipe.step_async(0, policy(o0))
+    got1 = [x.clone() for x in pipe.wait(1)[:4]]
+    o1 = got1[0]
+    for u0, u1, v in zip(got0, got1, want):
+        assert torch.equal(torch.cat([u0, u1]), v), t
+    ends += int(want[2].sum())
+assert ends > 0
+pipe.wait(0)
+torch.cuda.synchronize()
+pipe.close()
+plain.close()
 dist.barrier()
 dist.destroy_process_group()
 print("SHARDED_OK")
@@ -354,8 +383,9 @@ print("SHARDED_OK")
 
 
 def test_sharded_env_in_a_spawned_nccl_process_group(tmp_path):
-    """ShardedCopterVecEnv (the real CopterVecEnv underneath, gather none / obs / all) in a child process
-    that initialises torch.distributed with the nccl (= RCCL) backend, world size 1."""
+    """ShardedCopterVecEnv (the real CopterVecEnv underneath, gather none / obs / all) and the double-buffered
+    HalfBatchPipeline in a child process that initialises torch.distributed with the nccl (= RCCL) backend,
+    world size 1."""
     script = tmp_path / "child.py"
     script.write_text(_CHILD % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",

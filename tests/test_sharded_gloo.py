@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gym_copter_amd.sharded import ShardedCopterVecEnv, shard_bounds
+from gym_copter_amd.sharded import HalfBatchPipeline, ShardedCopterVecEnv, shard_bounds
 from gym_copter_amd.spaces import Box
 from oracle import refvec
 from oracle.refvec import VecOracle
@@ -71,6 +71,38 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, out_dir):
+    """The double-buffered half-batch schedule: policy(half 1) between step_async(0) and wait(0)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gym_copter_amd.vecenv as vecenv
+    vecenv.CopterVecEnv = OracleLocalEnv
+    try:
+        pipe = HalfBatchPipeline("lander3d", TOTAL, gather="all", seed=77)
+        half, n_half = TOTAL // 2, TOTAL // 2 // world
+        for h, env in enumerate(pipe.halves):
+            assert (env.env_id_base, env.n_local, env.first_row) == (h * half + rank * n_half, n_half, rank * n_half)
+        acts = torch.from_numpy(_actions())
+        obs, _ = pipe.reset()
+        rows = [np.concatenate([o.numpy() for o in obs])]
+        pipe.step_async(0, acts[0][:half])
+        for t in range(STEPS):
+            pipe.step_async(1, acts[t][half:])            # half 1 steps while half 0's gather is out
+            o0, r0, t0, u0, _ = pipe.wait(0)
+            keep0 = [x.numpy().copy() for x in (o0, r0, t0, u0)]
+            if t + 1 < STEPS:
+                pipe.step_async(0, acts[t + 1][:half])
+            o1, r1, t1, u1, _ = pipe.wait(1)
+            assert o1.shape == (half, 10) and r1.shape == (half,) and t1.dtype == torch.bool
+            both = [np.concatenate([a, b.numpy()]) for a, b in zip(keep0, (o1, r1, t1, u1))]
+            rows.append(np.concatenate([both[0].ravel(), both[1], both[2], both[3]]))
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([x.ravel() for x in rows]))
+        pipe.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -79,9 +111,10 @@ def _free_port():
     return p
 
 
-def test_two_rank_sharding_matches_unsharded_batch(tmp_path):
+@pytest.mark.parametrize("worker", [_worker, _pipeline_worker], ids=["sharded", "half_batch_pipeline"])
+def test_two_rank_sharding_matches_unsharded_batch(tmp_path, worker):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     ref = VecOracle("lander3d", TOTAL, store_mode="float32", seed=77,
                     autoreset=refvec.AUTORESET_NEXT_STEP)
     rows = [ref.reset()]
@@ -96,6 +129,11 @@ def test_two_rank_sharding_matches_unsharded_batch(tmp_path):
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank))
         assert np.array_equal(got, want), rank     # every rank holds the same, correct concatenation
+
+
+def test_half_batch_pipeline_rejects_odd_batches():
+    with pytest.raises(ValueError):
+        HalfBatchPipeline("lander3d", 7)
 
 
 def test_shard_bounds():
