@@ -727,10 +727,9 @@ struct Rccl {
 };
 
 Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // initialised once, also when two threads get here together
+  static Rccl loaded = [] {
+    Rccl r;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (r.lib) break;
@@ -743,8 +742,9 @@ Rccl* rccl() {
       r.get_error_string = (decltype(r.get_error_string))dlsym(r.lib, "ncclGetErrorString");
       if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather) r.lib = nullptr;
     }
-  }
-  return r.lib ? &r : nullptr;
+    return r;
+  }();
+  return loaded.lib ? &loaded : nullptr;
 }
 
 int rccl_fail(Rccl* r, int code, const char* what) {
