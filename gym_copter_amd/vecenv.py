@@ -168,8 +168,22 @@ class CopterVecEnv:
                                for t in (self._obs, self._reward, self._term, self._trunc))
         self._term_b, self._trunc_b = self._term.view(torch.bool), self._trunc.view(torch.bool)
         self._dev_index = self.device.index
-        # raw current-stream query (no Stream object); falls back to the public API
+        # raw current-stream / current-device queries (no Stream object, no lazy-init check); fall back
+        # to the public API
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._cur_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
+        # the per-step call: cs_step by address through the _cs_call module when it is built (same entry
+        # point, no ctypes marshalling), else through ctypes
+        self._Tensor, self._f32 = torch.Tensor, torch.float32
+        self._ashape = (self.num_envs, self.action_dim)
+        self._fast = None
+        try:
+            from . import _cs_call
+            addr = C.cast(self._lib.cs_step, C.c_void_p).value
+            if self._raw_stream is not None and addr:
+                self._fast = (_cs_call.step, addr, self._ctx.value) + tuple(p.value for p in self._out_ptrs)
+        except ImportError:
+            pass
 
     # -- plumbing ------------------------------------------------------------------
     @property
@@ -259,11 +273,23 @@ class CopterVecEnv:
         """One env step for the whole batch: exactly one kernel launch, asynchronous on
         the current torch stream.  Returned tensors are this env's persistent output
         buffers (overwritten by the next step())."""
+        fast = self._fast
+        if (fast is not None and type(actions) is self._Tensor and actions.dtype is self._f32
+                and actions.shape == self._ashape and actions.device == self.device and actions.is_contiguous()
+                and self._final_obs is None and self._done is None and not self.closed
+                and self._cur_device() == self._dev_index):
+            # eager fast path: a resident float32 action batch, default outputs, this env's device current
+            rc = fast[0](fast[1], fast[2], actions.data_ptr(), fast[3], fast[4], fast[5], fast[6],
+                         self._raw_stream(self._dev_index))
+            if rc != 0:
+                _lib.check(rc)
+            self._keep = actions
+            return self._obs, self._reward, self._term_b, self._trunc_b, {}
         self._check_open()
         torch = _torch()
         a, was_numpy = self._dev_f32(actions, (self.num_envs, self.action_dim), "actions")
-        if self._final_obs is None and self._done is None and torch.cuda.current_device() == self._dev_index:
-            # fast path: resident actions, default outputs, the env's device already current
+        if self._final_obs is None and self._done is None and self._cur_device() == self._dev_index:
+            # resident actions, default outputs, the env's device already current
             po, pr, pt, pu = self._out_ptrs
             rc = self._lib.cs_step(self._ctx, C.c_void_p(a.data_ptr()), po, pr, pt, pu, self._stream())
             if rc != 0:

@@ -70,9 +70,25 @@ int main(int argc, char** argv) {
 
   auto t0 = std::chrono::steady_clock::now();
   for (int j = 0; j < steps; ++j) OK(step(j));
+  const double enq = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps;
   HIP(hipStreamSynchronize(stream));
   double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps;
-  std::printf("eager      %8lld envs  %8.3f us/step  %8.2f G env-steps/s\n", (long long)n, us, n / us * 1e-3);
+  std::printf("eager      %8lld envs  %8.3f us/step  %8.2f G env-steps/s  (host enqueue %.3f us/step)\n", (long long)n,
+              us, n / us * 1e-3, enq);
+  if (n > 64) {  // the host cost of one cs_step alone: a batch small enough that the GPU never back-pressures
+    cs_ctx* tiny = nullptr;
+    cfg.num_envs = 64;
+    OK(cs_create(&cfg, &tiny));
+    OK(cs_reset(tiny, nullptr, nullptr, obs, stream));
+    HIP(hipStreamSynchronize(stream));
+    t0 = std::chrono::steady_clock::now();
+    for (int j = 0; j < 2000; ++j) OK(cs_step(tiny, act, obs, rew, term, trunc, stream));
+    const double e64 = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000;
+    HIP(hipStreamSynchronize(stream));
+    std::printf("eager            64 envs  host enqueue %.3f us/step\n", e64);
+    OK(cs_destroy(tiny));
+    cfg.num_envs = n;
+  }
 
   hipGraph_t graph;
   hipGraphExec_t exec;

@@ -148,3 +148,27 @@ def test_header_is_plain_c():
                                "-x", "c", hdr])
     if shutil.which("g++"):
         subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+
+
+def test_step_call_module_passes_its_arguments_through_unchanged():
+    """gym_copter_amd/_cs_call.so (csrc/pyhost.c): cs_step by address, integer arguments in, status out."""
+    from gym_copter_amd import _cs_call
+    seen = []
+
+    @C.CFUNCTYPE(C.c_int, *([C.c_void_p] * 7))
+    def fake_step(*a):
+        seen.append(a)
+        return -3
+
+    addr = C.cast(fake_step, C.c_void_p).value
+    big = (1 << 63) + 5                                     # device pointers use the full 64 bits
+    assert _cs_call.step(addr, 11, 22, big, 44, 55, 66, None) == -3
+    assert seen == [(11, 22, big, 44, 55, 66, None)]
+    with pytest.raises(TypeError):
+        _cs_call.step(addr, 1, 2)
+    with pytest.raises(ValueError):
+        _cs_call.step(0, 1, 2, 3, 4, 5, 6, 7)
+    with pytest.raises((TypeError, OverflowError)):
+        _cs_call.step(addr, 1, "x", 3, 4, 5, 6, 7)
+    with pytest.raises(OverflowError):
+        _cs_call.step(addr, 1, -2, 3, 4, 5, 6, 7)

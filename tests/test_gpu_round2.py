@@ -318,6 +318,35 @@ def test_float64_mode_at_the_context_size_limit():
     env.close()
 
 
+def test_step_through_the_call_module_equals_step_through_ctypes():
+    """The eager fast path (cs_step by address, gym_copter_amd/_cs_call.so) is in use and equals the ctypes path
+    bit for bit; anything but a resident contiguous float32 batch takes the general path."""
+    import torch
+    import gym_copter_amd
+    n = 3000
+    fast = gym_copter_amd.CopterVecEnv("lander3d", n, seed=4, autoreset_mode="next_step")
+    slow = gym_copter_amd.CopterVecEnv("lander3d", n, seed=4, autoreset_mode="next_step")
+    assert fast._fast is not None, "gym_copter_amd/_cs_call.so is not built"
+    slow._fast = None
+    fast.reset()
+    slow.reset()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    for t in range(60):
+        a = torch.rand((n, 4), generator=g, device="cuda") * 2 - 1
+        if t % 7 == 3:
+            a = a.double()                       # general path on both: converted, same values
+        got, want = fast.step(a), slow.step(a)
+        for u, v in zip(got[:4], want[:4]):
+            assert torch.equal(u, v), t
+    with pytest.raises(ValueError):
+        fast.step(torch.zeros((n, 3), device="cuda"))
+    fast.close()
+    with pytest.raises(RuntimeError):
+        fast.step(torch.zeros((n, 4), device="cuda"))
+    slow.close()
+
+
 # ---------------------------------------------------------------------------------------
 # the sharded env in its own process group under RCCL (world 1: what one GPU allows)
 # ---------------------------------------------------------------------------------------
