@@ -401,7 +401,7 @@ struct Trig {
 };
 template <bool FULL>
 __device__ __forceinline__ void sincos_roll_pitch(const DevConst& c, double phi, double the, Trig& t) {
-  if (__all(fabs(phi) < 0.785 && fabs(the) < 0.785)) {
+  if (__builtin_expect(__all(fabs(phi) < 0.785 && fabs(the) < 0.785), 1)) {
     sincos_kernel<FULL>(c.trig, phi, t.sph, t.cph);
     sincos_kernel<FULL>(c.trig, the, t.sth, t.cth);
   } else {
@@ -411,7 +411,7 @@ __device__ __forceinline__ void sincos_roll_pitch(const DevConst& c, double phi,
 }
 template <bool FULL>
 __device__ __forceinline__ void sincos_yaw(const DevConst& c, double psi, Trig& t) {
-  if (__all(fabs(psi) < 0.785)) {
+  if (__builtin_expect(__all(fabs(psi) < 0.785), 1)) {
     sincos_kernel<FULL>(c.trig, psi, t.sps, t.cps);
   } else {
     sincos_f64<FULL>(c, psi, t.sps, t.cps);
@@ -787,7 +787,7 @@ __device__ __forceinline__ void pending_perturbation(const DevConst& c, const Co
   if (pend) {
     double f[3];
     draw_force<T>(c, i, episode - 1u, f);
-    if (expl) {
+    if (__builtin_expect(expl, 0)) {  // an installed force: rare, kept out of the common path
       const Vec4<T> fe = tile.load_fe();
       f[0] = (double)fe.v[0];
       f[1] = (double)fe.v[1];

@@ -41,6 +41,19 @@ double chain(hipStream_t s, F launch) {
   return us / (chunk * reps);
 }
 
+// host cost of one launch call (the kernel is far shorter than the call, so the loop is host-bound)
+template <class F>
+double host_cost(hipStream_t s, F launch) {
+  const int n = 20000;
+  for (int i = 0; i < 1000; ++i) launch();
+  CK(hipStreamSynchronize(s));
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n; ++i) launch();
+  double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  CK(hipStreamSynchronize(s));
+  return us / n;
+}
+
 int main() {
   hipStream_t s; CK(hipStreamCreate(&s));
   unsigned* buf; CK(hipMalloc(&buf, 1024 * 64 * 4)); CK(hipMemset(buf, 0, 1024 * 64 * 4));
@@ -49,6 +62,18 @@ int main() {
     printf("noarg %.3f us/kernel\n", chain(s, [&] { hipLaunchKernelGGL(k_noarg, dim3(1024), dim3(64), 0, s); }));
     printf("ptr   %.3f us/kernel\n", chain(s, [&] { hipLaunchKernelGGL(k_ptr, dim3(1024), dim3(64), 0, s, buf); }));
     printf("big   %.3f us/kernel\n", chain(s, [&] { hipLaunchKernelGGL(k_big, dim3(1024), dim3(64), 0, s, b); }));
+  }
+  // ---- host-side cost of the launch call itself ----
+  hipFunction_t f_big;
+  CK(hipGetFuncBySymbol(&f_big, (const void*)k_big));
+  size_t sz = sizeof(Big);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &b, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  void* params[] = {&b};
+  for (int pass = 0; pass < 2; ++pass) {
+    printf("host cost  <<<>>> ptr        %.3f us/launch\n", host_cost(s, [&] { hipLaunchKernelGGL(k_ptr, dim3(1), dim3(64), 0, s, buf); }));
+    printf("host cost  <<<>>> 640 B      %.3f us/launch\n", host_cost(s, [&] { hipLaunchKernelGGL(k_big, dim3(1), dim3(64), 0, s, b); }));
+    printf("host cost  hipLaunchKernel   %.3f us/launch\n", host_cost(s, [&] { (void)hipLaunchKernel((const void*)k_big, dim3(1), dim3(64), params, 0, s); }));
+    printf("host cost  hipModuleLaunch   %.3f us/launch\n", host_cost(s, [&] { (void)hipModuleLaunchKernel(f_big, 1, 1, 1, 64, 1, 1, 0, s, nullptr, extra); }));
   }
   return 0;
 }

@@ -70,6 +70,68 @@ __global__ __launch_bounds__(64) void k_issue(unsigned long long* out, int iters
   if (lane == 0 && blockIdx.x == 0) out[0] = t1 - t0;
 }
 
+// Straight-line version (no loop, no branch): 256 instructions in CHAINS independent dependency chains.
+// CHAINS = 1 is a pure dependent chain (issue-to-issue latency), CHAINS = 8 is the issue rate.
+enum { SL_F64 = 0, SL_F32 = 1, SL_INT = 2, SL_MAD64 = 3, SL_CVT = 4, SL_F64_MUL = 5, SL_RCP64 = 6, SL_SQRT64 = 7, SL_BRANCH = 8, SL_TAKEN = 9, SL_NOT_TAKEN = 10, SL_EXECZ_NOT_TAKEN = 11, SL_SALU = 12 };
+template <int OP, int CHAINS>
+__global__ __launch_bounds__(64) void k_line(unsigned long long* out, double seed, int never) {
+  const int lane = threadIdx.x;
+  double a[8];
+  float f[8];
+  unsigned u[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = seed + j + lane; f[j] = (float)a[j]; u[j] = (unsigned)(lane * 7 + j + (int)seed); }
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int it = 0; it < 256; ++it) {
+    const int j = it % CHAINS;
+    if (OP == SL_F64) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(a[j]));
+    if (OP == SL_F64_MUL) asm volatile("v_mul_f64 %0, %0, %0" : "+v"(a[j]));
+    if (OP == SL_F32) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[j]));
+    if (OP == SL_INT) asm volatile("v_xor_b32 %0, %0, %0" : "+v"(u[j]));
+    if (OP == SL_MAD64) {
+      unsigned long long r;
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, 0" : "=v"(r) : "v"(u[j]) : "vcc");
+      u[j] = (unsigned)(r >> 32);
+    }
+    if (OP == SL_CVT) { asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[j]) : "v"(a[j])); asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a[j]) : "v"(f[j])); }
+    if (OP == SL_RCP64) asm volatile("v_rcp_f64 %0, %0" : "+v"(a[j]));
+    if (OP == SL_SQRT64) asm volatile("v_rsq_f64 %0, %0" : "+v"(a[j]));
+    if (OP == SL_TAKEN)
+      asm volatile("v_xor_b32 %0, %0, %0\n s_cmp_eq_u32 %1, %1\n s_cbranch_scc1 .Lt%=\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n.Lt%=:" : "+v"(u[j]) : "s"(never) : "scc");
+    if (OP == SL_NOT_TAKEN)
+      asm volatile("v_xor_b32 %0, %0, %0\n s_cmp_eq_u32 %1, %1\n s_cbranch_scc0 .Ln%=\n.Ln%=:" : "+v"(u[j]) : "s"(never) : "scc");
+    if (OP == SL_EXECZ_NOT_TAKEN)
+      asm volatile("v_xor_b32 %0, %0, %0\n s_cbranch_execz .Le%=\n.Le%=:" : "+v"(u[j]));
+    if (OP == SL_SALU)
+      asm volatile("v_xor_b32 %0, %0, %0\n s_cmp_eq_u32 %1, %1" : "+v"(u[j]) : "s"(never) : "scc");
+    if (OP == SL_BRANCH) {  // a uniform branch that is always taken over one instruction
+      asm volatile("v_xor_b32 %0, %0, %0" : "+v"(u[j]));
+      if (never == it) asm volatile("v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0\n v_xor_b32 %0, %0, %0" : "+v"(u[(j + 1) & 7]));
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_sched_barrier(0);
+  double s = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += a[j] + f[j] + u[j];
+  if (s == 12345.678) out[1] = 1;
+  if (lane == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+}
+
+template <int OP, int CHAINS>
+void line(const char* name, unsigned long long* dev, int per = 1) {
+  for (int rep = 0; rep < 2; ++rep) {
+    hipLaunchKernelGGL((k_line<OP, CHAINS>), dim3(1024), dim3(64), 0, 0, dev, 1.5, -1);
+    CK(hipDeviceSynchronize());
+  }
+  unsigned long long t;
+  CK(hipMemcpy(&t, dev, 8, hipMemcpyDeviceToHost));
+  printf("straight-line %-12s %d chain(s): %6llu ticks / %d instr = %.2f ticks/instr\n", name, CHAINS, t, 256 * per,
+         (double)t / (256 * per));
+}
+
 template <int OP>
 void run(const char* name, unsigned long long* dev, int waves_per_simd) {
   const int iters = 200;
@@ -119,6 +181,19 @@ int main() {
   }
   // ---- 2. issue cost ----
   unsigned long long* dev; CK(hipMalloc(&dev, 64));
+  line<SL_F64, 1>("f64 fma", dev); line<SL_F64, 2>("f64 fma", dev); line<SL_F64, 4>("f64 fma", dev); line<SL_F64, 8>("f64 fma", dev);
+  line<SL_F64_MUL, 1>("f64 mul", dev); line<SL_F64_MUL, 2>("f64 mul", dev); line<SL_F64_MUL, 8>("f64 mul", dev);
+  line<SL_F32, 1>("f32 fma", dev); line<SL_F32, 2>("f32 fma", dev); line<SL_F32, 8>("f32 fma", dev);
+  line<SL_INT, 1>("xor b32", dev); line<SL_INT, 2>("xor b32", dev); line<SL_INT, 8>("xor b32", dev);
+  line<SL_MAD64, 1>("mad_u64_u32", dev); line<SL_MAD64, 2>("mad_u64_u32", dev); line<SL_MAD64, 8>("mad_u64_u32", dev);
+  line<SL_CVT, 1>("cvt 64<->32", dev, 2); line<SL_CVT, 8>("cvt 64<->32", dev, 2);
+  line<SL_RCP64, 1>("rcp f64", dev); line<SL_RCP64, 8>("rcp f64", dev);
+  line<SL_SQRT64, 1>("rsq f64", dev); line<SL_SQRT64, 8>("rsq f64", dev);
+  line<SL_BRANCH, 8>("xor + skipped branch", dev);
+  line<SL_SALU, 8>("xor + s_cmp", dev);
+  line<SL_NOT_TAKEN, 8>("xor + s_cmp + branch not taken", dev);
+  line<SL_EXECZ_NOT_TAKEN, 8>("xor + execz branch not taken", dev);
+  line<SL_TAKEN, 8>("xor + s_cmp + branch taken over 2", dev);
   for (int w : {1, 2, 4, 8}) {
     run<OP_F64>("f64 fma", dev, w);
     run<OP_F64_DEP>("f64 dep", dev, w);
