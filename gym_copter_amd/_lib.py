@@ -76,7 +76,7 @@ class PidGains(C.Structure):
 class Tuning(C.Structure):
     """cs_tuning (include/copterstep.h)."""
     _fields_ = [("struct_size", C.c_uint32), ("nt_action_max_envs", C.c_uint32),
-                ("nt_state_min_envs", C.c_uint32)]
+                ("nt_state_min_envs", C.c_uint32), ("direct_rows_max_envs", C.c_uint32)]
 
 
 PID_LANDER, PID_HOVER = 0, 1

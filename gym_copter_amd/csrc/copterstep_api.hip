@@ -338,6 +338,7 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   ctx->cfg = *cfg;
   ctx->tune.nt_action_max_envs = env_u32("COPTERSTEP_NT_ACTION_MAX_ENVS");
   ctx->tune.nt_state_min_envs = env_u32("COPTERSTEP_NT_STATE_MIN_ENVS");
+  ctx->tune.direct_rows_max_envs = env_u32("COPTERSTEP_DIRECT_ROWS_MAX_ENVS");
   ctx->layout = cs::make_layout(cfg->state_mode);
   cs::DevState& s = ctx->st;
   s.n = (uint32_t)cfg->num_envs;
@@ -485,7 +486,7 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       const_cast<float*>(actions_dev), obs_dev, reward_dev,
                                       terminated_dev, truncated_dev, cs::CS_POLICY_NONE, nullptr,
-                                      nullptr, 0, (hipStream_t)stream);
+                                      nullptr, 0, ctx->tune, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_step_many: kernel launch");
   return CS_OK;
 }
@@ -636,7 +637,7 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,
                                       truncated_dev, cs::CS_POLICY_PID, &ctx->pid, ctx->pid_state,
-                                      ctx->pid_stride, (hipStream_t)stream);
+                                      ctx->pid_stride, ctx->tune, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_rollout_pid: kernel launch");
   return CS_OK;
 }
@@ -649,7 +650,7 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,
-                                      truncated_dev, cs::CS_POLICY_RANDOM, nullptr, nullptr, 0,
+                                      truncated_dev, cs::CS_POLICY_RANDOM, nullptr, nullptr, 0, ctx->tune,
                                       (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_rollout_random: kernel launch");
   return CS_OK;
@@ -698,6 +699,7 @@ int cs_set_tuning(cs_ctx* ctx, const cs_tuning* t) {
     return fail(CS_ERR_ARG, "cs_set_tuning: tuning missing or struct_size mismatch");
   ctx->tune.nt_action_max_envs = t->nt_action_max_envs;
   ctx->tune.nt_state_min_envs = t->nt_state_min_envs;
+  ctx->tune.direct_rows_max_envs = t->direct_rows_max_envs;
   return CS_OK;
 }
 
@@ -707,6 +709,8 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out) {
   out->struct_size = (uint32_t)sizeof(cs_tuning);
   out->nt_action_max_envs = ctx->tune.nt_action_max_envs ? ctx->tune.nt_action_max_envs : d.nt_action_max_envs;
   out->nt_state_min_envs = ctx->tune.nt_state_min_envs ? ctx->tune.nt_state_min_envs : d.nt_state_min_envs;
+  out->direct_rows_max_envs =
+      ctx->tune.direct_rows_max_envs ? ctx->tune.direct_rows_max_envs : d.direct_rows_max_envs;
   return CS_OK;
 }
 

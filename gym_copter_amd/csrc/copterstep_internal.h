@@ -183,6 +183,7 @@ struct DevState {
 struct Tuning {
   uint32_t nt_action_max_envs;  // <= this many envs: action rows are loaded with the non-temporal hint
   uint32_t nt_state_min_envs;   // >= this many envs: the state is streamed past the caches
+  uint32_t direct_rows_max_envs;  // <= this many envs: the K-step kernels store observation rows per lane
 };
 
 Tuning default_tuning();
@@ -196,7 +197,7 @@ enum { CS_POLICY_NONE = 0, CS_POLICY_PID = 1, CS_POLICY_RANDOM = 2 };
 hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
                             float* actions, float* obs, float* reward, uint8_t* term,
                             uint8_t* trunc, int policy, const PidConst* pid, double* pid_state,
-                            uint32_t pid_stride, hipStream_t stream);
+                            uint32_t pid_stride, const Tuning& tune, hipStream_t stream);
 hipError_t launch_export_state(int mode, const DevConst& c, const DevState& s, float* x, uint8_t* status,
                                int32_t* steps, hipStream_t stream);
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,

@@ -91,6 +91,9 @@ constexpr uint32_t kNtActionMaxEnvs = 98304;
 // streaming it (non-temporal loads and stores) measured -17 % time at 4 M envs and -14 % at 16 M
 // under reset churn, but +7..25 % at 1 M envs and below, where the caches do hold it.
 constexpr uint32_t kNtStateMinEnvs = 3670016;  // 3.5 M (3 M envs still measured 5..10 % better un-streamed)
+// K-step kernels: up to this many envs (one wavefront per SIMD on 256 CUs) the observation rows are stored
+// per lane instead of through the LDS transpose: -8..12 % per step at 65 536 envs, +13..55 % from 131 072 up
+constexpr uint32_t kDirectRowsMaxEnvs = 65536;
 template <bool STREAM, class V>
 __device__ __forceinline__ V load_maybe_stream(const V* p) {
   if constexpr (STREAM) {
@@ -399,9 +402,12 @@ __device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& 
 struct Trig {
   double sph, cph, sth, cth, sps, cps;
 };
-template <bool FULL>
+// IN_LOOP: the call sits in a K-step loop, where laying the in-range path out as the fall-through pays
+// (-3 % per step); in the one-step kernel the same layout measured +2.5 %, so it keeps the compiler's
+template <bool FULL, bool IN_LOOP>
 __device__ __forceinline__ void sincos_roll_pitch(const DevConst& c, double phi, double the, Trig& t) {
-  if (__builtin_expect(__all(fabs(phi) < 0.785 && fabs(the) < 0.785), 1)) {
+  const bool in_range = __all(fabs(phi) < 0.785 && fabs(the) < 0.785);
+  if (IN_LOOP ? __builtin_expect(in_range, 1) : in_range) {
     sincos_kernel<FULL>(c.trig, phi, t.sph, t.cph);
     sincos_kernel<FULL>(c.trig, the, t.sth, t.cth);
   } else {
@@ -409,9 +415,10 @@ __device__ __forceinline__ void sincos_roll_pitch(const DevConst& c, double phi,
     sincos_f64<FULL>(c, the, t.sth, t.cth);
   }
 }
-template <bool FULL>
+template <bool FULL, bool IN_LOOP>
 __device__ __forceinline__ void sincos_yaw(const DevConst& c, double psi, Trig& t) {
-  if (__builtin_expect(__all(fabs(psi) < 0.785), 1)) {
+  const bool in_range = __all(fabs(psi) < 0.785);
+  if (IN_LOOP ? __builtin_expect(in_range, 1) : in_range) {
     sincos_kernel<FULL>(c.trig, psi, t.sps, t.cps);
   } else {
     sincos_f64<FULL>(c, psi, t.sps, t.cps);
@@ -577,13 +584,13 @@ __device__ __forceinline__ void euler_rotation(const Coef& q, const Wrench& w, d
 // (px,py,pz) = 2*force/M, the pending reset perturbation in its doubled form (upstream
 // adds it inside the derivative, :263-271, and again at :183), zero when none is
 // pending.  Returns what the call did.
-template <bool FULL, bool GYRO>
+template <bool FULL, bool GYRO, bool IN_LOOP = false>
 __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, const Wrench& w,
                                             double (&x)[12], int& fs, double px, double py,
                                             double pz) {
   Trig t;
-  sincos_roll_pitch<FULL>(c, x[6], x[8], t);
-  sincos_yaw<FULL>(c, x[10], t);
+  sincos_roll_pitch<FULL, IN_LOOP>(c, x[6], x[8], t);
+  sincos_yaw<FULL, IN_LOOP>(c, x[10], t);
   double ax, ay, netz;
   thrust_ned(q, w.bz, t, ax, ay, netz);
   const CallPlan p = plan_call(c, fs, netz, x[4], x[5], x[3], x[6]);
@@ -597,18 +604,18 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, co
 // `nsub` x Dynamics.setMotors with one wrench.  The pending perturbation can only enter the FIRST
 // call: a call that freezes on ground contact keeps it, but the status it leaves (CRASHED / LEVELING)
 // makes the next call drop it.
-template <bool FULL, bool GYRO, bool ONE_CALL>
+template <bool FULL, bool GYRO, bool ONE_CALL, bool IN_LOOP = false>
 __device__ __forceinline__ void physics_substeps(const DevConst& c, const Coef& q, const Wrench& w,
                                                  double (&x)[12], int& fs, bool& pend, double px,
                                                  double py, double pz) {
   if constexpr (ONE_CALL) {  // upstream's own configuration (substeps = 1): no loop
-    const int what = physics_call<FULL, GYRO>(c, q, w, x, fs, px, py, pz);
+    const int what = physics_call<FULL, GYRO, IN_LOOP>(c, q, w, x, fs, px, py, pz);
     pend = pend && what == kCallFroze;
     return;
   }
 #pragma clang loop unroll(disable)
   for (int sub = 0; sub < c.nsub; ++sub) {
-    const int what = physics_call<FULL, GYRO>(c, q, w, x, fs, px, py, pz);
+    const int what = physics_call<FULL, GYRO, IN_LOOP>(c, q, w, x, fs, px, py, pz);
     // a call that froze keeps the perturbation (upstream's early return); it is inert
     // there (dt = 0) and the next call, which cannot integrate either, drops it
     const bool keep = pend && what == kCallFroze;
@@ -850,7 +857,7 @@ __device__ __forceinline__ bool test_tilt(const DevConst& c, double phi, double 
 // substeps -> stored-word rounding -> reward / termination -> optional done list and
 // final_obs -> masked auto-reset (task.py:145-197).  Shared by the one-step and the
 // K-step kernels, so both advance an env bit-identically.
-template <int TASK, int MODE, int OBS, bool LEAN, bool ONE_CALL, class TILE>
+template <int TASK, int MODE, int OBS, bool LEAN, bool ONE_CALL, bool IN_LOOP, class TILE>
 __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const StepOpts& o,
                                         Env<MODE>& e, const float4 act, const cs_step_io& io, uint32_t i,
                                         int lane, bool valid, const TILE& tile,
@@ -881,9 +888,9 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     bool gyro = false;
     if constexpr (!LEAN) gyro = o.gyro;
     if (gyro) {
-      physics_substeps<FULL, true, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+      physics_substeps<FULL, true, false, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
     } else {
-      physics_substeps<FULL, false, ONE_CALL>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+      physics_substeps<FULL, false, ONE_CALL, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
     }
   }
 
@@ -1048,7 +1055,7 @@ __device__ __forceinline__ void step_body(
     if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
   }
   StepOut<OBS> out;
-  advance<TASK, MODE, OBS, LEAN, ONE_CALL>(c, q, o, e, act, io, i, lane, valid, tile, out);
+  advance<TASK, MODE, OBS, LEAN, ONE_CALL, false>(c, q, o, e, act, io, i, lane, valid, tile, out);
   CS_STAMP(5);
 
   // ---- stores: 4 x 16 B (state, guards, counters) + prev_shaping ----
@@ -1182,7 +1189,7 @@ __device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[NC
 // would take the landing-heuristic kernel from four to three wavefronts per SIMD)
 enum { kPolicyNone = 0, kPolicyPid = 1, kPolicyRandom = 2, kPolicyPidHover = 3 };
 
-template <int TASK, int MODE, bool LEAN, int POLICY>
+template <int TASK, int MODE, bool LEAN, int POLICY, bool ONE_CALL, bool DIRECT_ROWS>
 __global__ __launch_bounds__(kBlock) void step_many_kernel(
     char* const tiles, const uint32_t n_envs, float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
@@ -1320,7 +1327,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       act_next = load_action<TASK>(actions_dev + (size_t)kn * n * ACT, ia);  // prefetch
     }
     StepOut<OBS> out;
-    advance<TASK, MODE, OBS, LEAN, false>(c, q, o, e, act, io, i, lane, valid, tile, out);
+    advance<TASK, MODE, OBS, LEAN, ONE_CALL, true>(c, q, o, e, act, io, i, lane, valid, tile, out);
     if constexpr (kPid) {
 #pragma unroll
       for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
@@ -1334,7 +1341,17 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       if (terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(terminated_dev + row, i));
       if (truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(truncated_dev + row, i));
     }
-    write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
+    if constexpr (DIRECT_ROWS) {
+      // one wavefront per SIMD: instruction issue is the limit, and three row stores per lane cost fewer
+      // instructions than the LDS transpose (whose full-line stores win as soon as SIMDs hold two wavefronts)
+      if (obs_dev != nullptr && valid) {
+        float* dst = obs_dev + (row + i) * OBS;
+#pragma unroll
+        for (int j = 0; j < OBS; ++j) dst[j] = out.row[j];
+      }
+    } else {
+      write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
+    }
     act = act_next;
   }
 
@@ -1734,14 +1751,30 @@ template <int TASK, int MODE>
 hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, float* actions,
                        float* obs, float* reward, uint8_t* term, uint8_t* trunc,
                        int policy, const PidConst* pid, double* pid_state, uint32_t pid_stride,
-                       hipStream_t stream) {
+                       const Tuning& tune, hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
   const bool lean = lean_config(c, s);
+  const uint32_t direct_max = tune.direct_rows_max_envs ? tune.direct_rows_max_envs : kDirectRowsMaxEnvs;
   const PidConst pc = pid ? *pid : PidConst{};
-#define CS_MANY(LEAN, POLICY)                                                                   \
-  hipLaunchKernelGGL((step_many_kernel<TASK, MODE, LEAN, POLICY>), grid, block, 0, stream,      \
-                     s.tiles, s.n, actions, obs, reward, term, trunc, num_steps, c, s, pc,      \
+#define CS_MANY_N(LEAN, POLICY, ONE, DIRECT)                                                           \
+  hipLaunchKernelGGL((step_many_kernel<TASK, MODE, LEAN, POLICY, ONE, DIRECT>), grid, block, 0, stream, \
+                     s.tiles, s.n, actions, obs, reward, term, trunc, num_steps, c, s, pc,             \
                      pid_state, pid_stride)
+  // upstream's own configuration (one physics call per step) has its own instantiation of the lean
+  // kernels of the tuned combinations, as in step_t
+#define CS_MANY(LEAN, POLICY)                                  \
+  do {                                                         \
+    if constexpr (LEAN && is_tuned(TASK, MODE)) {              \
+      if (c.nsub == 1) {                                       \
+        if (s.n <= direct_max)                                 \
+          CS_MANY_N(LEAN, POLICY, true, true);                 \
+        else                                                   \
+          CS_MANY_N(LEAN, POLICY, true, false);                \
+        break;                                                 \
+      }                                                        \
+    }                                                          \
+    CS_MANY_N(LEAN, POLICY, false, false);                     \
+  } while (0)
   if (policy == kPolicyPid) {
     if constexpr (task_act_dim(TASK) == 4) {  // the heuristic reads the 3D observation
       if (pid == nullptr || pid_state == nullptr) return hipErrorInvalidValue;
@@ -1773,6 +1806,7 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
     CS_MANY(false, kPolicyNone);
   }
 #undef CS_MANY
+#undef CS_MANY_N
   return hipGetLastError();
 }
 
@@ -1788,7 +1822,7 @@ hipError_t reset_t(const DevConst& c, const DevState& s, const uint8_t* mask, co
 
 }  // namespace
 
-Tuning default_tuning() { return Tuning{kNtActionMaxEnvs, kNtStateMinEnvs}; }
+Tuning default_tuning() { return Tuning{kNtActionMaxEnvs, kNtStateMinEnvs, kDirectRowsMaxEnvs}; }
 
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                        const cs_step_io& io, const Tuning& tune, hipStream_t stream) {
@@ -1798,9 +1832,9 @@ hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
 hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevState& s, int num_steps,
                             float* actions, float* obs, float* reward, uint8_t* term,
                             uint8_t* trunc, int policy, const PidConst* pid, double* pid_state,
-                            uint32_t pid_stride, hipStream_t stream) {
+                            uint32_t pid_stride, const Tuning& tune, hipStream_t stream) {
   CS_DISPATCH(step_many_t, c, s, num_steps, actions, obs, reward, term, trunc, policy, pid,
-              pid_state, pid_stride, stream)
+              pid_state, pid_stride, tune, stream)
 }
 
 hipError_t launch_export_state(int mode, const DevConst& c, const DevState& s, float* x, uint8_t* status,

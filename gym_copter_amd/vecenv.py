@@ -623,18 +623,20 @@ class CopterVecEnv:
             _lib.check(self._lib.cs_episode_stats(self._ctx, C.c_void_p(self._stats_t.data_ptr()), self._stream()))
         return self._stats_t
 
-    def set_tuning(self, nt_action_max_envs=0, nt_state_min_envs=0):
+    def set_tuning(self, nt_action_max_envs=0, nt_state_min_envs=0, direct_rows_max_envs=0):
         """Launcher thresholds (0 = built-in default; they pick between instantiations of the same
         kernel and never change results).  Returns the values in effect."""
         self._check_open()
-        t = _lib.Tuning(C.sizeof(_lib.Tuning), int(nt_action_max_envs), int(nt_state_min_envs))
+        t = _lib.Tuning(C.sizeof(_lib.Tuning), int(nt_action_max_envs), int(nt_state_min_envs),
+                        int(direct_rows_max_envs))
         _lib.check(self._lib.cs_set_tuning(self._ctx, C.byref(t)))
         return self.get_tuning()
 
     def get_tuning(self):
         t = _lib.Tuning()
         _lib.check(self._lib.cs_get_tuning(self._ctx, C.byref(t)))
-        return {"nt_action_max_envs": t.nt_action_max_envs, "nt_state_min_envs": t.nt_state_min_envs}
+        return {"nt_action_max_envs": t.nt_action_max_envs, "nt_state_min_envs": t.nt_state_min_envs,
+                "direct_rows_max_envs": t.direct_rows_max_envs}
 
 
 def _to_numpy(v):

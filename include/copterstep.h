@@ -302,11 +302,14 @@ int cs_episode_stats(cs_ctx* ctx, double* stats_dev, void* stream);
 
 /* Launcher thresholds that depend on the batch size (0 = built-in default).  They select between
  * instantiations of the same step kernel and never change results.  cs_create also reads the
- * environment variables COPTERSTEP_NT_ACTION_MAX_ENVS and COPTERSTEP_NT_STATE_MIN_ENVS. */
+ * environment variables COPTERSTEP_NT_ACTION_MAX_ENVS, COPTERSTEP_NT_STATE_MIN_ENVS and
+ * COPTERSTEP_DIRECT_ROWS_MAX_ENVS. */
 typedef struct cs_tuning {
   uint32_t struct_size;         /* sizeof(cs_tuning) */
   uint32_t nt_action_max_envs;  /* up to this many envs the action rows are loaded non-temporally */
   uint32_t nt_state_min_envs;   /* from this many envs the state is streamed past the caches */
+  uint32_t direct_rows_max_envs; /* up to this many envs the K-step kernels (cs_step_many, cs_rollout_*)
+                                    store observation rows per lane instead of through the LDS transpose */
 } cs_tuning;
 int cs_set_tuning(cs_ctx* ctx, const cs_tuning* tuning);
 int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out); /* the values in effect */

@@ -188,12 +188,13 @@ int main(int argc, char** argv) {
   {
     cs_tuning t;
     OK(cs_get_tuning(ctx, &t));
-    CHECK(t.struct_size == sizeof(cs_tuning) && t.nt_action_max_envs == 98304 && t.nt_state_min_envs == 3670016);
+    CHECK(t.struct_size == sizeof(cs_tuning) && t.nt_action_max_envs == 98304 && t.nt_state_min_envs == 3670016 &&
+          t.direct_rows_max_envs == 65536);
     t.nt_action_max_envs = 5;
     t.nt_state_min_envs = 0;
     OK(cs_set_tuning(ctx, &t));
     OK(cs_get_tuning(ctx, &t));
-    CHECK(t.nt_action_max_envs == 5 && t.nt_state_min_envs == 3670016);
+    CHECK(t.nt_action_max_envs == 5 && t.nt_state_min_envs == 3670016 && t.direct_rows_max_envs == 65536);
     t.struct_size = 3;
     CHECK(cs_set_tuning(ctx, &t) == CS_ERR_ARG);
   }

@@ -12,10 +12,10 @@
 #include <cinttypes>
 
 namespace cs {
-Tuning default_tuning() { return Tuning{98304u, 3670016u}; }
+Tuning default_tuning() { return Tuning{98304u, 3670016u, 65536u}; }
 hipError_t launch_step(int, int, const DevConst&, const DevState&, const cs_step_io&, const Tuning&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_step_many(int, int, const DevConst&, const DevState&, int, float*, float*, float*, uint8_t*, uint8_t*, int,
-                            const PidConst*, double*, uint32_t, hipStream_t) { return hipErrorUnknown; }
+                            const PidConst*, double*, uint32_t, const Tuning&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_export_state(int, const DevConst&, const DevState&, float*, uint8_t*, int32_t*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_set_motors(int, const DevConst&, const DevState&, const float*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_reset(int, int, const DevConst&, const DevState&, const uint8_t*, const float*, float*, double*, uint32_t,

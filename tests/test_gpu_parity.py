@@ -1195,9 +1195,37 @@ def test_tuning_overrides_from_the_environment(monkeypatch):
     env = gym_copter_amd.CopterVecEnv("lander3d", 256)
     t = env.get_tuning()
     assert t["nt_action_max_envs"] == 1234 and t["nt_state_min_envs"] == 3670016
+    assert t["direct_rows_max_envs"] == 65536
     t = env.set_tuning(nt_state_min_envs=512)
-    assert t == {"nt_action_max_envs": 98304, "nt_state_min_envs": 512}
+    assert t == {"nt_action_max_envs": 98304, "nt_state_min_envs": 512, "direct_rows_max_envs": 65536}
     env.close()
+
+
+@pytest.mark.parametrize("task", ["lander3d", "hover3d"])
+def test_k_step_row_store_instantiations_agree(task):
+    """cs_step_many / cs_rollout_* store observation rows per lane up to direct_rows_max_envs and through
+    the LDS transpose beyond: the same results either way, also on a ragged last wavefront."""
+    import torch
+    n, K = 3000 + 37, 12
+    rng = np.random.default_rng(4)
+    envs = []
+    for direct_max in (1, 1 << 30):          # transpose / per-lane rows
+        e, _ = make_pair(task, n, "float32", autoreset="next_step", seed=6)
+        e.set_tuning(direct_rows_max_envs=direct_max)
+        e.configure_pid("hover" if task == "hover3d" else "lander")
+        e.reset()
+        envs.append(e)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (K, n, 4)).astype(np.float32)).to(envs[0].device)
+    for call in (lambda e: e.step_many(acts), lambda e: e.rollout_random(K, return_actions=True),
+                 lambda e: e.rollout_pid(K, return_actions=True)):
+        a, b = call(envs[0]), call(envs[1])
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    s1, s2 = envs[0].get_state(), envs[1].get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k], equal_nan=True), k
+    for e in envs:
+        e.close()
 
 
 @pytest.mark.parametrize("tuning", [dict(nt_action_max_envs=1, nt_state_min_envs=1),      # streamed state
