@@ -45,9 +45,9 @@ line = ("step_kernel<Lander3D,F32G,LEAN,stream actions> dispatch durations from 
 m = rr[0]
 line += "VGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s\n" % (
     m["VGPR_Count"], m["SGPR_Count"], m["LDS_Block_Size"], m["Scratch_Size"], m["Grid_Size_X"], m["Workgroup_Size_X"])
-for name, desc in (("step_many_kernel<0, 0, true, 0>", "open loop, 64 steps per launch"),
-                   ("step_many_kernel<0, 0, true, 1>", "PID policy, 100 steps per launch"),
-                   ("step_many_kernel<0, 0, true, 2>", "random policy, 100 steps per launch")):
+for name, desc in (("step_many_kernel<0, 0, true, 0,", "open loop, 64 steps per launch"),
+                   ("step_many_kernel<0, 0, true, 1,", "PID policy, 100 steps per launch"),
+                   ("step_many_kernel<0, 0, true, 2,", "random policy, 100 steps per launch")):
     rr, dd = durations(name)
     if len(dd):
         line += "%s (%s): n=%d mean=%.0f ns  VGPR=%s SGPR=%s\n" % (name, desc, len(dd), dd.mean(),

@@ -76,9 +76,9 @@ for sub in ("sq1", "sq2", "l2"):
 # the K-step kernels of the same runs (bench.py extras): executed instructions per wavefront and env-step
 print("\n== PMC, K-step kernels: per wavefront and env-step ==")
 res["pmc_k_step"] = {}
-for name, label, k in (("step_many_kernel<0, 0, true, 0>", "open loop", 64),
-                       ("step_many_kernel<0, 0, true, 1>", "PID policy", 100),
-                       ("step_many_kernel<0, 0, true, 2>", "random policy", 100)):
+for name, label, k in (("step_many_kernel<0, 0, true, 0,", "open loop", 64),
+                       ("step_many_kernel<0, 0, true, 1,", "PID policy", 100),
+                       ("step_many_kernel<0, 0, true, 2,", "random policy", 100)):
     m = {}
     for sub in ("sq1", "sq2"):
         m.update(counters(sub, name))
