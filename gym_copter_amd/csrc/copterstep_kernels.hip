@@ -1299,6 +1299,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     for (int j = 0; j < OBS; ++j) seen[j] = (float)e.x[j];
   } else if constexpr (POLICY == kPolicyNone) {
     act = load_action<TASK>(actions_dev, ia);
+    // delivered before the loop is entered, as every later row is before its iteration (below): the loop
+    // body then never waits on the memory counter for its action
+    asm volatile("" : "+v"(act.x), "+v"(act.y), "+v"(act.z), "+v"(act.w));
   }
   for (int k = 0; k < num_steps; ++k) {
     // rows of step k (64-bit uniform offsets: K * N can exceed 32 bits)
@@ -1335,6 +1338,12 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
 #pragma unroll
         for (int j = 0; j < NCTL; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
       }
+    }
+    if constexpr (POLICY == kPolicyNone) {
+      // The memory counter retires loads and stores in issue order: taking delivery of the next action
+      // row HERE, before this step's stores are issued, costs nothing (it was requested a whole step ago),
+      // while at the top of the next iteration the same wait would also sit out these stores' round trip.
+      asm volatile("" : "+v"(act_next.x), "+v"(act_next.y), "+v"(act_next.z), "+v"(act_next.w));
     }
     if (valid) {
       if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
