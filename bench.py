@@ -591,6 +591,37 @@ def main(argv=None):
             extra["config5"] = {"error": repr(e)}
             torch.cuda.empty_cache()
 
+    if rank == 0 and use_graph and not a.no_sweep:
+        # context for the headline's latency-bound figure: what ONE dependent launch costs on this box when the
+        # kernel does next to nothing -- a hipGraph chain of in-place adds on 64 Ki floats (1 024 x 64 threads)
+        try:
+            probe = torch.zeros(65536, dtype=torch.float32, device=device)
+
+            class Floor:
+                def __init__(self):
+                    s = torch.cuda.Stream(device=device)
+                    s.wait_stream(torch.cuda.current_stream(device))
+                    with torch.cuda.stream(s):
+                        probe.add_(1.0)
+                    torch.cuda.current_stream(device).wait_stream(s)
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph):
+                        for _ in range(100):
+                            probe.add_(1.0)
+
+                def run(self, count):
+                    for _ in range(count // 100):
+                        self.graph.replay()
+
+            fl = Timer(torch, None, device).measure(Floor(), 2000, 200, min_region_s, 3, quantum=100)
+            extra["dependent_launch_floor"] = {
+                "us_per_launch": fl["launch_s"] * 1e6,
+                "note": "hipGraph chain of torch in-place adds on 65 536 floats: the per-launch cost of a dependent "
+                        "kernel that does almost nothing (inter-kernel gap + one read-modify-write through the "
+                        "fabric); the step kernel's launch_us contains the same floor"}
+        except Exception as e:
+            extra["dependent_launch_floor"] = {"error": repr(e)}
+
     traffic, tsrc = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
