@@ -97,7 +97,7 @@ class ShardedCopterVecEnv:
     group.  step()/reset() take and return LOCAL rows unless gather is enabled."""
 
     def __init__(self, task="lander3d", total_envs=1, gather="none", group=None, device=None,
-                 env_id_offset=0, **env_kwargs):
+                 env_id_offset=0, flat=True, **env_kwargs):
         import torch.distributed as dist
         if gather not in ("none", "obs", "all"):
             raise ValueError("gather must be 'none', 'obs' or 'all'")
@@ -116,6 +116,10 @@ class ShardedCopterVecEnv:
         self.local = vecenv.CopterVecEnv(task=task, num_envs=self.n_local, device=device,
                                          env_id_base=self.env_id_base, **env_kwargs)
         self.gather = gather
+        # gather="all": flat=True returns [N, ...] rows (one device copy per step when world > 1: the
+        # sections of the packed per-rank chunks are not adjacent); flat=False returns the zero-copy
+        # [world, n_local, ...] views of the gathered buffer, rank-major = global env-id order
+        self.flat = bool(flat)
         self._gather = ShardGather(self.n_local, self.world, group)
         self._packed = None
         if gather == "all":
@@ -160,9 +164,12 @@ class ShardedCopterVecEnv:
                 pk.term.copy_(term.view(torch.uint8))
                 pk.trunc.copy_(trunc.view(torch.uint8))
             g_obs, g_rew, g_term, g_trunc = pk.all_gather()       # ONE collective
-            # [world, n_local, ...] views -> [N, ...] rows in global env-id order
-            obs, reward = g_obs.reshape(N, self.obs_dim), g_rew.reshape(N)
-            term, trunc = g_term.reshape(N).view(torch.bool), g_trunc.reshape(N).view(torch.bool)
+            if self.flat:    # [world, n_local, ...] views -> [N, ...] rows in global env-id order
+                obs, reward = g_obs.reshape(N, self.obs_dim), g_rew.reshape(N)
+                term, trunc = g_term.reshape(N).view(torch.bool), g_trunc.reshape(N).view(torch.bool)
+            else:
+                obs, reward = g_obs, g_rew
+                term, trunc = g_term.view(torch.bool), g_trunc.view(torch.bool)
         return obs, reward, term, trunc, infos
 
     def close(self):

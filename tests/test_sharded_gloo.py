@@ -67,6 +67,14 @@ def _worker(rank, world, port, out_dir):
             assert obs.shape == (TOTAL, 10) and r.shape == (TOTAL,) and term.dtype == torch.bool
             rows.append(np.concatenate([obs.numpy().ravel(), r.numpy(), term.numpy(), trunc.numpy()]))
         np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([x.ravel() for x in rows]))
+        # flat=False: the zero-copy [world, n_local, ...] views hold the same rows
+        env2 = ShardedCopterVecEnv("lander3d", TOTAL, gather="all", seed=77, flat=False)
+        env2.reset()
+        o3, r3, t3, u3, _ = env2.step(acts[0])
+        assert o3.shape == (world, TOTAL // world, 10) and r3.shape == (world, TOTAL // world)
+        assert t3.dtype == torch.bool and u3.shape == (world, TOTAL // world)
+        assert np.array_equal(o3.reshape(TOTAL, 10).numpy().ravel(), rows[1][:TOTAL * 10])
+        assert o3.untyped_storage().data_ptr() == env2._packed.gathered.untyped_storage().data_ptr()
     finally:
         dist.destroy_process_group()
 
