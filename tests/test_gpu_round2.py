@@ -421,3 +421,29 @@ def test_sharded_env_in_a_spawned_nccl_process_group(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "SHARDED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_bench_as_a_torchrun_rank_with_gather_legs(tmp_path):
+    """bench.py the way the driver launches N > 1 (torch.distributed.run, RCCL process group, rendezvous on
+    127.0.0.1), with one rank -- what one GPU allows: ONE JSON line on stdout carrying the contract keys and the
+    three gather legs (obs rows, packed, double-buffered half-batches), all hipGraph-captured."""
+    import json
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20",
+           "--warmup", "5", "--gather", "--no-sweep", "--no-cpu-baseline", "--pid", "0", "--many", "0",
+           "--min-region-ms", "5", "--regions", "3"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    for k in ("value_with_allgather", "value_with_packed_allgather", "value_with_pipelined_allgather"):
+        assert 0 < d[k] <= d["value"] * 1.05, (k, d[k], d["value"])
+    assert set(d["allgather_launch_mode"]) == {"obs", "packed", "pipelined"}
+    assert all(m == "graph" for m in d["allgather_launch_mode"].values()), d["allgather_launch_mode"]
