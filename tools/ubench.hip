@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_issue(unsigned long long* out, int iters
 
 // Straight-line version (no loop, no branch): 256 instructions in CHAINS independent dependency chains.
 // CHAINS = 1 is a pure dependent chain (issue-to-issue latency), CHAINS = 8 is the issue rate.
-enum { SL_F64 = 0, SL_F32 = 1, SL_INT = 2, SL_MAD64 = 3, SL_CVT = 4, SL_F64_MUL = 5, SL_RCP64 = 6, SL_SQRT64 = 7, SL_BRANCH = 8, SL_TAKEN = 9, SL_NOT_TAKEN = 10, SL_EXECZ_NOT_TAKEN = 11, SL_SALU = 12 };
+enum { SL_F64 = 0, SL_F32 = 1, SL_INT = 2, SL_MAD64 = 3, SL_CVT = 4, SL_F64_MUL = 5, SL_RCP64 = 6, SL_SQRT64 = 7, SL_BRANCH = 8, SL_TAKEN = 9, SL_NOT_TAKEN = 10, SL_EXECZ_NOT_TAKEN = 11, SL_SALU = 12, SL_SETREG = 13, SL_CVT_ONLY = 14 };
 template <int OP, int CHAINS>
 __global__ __launch_bounds__(64) void k_line(unsigned long long* out, double seed, int never) {
   const int lane = threadIdx.x;
@@ -104,6 +104,10 @@ __global__ __launch_bounds__(64) void k_line(unsigned long long* out, double see
       asm volatile("v_xor_b32 %0, %0, %0\n s_cmp_eq_u32 %1, %1\n s_cbranch_scc0 .Ln%=\n.Ln%=:" : "+v"(u[j]) : "s"(never) : "scc");
     if (OP == SL_EXECZ_NOT_TAKEN)
       asm volatile("v_xor_b32 %0, %0, %0\n s_cbranch_execz .Le%=\n.Le%=:" : "+v"(u[j]));
+    if (OP == SL_SETREG)   // the round-mode bracket of words_of_rtz6 around ONE conversion
+      asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n s_nop 0\n v_cvt_f32_f64 %0, %1\n s_nop 0\n"
+                   "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0" : "=v"(f[j]) : "v"(a[j]));
+    if (OP == SL_CVT_ONLY) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[j]) : "v"(a[j]));
     if (OP == SL_SALU)
       asm volatile("v_xor_b32 %0, %0, %0\n s_cmp_eq_u32 %1, %1" : "+v"(u[j]) : "s"(never) : "scc");
     if (OP == SL_BRANCH) {  // a uniform branch that is always taken over one instruction
@@ -190,6 +194,8 @@ int main() {
   line<SL_RCP64, 1>("rcp f64", dev); line<SL_RCP64, 8>("rcp f64", dev);
   line<SL_SQRT64, 1>("rsq f64", dev); line<SL_SQRT64, 8>("rsq f64", dev);
   line<SL_BRANCH, 8>("xor + skipped branch", dev);
+  line<SL_CVT_ONLY, 8>("cvt f32<-f64 alone", dev);
+  line<SL_SETREG, 8>("setreg + nop + cvt + nop + setreg", dev);
   line<SL_SALU, 8>("xor + s_cmp", dev);
   line<SL_NOT_TAKEN, 8>("xor + s_cmp + branch not taken", dev);
   line<SL_EXECZ_NOT_TAKEN, 8>("xor + execz branch not taken", dev);
