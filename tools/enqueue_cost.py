@@ -1,6 +1,15 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
-import torch, gym_copter_amd
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): host cost of one CopterVecEnv.step() call, through the _cs_call module and through
+ctypes, on a 64-env context (the kernel is far shorter than the call, so the loop is host-bound).
+  python tools/enqueue_cost.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import gym_copter_amd  # noqa: E402
+
 env = gym_copter_amd.CopterVecEnv("lander3d", 64, seed=1, autoreset_mode="next_step")
 env.reset()
 a = torch.rand((64, 4), device=env.device) * 2 - 1
