@@ -262,6 +262,44 @@ def test_full_size_short_rollout_vs_oracle(task, n):
     env.close()
 
 
+def test_long_soak_mixed_actions_vs_oracle():
+    """20 000 steps of 384 envs (7.7 M env-steps, thousands of episodes per env: the episode counters, the
+    Philox draws keyed by them and the step-limit path all run far past anything a short test reaches) with a
+    mixed action law -- a third of the envs random (crash / tilt / out-of-bounds churn), a third near hover
+    (episodes end at the 1000-step limit), a third descending gently from 2 m (soft landings with the bonus, and
+    crashes when the reset perturbation pushes the sink rate past the limit); every output of every step against
+    the oracle, and the full state at the end."""
+    import torch
+    n, T = 384, 20000
+    rng = np.random.default_rng(2024)
+    env, orc = make_pair("lander3d", n, "float32", autoreset="next_step", seed=99, initial_altitude=2.0)
+    env.reset()
+    orc.reset()
+    hover = HOVER
+    ends = np.zeros(n, dtype=np.int64)
+    bonus = 0
+    seen = set()
+    chunk = 500
+    for t0 in range(0, T, chunk):
+        a = np.empty((chunk, n, 4), dtype=np.float32)
+        a[:, 0::3] = rng.uniform(-1, 1, (chunk, n // 3, 4))
+        a[:, 1::3] = hover * (1 + 0.01 * rng.standard_normal((chunk, n // 3, 4)))
+        a[:, 2::3] = 0.99 * hover * (1 + 0.002 * rng.standard_normal((chunk, n // 3, 4)))   # -0.2 m/s^2
+        for k in range(chunk):
+            got, want, _ = step_both(env, orc, a[k])
+            assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6, ctx="t=%d" % (t0 + k))
+            ends += want[2]
+            bonus += int((want[1][2::3] > 50).sum())
+            seen |= set(np.unique(orc.status).tolist())
+    assert_state_close(env, orc, 2e-6, ctx="soak")
+    assert ends[0::3].min() > 500 and ends[1::3].min() >= 15 and ends[2::3].min() >= 15, (
+        ends[0::3].min(), ends[1::3].min(), ends[2::3].min())
+    assert bonus > 1000 and seen == {0, 1, 2, 3}       # soft landings with the bonus; every flight status met
+    st = env.get_state()
+    assert st["episode"].max() > 1000
+    env.close()
+
+
 def test_substeps_config5():
     """BASELINE config 5: dt = 1e-3 with 10 inner substeps per step()."""
     g = DYN["D10_fps1000"]
