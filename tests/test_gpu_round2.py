@@ -318,6 +318,53 @@ def test_float64_mode_at_the_context_size_limit():
     env.close()
 
 
+@pytest.mark.parametrize("task,n", [("lander3d", 65536), ("hover3d", 262144)])
+def test_mirror_symmetry_at_full_size(task, n):
+    """A property of the rigid body that needs no oracle, at BASELINE's full batch sizes: reflect the world in
+    the x-z plane (y, dy, roll, roll rate, yaw, yaw rate and the lateral perturbation change sign; the motors
+    swap 0<->2 and 1<->3, which negates the roll and yaw torques and keeps thrust and pitch torque,
+    dynamics/__init__.py:127-132, :231-247) and the trajectory is the reflected trajectory: same rewards, same
+    terminations, mirrored observations -- to float64 rounding (the sums of the motor model are re-associated
+    by the swap)."""
+    import torch
+    import gym_copter_amd
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    a_env = gym_copter_amd.CopterVecEnv(task, n, state_dtype="float64", autoreset_mode="disabled")
+    b_env = gym_copter_amd.CopterVecEnv(task, n, state_dtype="float64", autoreset_mode="disabled")
+    forces = (torch.rand((3, n), generator=g, device="cuda") * 2 - 1) * 30
+    mirrored = forces.clone()
+    mirrored[1] = -mirrored[1]
+    oa, _ = a_env.reset(options={"forces": forces})
+    ob, _ = b_env.reset(options={"forces": mirrored})
+    od = a_env.obs_dim
+    sign = torch.ones(od, device="cuda")
+    for slot in (2, 3, 6, 7, 10, 11):          # y, dy, phi, dphi, psi, dpsi
+        if slot < od:
+            sign[slot] = -1
+    assert torch.equal(oa * sign, ob)
+    swap = torch.tensor([2, 3, 0, 1], device="cuda")
+    ends = 0
+    for t in range(60):
+        a = torch.rand((n, 4), generator=g, device="cuda") * 0.05       # around hover thrust: long flights
+        if t % 3 == 0:
+            a = torch.rand((n, 4), generator=g, device="cuda") * 2 - 1     # and violent ones
+        ra = [x.clone() for x in a_env.step(a)[:4]]
+        rb = b_env.step(a[:, swap].contiguous())[:4]
+        err = ((ra[0] * sign - rb[0]).abs() / rb[0].abs().clamp(min=1.0)).max().item()
+        assert err <= 1e-6, (t, err)       # float32 observations of float64 states
+        assert torch.equal(ra[2], rb[2]) and torch.equal(ra[3], rb[3]), t
+        assert ((ra[1] - rb[1]).abs() <= 1e-3 + 1e-6 * rb[1].abs()).all(), t
+        ends += int(ra[2].sum())
+    sa, sb = a_env.get_state(), b_env.get_state()
+    xs = np.ones(12)
+    xs[[2, 3, 6, 7, 10, 11]] = -1
+    assert scaled_err(sa["x"] * xs[:, None], sb["x"]) <= 1e-9
+    assert np.array_equal(sa["status"], sb["status"]) and ends > 0
+    a_env.close()
+    b_env.close()
+
+
 def test_step_through_the_call_module_equals_step_through_ctypes():
     """The eager fast path (cs_step by address, gym_copter_amd/_cs_call.so) is in use and equals the ctypes path
     bit for bit; anything but a resident contiguous float32 batch takes the general path."""
