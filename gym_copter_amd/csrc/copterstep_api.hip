@@ -1,6 +1,7 @@
 // copterstep_api.hip -- the C ABI of libcopterstep.so (include/copterstep.h): context
 // ownership, derivation of the per-launch constants from cs_config, error reporting,
-// and host<->device state exchange.  All compute lives in copterstep_kernels.hip.
+// and host<->device state exchange.  All compute lives in copterstep_kernels.hip
+// and its dev_*.h device headers.
 #include <dlfcn.h>
 
 #include <cmath>
@@ -75,7 +76,7 @@ uint64_t splitmix64(uint64_t z) {
 
 const double kPi = 3.141592653589793238462643383279502884;
 
-// The eleven folded coefficients of one vehicle + world (copterstep_kernels.hip: Coef).  Uniform
+// The eleven folded coefficients of one vehicle + world (dev_physics.h: Coef).  Uniform
 // factors and reciprocals are folded here in float64; the kernels multiply where upstream divides
 // (a few ulp(f64) apart).
 struct VehicleIn {

@@ -1,0 +1,94 @@
+// dev_pid.h -- the on-device PID heuristics (attic/mars/pidcontrollers, lander3d.py:64-87, hover3d.py:65-92).
+// Device code of copterstep_kernels.hip (included there, inside its floating-point-contraction pragma);
+// not a stand-alone header.
+#pragma once
+
+namespace cs {
+namespace {
+
+// Pin a uniform value into vector registers (opaque to the optimiser).
+__device__ __forceinline__ double in_vgpr(double v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------
+// On-device PID landing heuristic (the retired upstream controllers,
+// attic/mars/pidcontrollers/__init__.py:12-146, wired as attic/mars/lander3d.py:64-87).
+// Same float64 operation order as the Python classes: observation float32 -> float64,
+// controller arithmetic float64, action rounded to float32 (the action space's dtype).
+// Controller state per env: 4 controllers x {errorI, lastError, deltaError1, deltaError2}.
+// ---------------------------------------------------------------------------------
+struct PidCtl {
+  double err_i, last, d1, d2;
+};
+
+// _PidController.compute (pidcontrollers/__init__.py:33-63)
+__device__ __forceinline__ double pid_compute(PidCtl& s, double kp, double ki, double kd,
+                                              double windup, double target, double actual) {
+  const double error = target - actual;
+  double acc = error * kp;
+  double iterm = 0.0;
+  if (ki > 0.0) {
+    const double v = s.err_i + error;
+    s.err_i = v < -windup ? -windup : (v > windup ? windup : v);
+    iterm = s.err_i * ki;
+  }
+  acc = acc + iterm;
+  double dterm = 0.0;
+  if (kd > 0.0) {
+    const double de = error - s.last;
+    dterm = ((s.d1 + s.d2) + de) * kd;
+    s.d2 = s.d1;
+    s.d1 = de;
+    s.last = error;
+  }
+  return acc + dterm;
+}
+
+// AngularVelocityPidController.getDemand (:135-146): a wild rate restarts the controller
+__device__ __forceinline__ double pid_rate(const PidConst& p, PidCtl& s, double w) {
+  if (fabs(w) > p.rate_big) {
+    s.err_i = 0.0;
+    s.last = 0.0;
+  }
+  return pid_compute(s, p.rate_kp, p.rate_ki, p.rate_kd, p.rate_windup, 0.0, w);
+}
+
+// PositionHoldPidController.getDemand (:94-108): unit-gain position loop -> velocity loop
+__device__ __forceinline__ double pid_pos(const PidConst& p, PidCtl& s, double x, double dx) {
+  const double target_velocity = (p.pos_target - x) * 1.0;
+  return pid_compute(s, p.pos_kp, p.pos_ki, p.pos_kd, p.pos_windup, target_velocity, dx);
+}
+
+// heuristic + mixer: the landing heuristic (attic/mars/lander3d.py:64-87) or, on the 12-slot
+// observation, the hover heuristic (attic/mars/hover3d.py:65-92: a yaw-rate controller and the
+// altitude-hold controller of attic/mars/hover.py:23 instead of the descent law)
+template <int OBS, bool HOVER, int NCTL>
+__device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[NCTL],
+                                             const float (&obs)[OBS]) {
+  const double x = obs[0], dx = obs[1], y = obs[2], dy = obs[3], z = obs[4], dz = obs[5];
+  const double dphi = obs[7], dtheta = obs[9];
+  const double r = pid_rate(p, ctl[0], dphi) + pid_pos(p, ctl[2], y, dy);
+  const double q = pid_rate(p, ctl[1], -dtheta) + pid_pos(p, ctl[3], x, dx);
+  if constexpr (HOVER) {
+    static_assert(OBS >= 12 && NCTL == kPidControllers, "the hover heuristic reads dpsi and has six controllers");
+    {
+      const double dpsi = obs[11];
+      const double yw = pid_rate(p, ctl[4], -dpsi);
+      // AltitudeHoldPidController.getDemand (pidcontrollers/__init__.py:83-92): NED negated
+      const double target_velocity = (p.alt_target - (-z)) * 1.0;
+      const double hover =
+          pid_compute(ctl[5], p.alt_kp, p.alt_ki, p.alt_kd, p.alt_windup, target_velocity, -dz);
+      const double t = (hover + 1.0) / 2.0;
+      return make_float4((float)(((t - r) - q) - yw), (float)(((t + r) + q) - yw),
+                         (float)(((t + r) - q) + yw), (float)(((t - r) + q) + yw));
+    }
+  }
+  const double t = ((z * p.descent_kp + dz * p.descent_kd) + 1.0) / 2.0;
+  return make_float4((float)((t - r) - q), (float)((t + r) + q), (float)((t + r) - q),
+                     (float)((t - r) + q));
+}
+
+}  // namespace
+}  // namespace cs

@@ -1,0 +1,335 @@
+// dev_task.h -- one register-resident env and one _Task.step() on it: observation rows, tile <-> registers, reward / termination, auto-reset (task.py:77-202).
+// Device code of copterstep_kernels.hip (included there, inside its floating-point-contraction pragma);
+// not a stand-alone header.
+#pragma once
+
+namespace cs {
+namespace {
+
+// ---------------------------------------------------------------------------------
+// AoS observation rows through a per-wavefront LDS transpose.
+// Each lane deposits its OBS floats at row `lane`; the wavefront then streams the
+// 64*OBS contiguous floats out as 16-byte-per-lane stores (1 KiB per instruction).
+// ---------------------------------------------------------------------------------
+template <int OBS>
+__device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_wave, int lane,
+                                           uint32_t env0, uint32_t n, bool valid,
+                                           const float (&row)[OBS]) {
+  if (out == nullptr) return;
+  // full wavefront (a wavefront past the end has env0 >= n) and a 16-byte aligned block: the K-step
+  // kernels offset `out` by k*n*OBS floats, which an odd n leaves only 8-byte aligned
+  const bool vec_ok = env0 + (uint32_t)kWave <= n && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  if (vec_ok) {
+#pragma unroll
+    for (int j = 0; j < OBS; j += 2) {
+      *reinterpret_cast<float2*>(lds_wave + lane * OBS + j) = make_float2(row[j], row[j + 1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float4* src = reinterpret_cast<const float4*>(lds_wave);
+    constexpr int kVec = kWave * OBS / 4;  // 160 (Lander3D) or 192 (Hover3D) float4
+    const uint32_t base = env0 * (uint32_t)(OBS * 4) + (uint32_t)lane * 16u;
+#pragma unroll
+    for (int k = 0; k < (kVec + kWave - 1) / kWave; ++k) {
+      const int v = k * kWave + lane;
+      if (v < kVec) {
+        const float4 r = src[v];
+        const f32x4 rv = {r.x, r.y, r.z, r.w};
+        CS_NT_STORE(rv, at32<f32x4>(out, base + (uint32_t)k * 1024u));
+      }
+    }
+  } else if (valid) {  // ragged last wavefront / unaligned block: plain row stores
+    float* dst = out + (size_t)(env0 + lane) * OBS;
+#pragma unroll
+    for (int j = 0; j < OBS; ++j) dst[j] = row[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// one env, register-resident, and one _Task.step() on it
+// ---------------------------------------------------------------------------------
+template <int MODE>
+struct Env {
+  using T = typename ModeOf<MODE>::T;
+  double x[12];        // the values the stored representation decodes to
+  int steps, fs;       // step counter, flight status
+  bool pend;           // this episode's reset perturbation is not yet consumed
+  bool expl;           // ... and it is the explicit force of the FE group (else: the Philox draw)
+  bool reset_pending;  // NEXT_STEP: finished, resets at the next step
+  uint32_t episode;    // episodes started
+  double prev_sh;
+  float ep_ret;
+};
+
+template <int OBS>
+struct StepOut {
+  float row[OBS];  // observation returned by this step
+  double reward;
+  bool term, trunc;
+  bool did_reset;  // the env started a new episode inside this step
+};
+
+struct StepOpts {  // uniform switches (compiled out in LEAN builds)
+  bool stats, trunc, done_list, same_step, gyro, act_f32;
+};
+
+// the raw groups of one tile <-> Env
+template <int MODE, class TILE>
+__device__ __forceinline__ void unpack_env(const DevConst& c, const typename TILE::Group& t1,
+                                           const typename TILE::Group& t2, const typename TILE::Group& r1,
+                                           const typename TILE::Group& r2, Env<MODE>& e) {
+  const uint32_t gT = TILE::int_lo(t2), meta = TILE::int_hi(t2), gR = TILE::int_lo(r2);
+  e.episode = TILE::int_hi(r2);
+  e.steps = (int)(meta & kMetaStepsMask);
+  e.fs = (int)(gT >> kStatusShift);
+  e.pend = (meta & kMetaPerturbPending) != 0;
+  e.expl = (meta & kMetaExplicitForce) != 0;
+  e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && (meta & kMetaResetPending) != 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    e.x[k] = decode_word<MODE>(as_word(t1.v[k]), gT, k);
+    e.x[6 + k] = decode_word<MODE>(as_word(r1.v[k]), gR, k);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    e.x[4 + k] = decode_word<MODE>(as_word(t2.v[k]), gT, 4 + k);
+    e.x[10 + k] = decode_word<MODE>(as_word(r2.v[k]), gR, 4 + k);
+  }
+}
+
+__device__ __forceinline__ uint32_t pack_meta(int steps, bool pend, bool expl, bool reset_pending) {
+  return (uint32_t)steps | (pend ? kMetaPerturbPending : 0u) | (expl ? kMetaExplicitForce : 0u) |
+         (reset_pending ? kMetaResetPending : 0u);
+}
+
+template <int MODE, class TILE>
+__device__ __forceinline__ void store_env(const TILE& tile, const Env<MODE>& e) {
+  using T = typename ModeOf<MODE>::T;
+  T w[12];
+  words6<MODE>(e.x, w);
+  words6<MODE>(e.x + 6, w + 6);
+  const uint32_t gT = pack_guards6<MODE>(e.x) | ((uint32_t)e.fs << kStatusShift);
+  const uint32_t gR = pack_guards6<MODE>(e.x + 6);
+  typename TILE::Group t1, t2, r1, r2;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    t1.v[k] = as_bits(w[k]);
+    r1.v[k] = as_bits(w[6 + k]);
+  }
+  t2.v[0] = as_bits(w[4]);
+  t2.v[1] = as_bits(w[5]);
+  r2.v[0] = as_bits(w[10]);
+  r2.v[1] = as_bits(w[11]);
+  TILE::set_ints(t2, gT, pack_meta(e.steps, e.pend, e.expl, e.reset_pending));
+  TILE::set_ints(r2, gR, e.episode);
+  tile.store_group(0, t1);
+  tile.store_group(1, t2);
+  tile.store_group(2, r1);
+  tile.store_group(3, r2);
+}
+
+// One action row -> the four motor demands: _get_motors (lander.py:95-97 for the 3D tasks; the
+// fan-outs of attic lander2d.py:48-50 / lander1d.py:46-48 for the variants).  Coalesced
+// 16 / 8 / 4 bytes per lane.
+template <int TASK, bool STREAM = false>
+__device__ __forceinline__ float4 load_action(const float* base, uint32_t env) {
+  constexpr int A = task_act_dim(TASK);
+  if constexpr (A == 4) {
+    const f32x4 a = load_maybe_stream<STREAM>(at32<const f32x4>(base, env << 4));
+    return make_float4(a.x, a.y, a.z, a.w);
+  } else if constexpr (A == 2) {
+    const f32x2 a = load_maybe_stream<STREAM>(at32<const f32x2>(base, env << 3));
+    return make_float4(a.x, a.y, a.y, a.x);
+  } else {
+    const float a = load_maybe_stream<STREAM>(at32<const float>(base, env << 2));
+    return make_float4(a, a, a, a);
+  }
+}
+
+// The pending reset perturbation of an env in its doubled form 2*F/M (dynamics :263-271 + :183):
+// the explicit force of the FE group, or this episode's Philox draw, evaluated here, where it is used.
+template <int MODE, class TILE>
+__device__ __forceinline__ void pending_perturbation(const DevConst& c, const Coef& q, const TILE& tile,
+                                                     uint32_t i, uint32_t episode, bool pend, bool expl,
+                                                     double& px, double& py, double& pz) {
+  using T = typename ModeOf<MODE>::T;
+  px = py = pz = 0.0;
+  if (pend) {
+    double f[3];
+    draw_force<T>(c, i, episode - 1u, f);
+    if (__builtin_expect(expl, 0)) {  // an installed force: rare, kept out of the common path
+      const Vec4<T> fe = tile.load_fe();
+      f[0] = (double)fe.v[0];
+      f[1] = (double)fe.v[1];
+      f[2] = (double)fe.v[2];
+    }
+    px = f[0] * q.two_inv_M;
+    py = f[1] * q.two_inv_M;
+    pz = f[2] * q.two_inv_M;
+  }
+}
+
+// reward / termination of one step (task.py:104-130, lander.py:58-74) from its ingredients:
+// sh = shaping potential of the new state, inside = sqrt(x^2+y^2) < target radius, oob / tilt = the
+// bounds and angle tests on the new state
+struct Verdict {
+  double reward;
+  bool term, trunc;
+};
+template <int TASK>
+__device__ __forceinline__ Verdict judge_step(const DevConst& c, bool opt_trunc, int status0, int steps,
+                                              double sh, double prev_sh, bool inside, bool oob, bool tilt) {
+  double reward;
+  bool done = false;
+  if constexpr (task_is_lander(TASK)) {
+    reward = (prev_sh != prev_sh) ? 0.0 : sh - prev_sh;  // NaN == None
+    if (status0 == CS_STATUS_LANDED) {
+      done = true;
+      if (inside) reward += c.bonus;
+    }
+  } else {
+    reward = 1.0;
+  }
+  if (oob) {
+    done = true;
+    reward -= c.oob_penalty;
+  } else if (tilt) {
+    done = true;
+    reward = -c.oob_penalty;
+  } else if (status0 == CS_STATUS_CRASHED) {
+    done = true;
+  }
+  const bool limit = steps == c.max_steps;
+  Verdict v;
+  v.trunc = opt_trunc && limit && !done;
+  v.term = done || (!opt_trunc && limit);
+  v.reward = reward;
+  return v;
+}
+__device__ __forceinline__ bool test_inside(const DevConst& c, double x, double y) {
+  return fma(x, x, y * y) < c.target_r2;
+}
+__device__ __forceinline__ bool test_oob(const DevConst& c, double x, double y) {
+  return fabs(x) >= c.bounds || fabs(y) >= c.bounds;
+}
+__device__ __forceinline__ bool test_tilt(const DevConst& c, double phi, double the) {
+  return fabs(phi) >= c.max_angle || fabs(the) >= c.max_angle;
+}
+
+// _Task.step() (task.py:77-137) for one register-resident env: Dynamics.setMotors x
+// substeps -> stored-word rounding -> reward / termination -> optional done list and
+// final_obs -> masked auto-reset (task.py:145-197).  Shared by the one-step and the
+// K-step kernels, so both advance an env bit-identically.
+template <int TASK, int MODE, int OBS, bool LEAN, bool ONE_CALL, bool IN_LOOP, class TILE>
+__device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const StepOpts& o,
+                                        Env<MODE>& e, const float4 act, const cs_step_io& io, uint32_t i,
+                                        int lane, bool valid, const TILE& tile,
+                                        StepOut<OBS>& out) {
+  using T = typename ModeOf<MODE>::T;
+  constexpr int FIRST = task_obs_first(TASK);
+  constexpr bool FULL = MODE == CS_STATE_F64;
+  const bool resetting = e.reset_pending;  // only ever set under NEXT_STEP auto-reset
+  double reward = 0.0;
+  bool term = false, trunc = false;
+
+  // ---- Dynamics.setMotors x substeps (skipped when the env entered LANDED) ----
+  const int status0 = e.fs;
+  if (!resetting && status0 != CS_STATUS_LANDED) {
+    // np.clip(action, 0, 1), task.py:91
+    const float a0 = clip01(act.x), a1 = clip01(act.y), a2 = clip01(act.z), a3 = clip01(act.w);
+    Wrench w;
+    bool f32_model = false;
+    if constexpr (!LEAN) f32_model = o.act_f32;
+    if (f32_model) {
+      w = motor_model_f32(c, a0, a1, a2, a3);
+    } else {
+      w.bz = thrust_model(q, a0, a1, a2, a3);
+      torque_model(q, a0, a1, a2, a3, w);
+    }
+    double px, py, pz;
+    pending_perturbation<MODE>(c, q, tile, i, e.episode, e.pend, e.expl, px, py, pz);
+    bool gyro = false;
+    if constexpr (!LEAN) gyro = o.gyro;
+    if (gyro) {
+      physics_substeps<FULL, true, false, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+    } else {
+      physics_substeps<FULL, false, ONE_CALL, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+    }
+  }
+
+  // ---- round to the stored precision; everything below sees exactly what is stored ----
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    e.x[k] = round_stored<MODE>(e.x[k]);
+    // float32 observation: round-to-nearest of the stored value (slots FIRST .. FIRST+OBS-1)
+    if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)e.x[k];
+  }
+
+  // ---- reward / termination (task.py:104-130, lander.py:46-74) ----
+  if (!resetting) {
+    double sh = 0.0;
+    if constexpr (task_is_lander(TASK)) sh = lander_shaping(c, e.x);
+    const Verdict v = judge_step<TASK>(c, o.trunc, status0, e.steps, sh, e.prev_sh,
+                                       test_inside(c, e.x[0], e.x[2]), test_oob(c, e.x[0], e.x[2]),
+                                       test_tilt(c, e.x[6], e.x[8]));
+    if constexpr (task_is_lander(TASK)) e.prev_sh = (double)(T)sh;
+    reward = v.reward;
+    term = v.term;
+    trunc = v.trunc;
+    e.steps = min(e.steps + 1, (int)kMetaStepsMask);
+    e.ep_ret += (float)reward;
+  }
+  const bool fin = term || trunc;
+
+  // ---- finished-episode list: wave ballot -> one atomic per wavefront ----
+  if (o.done_list) {
+    const unsigned long long m = __ballot(fin && valid);
+    if (m != 0ULL) {
+      const int leader = __ffsll((long long)m) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(io.done_count_dev, (int)__popcll(m));
+      base = __shfl(base, leader);
+      if (fin && valid) {
+        const int slot = base + (int)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (io.done_ids_dev) io.done_ids_dev[slot] = (int32_t)i;
+        if (io.done_return_dev) io.done_return_dev[slot] = e.ep_ret;
+        if (io.done_length_dev) io.done_length_dev[slot] = e.steps - 1;
+      }
+    }
+  }
+
+  // ---- observation of the finished state (SAME_STEP keeps it in final_obs) ----
+  if (o.same_step && io.final_obs_dev != nullptr && fin && valid) {
+    float* dst = io.final_obs_dev + (size_t)i * OBS;
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) dst[k] = out.row[k];
+  }
+
+  // ---- masked reset (task.py:145-197): fresh state, a new episode number (its perturbation is the
+  //      Philox draw of that number, evaluated when the physics consumes it), shaping, steps = 1 ----
+  const bool do_reset = resetting || (o.same_step && fin);
+  e.reset_pending = c.autoreset == CS_AUTORESET_NEXT_STEP && fin;
+  if (do_reset) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const T w0 = (k == 4) ? (T)c.z0 : (T)0;
+      e.x[k] = (double)w0;
+      if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
+    }
+    e.episode += 1u;
+    e.fs = c.status0;
+    e.pend = true;
+    e.expl = false;
+    e.steps = 1;
+    e.ep_ret = 0.f;
+    e.prev_sh = c.reset_shaping;
+  }
+  out.reward = reward;
+  out.term = term;
+  out.trunc = trunc;
+  out.did_reset = do_reset;
+}
+
+}  // namespace
+}  // namespace cs
