@@ -200,6 +200,68 @@ class Stepper:
             done += 1
 
 
+class PipeStepper:
+    """The double-buffered half-batch schedule of gym_copter_amd.sharded.HalfBatchPipeline without a policy:
+    per step, half h is waited for (where a learner would consume its rows) and stepped again, so its packed
+    all-gather is on the links while the other half steps.  hipGraph replay of `chunk` steps when `graph`."""
+
+    def __init__(self, torch, pipe, actions, device, graph, chunk):
+        self.torch, self.pipe, self.actions, self.chunk_steps = torch, pipe, actions, chunk
+        self.half, self.ring = actions.shape[1] // 2, actions.shape[0]
+        self.graph, self.pos = None, 0
+        if graph:
+            cur = torch.cuda.current_stream(device)
+            s = torch.cuda.Stream(device=device)
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                self.chunk(3)
+            cur.wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.chunk(chunk)
+
+    def chunk(self, count, start=0):
+        pipe, hn = self.pipe, self.half
+        for j in range(count):
+            row = self.actions[(start + j) % self.ring]
+            for h in (0, 1):
+                if j:
+                    pipe.wait(h)
+                pipe.step_async(h, row[h * hn:(h + 1) * hn])
+        pipe.wait(0)
+        pipe.wait(1)
+
+    def run(self, count):
+        done = 0
+        if self.graph is not None:
+            while count - done >= self.chunk_steps:
+                self.graph.replay()
+                done += self.chunk_steps
+        if done < count:
+            self.chunk(count - done, self.pos)
+            self.pos += count - done
+
+
+class LaunchFloor:
+    """A hipGraph chain of 100 in-place adds on a small tensor: what one dependent launch costs on this box when
+    the kernel does next to nothing."""
+
+    def __init__(self, torch, probe, device):
+        s = torch.cuda.Stream(device=device)
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            probe.add_(1.0)
+        torch.cuda.current_stream(device).wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            for _ in range(100):
+                probe.add_(1.0)
+
+    def run(self, count):
+        for _ in range(count // 100):
+            self.graph.replay()
+
+
 class Timer:
     """barrier + synchronize on both sides of a region; host clock for the wall time (MAX over
     ranks), HIP events on the launch stream for the device time of the same region."""
@@ -454,49 +516,13 @@ def main(argv=None):
             pipe = HalfBatchPipeline(task=a.task, total_envs=total_envs, gather="all", device=local, seed=1234,
                                      autoreset_mode="next_step", state_dtype=a.state, substeps=a.substeps)
             pipe.reset()
-            hn, ring = n // 2, actions.shape[0]
-
-            class PipeRunner:
-                def __init__(self, graph):
-                    self.graph, self.pos = None, 0
-                    if graph:
-                        cur = torch.cuda.current_stream(device)
-                        s = torch.cuda.Stream(device=device)
-                        s.wait_stream(cur)
-                        with torch.cuda.stream(s):
-                            self.chunk(3)
-                        cur.wait_stream(s)
-                        self.graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(self.graph):
-                            self.chunk(chunk)
-
-                def chunk(self, count, start=0):
-                    for j in range(count):
-                        row = actions[(start + j) % ring]
-                        for h in (0, 1):
-                            if j:
-                                pipe.wait(h)          # where a learner would consume half h's rows
-                            pipe.step_async(h, row[h * hn:(h + 1) * hn])
-                    pipe.wait(0)
-                    pipe.wait(1)
-
-                def run(self, count):
-                    done = 0
-                    if self.graph is not None:
-                        while count - done >= chunk:
-                            self.graph.replay()
-                            done += chunk
-                    if done < count:
-                        self.chunk(count - done, self.pos)
-                        self.pos += count - done
-
             mode4 = "graph"
             try:
-                pr = PipeRunner(use_graph)
+                pr = PipeStepper(torch, pipe, actions, device, use_graph, chunk)
             except Exception as e:
                 torch.cuda.synchronize()
                 mode4 = "eager (capture failed: %s)" % type(e).__name__
-                pr = PipeRunner(False)
+                pr = PipeStepper(torch, pipe, actions, device, False, chunk)
             g4 = timer.measure(pr, a.steps, min(a.warmup, 50), min_region_s, a.regions,
                                quantum=chunk if mode4 == "graph" else 1)
             extra["value_with_pipelined_allgather"] = total_envs / g4["s_per_step"]
@@ -597,23 +623,8 @@ def main(argv=None):
         try:
             probe = torch.zeros(65536, dtype=torch.float32, device=device)
 
-            class Floor:
-                def __init__(self):
-                    s = torch.cuda.Stream(device=device)
-                    s.wait_stream(torch.cuda.current_stream(device))
-                    with torch.cuda.stream(s):
-                        probe.add_(1.0)
-                    torch.cuda.current_stream(device).wait_stream(s)
-                    self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph):
-                        for _ in range(100):
-                            probe.add_(1.0)
-
-                def run(self, count):
-                    for _ in range(count // 100):
-                        self.graph.replay()
-
-            fl = Timer(torch, None, device).measure(Floor(), 2000, 200, min_region_s, 3, quantum=100)
+            fl = Timer(torch, None, device).measure(LaunchFloor(torch, probe, device), 2000, 200, min_region_s, 3,
+                                                    quantum=100)
             extra["dependent_launch_floor"] = {
                 "us_per_launch": fl["launch_s"] * 1e6,
                 "note": "hipGraph chain of torch in-place adds on 65 536 floats: the per-launch cost of a dependent "
