@@ -48,7 +48,11 @@ _THRUST = {"B": _lib.THRUST_B, "lift": _lib.THRUST_LIFT}
 _TASK_KEYS = {"initial_random_force": "initial_random_force",             # task.py:32-38
               "out_of_bounds_penalty": "out_of_bounds_penalty",
               "max_angle": "max_angle_deg", "bounds": "bounds",
-              "initial_altitude": "initial_altitude"}
+              "initial_altitude": "initial_altitude",
+              # Lander's class constants (lander.py:17-23), overridable upstream by subclassing
+              "target_radius": "target_radius", "yaw_penalty_factor": "yaw_penalty_factor",
+              "xyz_penalty_factor": "xyz_penalty_factor", "dz_max": "dz_max", "dz_penalty": "dz_penalty",
+              "inside_radius_bonus": "inside_radius_bonus"}
 
 STATE_NAMES_12 = ['X', 'dX', 'Y', 'dY', 'Z', 'dZ', 'Phi', 'dPhi', 'Theta', 'dTheta', 'Psi', 'dPsi']
 

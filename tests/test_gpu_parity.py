@@ -262,6 +262,45 @@ def test_full_size_short_rollout_vs_oracle(task, n):
     env.close()
 
 
+@pytest.mark.parametrize("case", range(16))
+def test_randomised_task_parameters_vs_oracle(case):
+    """Every constructor keyword of the task at once, drawn at random per case -- _Task's keywords
+    (task.py:32-38), Lander's class constants (lander.py:17-23), the frame rate, the step limit, substeps --
+    with a mixed action law and auto-reset churn: 300 steps of 256 envs against the oracle, both tasks, all
+    three auto-reset modes."""
+    rng = np.random.default_rng(5000 + case)
+    task = ("lander3d", "hover3d")[case % 2]
+    autoreset = ("next_step", "same_step", "disabled")[case % 3]
+    kw = dict(initial_random_force=float(rng.uniform(0, 60)), out_of_bounds_penalty=float(rng.uniform(10, 300)),
+              max_angle=float(rng.uniform(20, 70)), bounds=float(rng.uniform(3, 20)),
+              initial_altitude=float(rng.uniform(0.5, 12)), max_steps=int(rng.integers(20, 400)),
+              frames_per_second=int(rng.choice([50, 100, 200])),
+              target_radius=float(rng.uniform(0.5, 5)), yaw_penalty_factor=float(rng.uniform(0, 100)),
+              xyz_penalty_factor=float(rng.uniform(1, 60)), dz_max=float(rng.uniform(1, 15)),
+              dz_penalty=float(rng.uniform(0, 200)), inside_radius_bonus=float(rng.uniform(0, 300)))
+    n, T = 256, 300
+    env, orc = make_pair(task, n, "float32", autoreset=autoreset, seed=case, substeps=int(rng.choice([1, 1, 3])),
+                         time_limit_truncates=bool(case & 4), **kw)
+    assert float(env.config.target_radius) == kw["target_radius"] and env.config.max_steps == kw["max_steps"]
+    env.reset()
+    orc.reset()
+    ends = 0
+    for t in range(T):
+        a = np.empty((n, 4), dtype=np.float32)
+        a[0::2] = rng.uniform(-1, 1, (n // 2, 4))
+        a[1::2] = HOVER * rng.uniform(0.97, 1.01) * (1 + 0.01 * rng.standard_normal((n // 2, 4)))
+        got, want, _ = step_both(env, orc, a)
+        assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6, ctx="case %d %s %s t=%d" % (case, task, autoreset, t))
+        done = want[2] | want[3]
+        ends += int(done.sum())
+        if autoreset == "disabled" and done.any():      # the caller resets what finished (masked reset)
+            env.reset(options={"mask": done})
+            orc.reset(mask=done)
+    assert_state_close(env, orc, 2e-6, ctx="case %d" % case)
+    assert ends > 0
+    env.close()
+
+
 def test_long_soak_mixed_actions_vs_oracle():
     """20 000 steps of 384 envs (7.7 M env-steps, thousands of episodes per env: the episode counters, the
     Philox draws keyed by them and the step-limit path all run far past anything a short test reaches) with a
