@@ -267,7 +267,7 @@ def test_randomised_task_parameters_vs_oracle(case):
     """Every constructor keyword of the task at once, drawn at random per case -- _Task's keywords
     (task.py:32-38), Lander's class constants (lander.py:17-23), the frame rate, the step limit, substeps --
     with a mixed action law and auto-reset churn: 300 steps of 256 envs against the oracle, both tasks, all
-    three auto-reset modes."""
+    three auto-reset modes, all three state-word modes."""
     rng = np.random.default_rng(5000 + case)
     task = ("lander3d", "hover3d")[case % 2]
     autoreset = ("next_step", "same_step", "disabled")[case % 3]
@@ -279,7 +279,8 @@ def test_randomised_task_parameters_vs_oracle(case):
               xyz_penalty_factor=float(rng.uniform(1, 60)), dz_max=float(rng.uniform(1, 15)),
               dz_penalty=float(rng.uniform(0, 200)), inside_radius_bonus=float(rng.uniform(0, 300)))
     n, T = 256, 300
-    env, orc = make_pair(task, n, "float32", autoreset=autoreset, seed=case, substeps=int(rng.choice([1, 1, 3])),
+    mode = ("float32", "float64", "float32_rn")[(case // 2) % 3]
+    env, orc = make_pair(task, n, mode, autoreset=autoreset, seed=case, substeps=int(rng.choice([1, 1, 3])),
                          time_limit_truncates=bool(case & 4), **kw)
     assert float(env.config.target_radius) == kw["target_radius"] and env.config.max_steps == kw["max_steps"]
     env.reset()
