@@ -278,10 +278,12 @@ def test_randomised_task_parameters_vs_oracle(case):
               target_radius=float(rng.uniform(0.5, 5)), yaw_penalty_factor=float(rng.uniform(0, 100)),
               xyz_penalty_factor=float(rng.uniform(1, 60)), dz_max=float(rng.uniform(1, 15)),
               dz_penalty=float(rng.uniform(0, 200)), inside_radius_bonus=float(rng.uniform(0, 300)))
-    n, T = 256, 300
     mode = ("float32", "float64", "float32_rn")[(case // 2) % 3]
-    env, orc = make_pair(task, n, mode, autoreset=autoreset, seed=case, substeps=int(rng.choice([1, 1, 3])),
-                         time_limit_truncates=bool(case & 4), **kw)
+    n, T = 256, 300
+    seed = (case, 2 ** 63 + case, 2 ** 64 - 1 - case)[int(rng.integers(3))]     # every bit of the seed matters
+    base = (0, 123456789, 2 ** 32 - n)[int(rng.integers(3))]                     # ... and of the global env id
+    env, orc = make_pair(task, n, mode, autoreset=autoreset, seed=seed, substeps=int(rng.choice([1, 1, 3])),
+                         time_limit_truncates=bool(case & 4), env_id_base=base, **kw)
     assert float(env.config.target_radius) == kw["target_radius"] and env.config.max_steps == kw["max_steps"]
     env.reset()
     orc.reset()
