@@ -494,3 +494,59 @@ def test_bench_as_a_torchrun_rank_with_gather_legs(tmp_path):
         assert 0 < d[k] <= d["value"] * 1.05, (k, d[k], d["value"])
     assert set(d["allgather_launch_mode"]) == {"obs", "packed", "pipelined"}
     assert all(m == "graph" for m in d["allgather_launch_mode"].values()), d["allgather_launch_mode"]
+
+
+def test_two_contexts_driven_from_two_threads():
+    """include/copterstep.h: contexts are not thread-safe, distinct contexts are independent -- two host threads,
+    each with its own context and its own stream, stepping concurrently, produce what the same contexts produce
+    when stepped one after the other."""
+    import threading
+    import torch
+    import gym_copter_amd
+    n, T = 4096, 400
+    g = torch.Generator(device="cuda")
+    g.manual_seed(23)
+    acts = torch.rand((T, n, 4), generator=g, device="cuda") * 2 - 1
+
+    def fly(env, stream, out, errs):
+        try:
+            with torch.cuda.stream(stream):
+                env.reset()
+                for t in range(T):
+                    o, r, term, _, _ = env.step(acts[t])
+                    if t % 50 == 49:
+                        out.append((o.clone(), r.clone(), term.clone()))
+                stream.synchronize()
+        except Exception as e:      # surfaced by the main thread
+            errs.append(e)
+
+    def run(threaded):
+        envs = [gym_copter_amd.CopterVecEnv("lander3d", n, seed=31 + k, autoreset_mode="next_step") for k in (0, 1)]
+        streams = [torch.cuda.Stream() for _ in envs]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        outs, errs = ([], []), []
+        if threaded:
+            th = [threading.Thread(target=fly, args=(envs[k], streams[k], outs[k], errs)) for k in (0, 1)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        else:
+            for k in (0, 1):
+                fly(envs[k], streams[k], outs[k], errs)
+        assert not errs, errs
+        torch.cuda.synchronize()
+        states = [e.get_state() for e in envs]
+        for e in envs:
+            e.close()
+        return outs, states
+
+    (a0, a1), sa = run(True)
+    (b0, b1), sb = run(False)
+    for x, y in zip(a0 + a1, b0 + b1):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+    for s1, s2 in zip(sa, sb):
+        for k in s1:
+            assert np.array_equal(s1[k], s2[k], equal_nan=True), k
