@@ -199,7 +199,10 @@ class HalfBatchPipeline:
         self.halves = [ShardedCopterVecEnv(task=task, total_envs=half, gather=gather, group=group,
                                            device=device, env_id_offset=h * half, **env_kwargs)
                        for h in (0, 1)]
-        self.n_local = self.halves[0].n_local
+        self.n_local = self.halves[0].n_local          # local envs PER HALF
+        self.rank, self.world = self.halves[0].rank, self.halves[0].world
+        self.gather = gather
+        self.num_envs = self.halves[0].num_envs        # rows per half that step()/wait() return
         self.obs_dim = self.halves[0].obs_dim
         self.single_observation_space = self.halves[0].single_observation_space
         self.single_action_space = self.halves[0].single_action_space
