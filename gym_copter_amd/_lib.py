@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # COPTERSTEP_LIB selects a diagnostic build of the same ABI (e.g. the stamp build); default = product
 LIB_PATH = os.environ.get("COPTERSTEP_LIB", os.path.join(_HERE, "libcopterstep.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 TASK_LANDER3D, TASK_HOVER3D, TASK_LANDER2D, TASK_LANDER1D, TASK_HOVER2D, TASK_HOVER1D = range(6)
 STATE_F32G, STATE_F32_RN, STATE_F64 = 0, 1, 2
 AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
@@ -18,7 +18,7 @@ STATUS_CRASHED, STATUS_LANDED, STATUS_LEVELING, STATUS_AIRBORNE = 0, 1, 2, 3
 ARITH_F64, ARITH_F32 = 0, 1
 THRUST_B, THRUST_LIFT = 0, 1
 VEHICLE_ROWS = 12
-EPISODE_STATS = 6
+EPISODE_STATS = 7
 COMM_ID_BYTES = 128
 
 
@@ -48,7 +48,7 @@ class Config(C.Structure):
         ("xyz_penalty_factor", C.c_double), ("dz_max", C.c_double), ("dz_penalty", C.c_double),
         ("inside_radius_bonus", C.c_double),
         ("action_arith", C.c_int32), ("thrust_model", C.c_int32), ("rotor_gyro", C.c_int32),
-        ("reserved_", C.c_int32), ("rho", C.c_double), ("C_L", C.c_double),
+        ("track_time", C.c_int32), ("rho", C.c_double), ("C_L", C.c_double),
     ]
 
 
@@ -108,7 +108,7 @@ SYMBOLS = {
     "cs_comm_create": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "cs_comm_destroy": (C.c_int, [_P]),
     "cs_allgather": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
-    "cs_export_state": (C.c_int, [_P, _P, _P, _P, _P]),
+    "cs_export_state": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "cs_set_vehicle_params": (C.c_int, [_P, _P]),
     "cs_pid_gains_init": (C.c_int, [_P]),
     "cs_pid_configure": (C.c_int, [_P, _P]),
@@ -116,8 +116,8 @@ SYMBOLS = {
     "cs_pid_set_state": (C.c_int, [_P, _P, _P]),
     "cs_rollout_pid": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_rollout_random": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
-    "cs_get_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
-    "cs_set_state": (C.c_int, [_P] + [_P] * 8 + [_P]),
+    "cs_get_state": (C.c_int, [_P] + [_P] * 9 + [_P]),
+    "cs_set_state": (C.c_int, [_P] + [_P] * 9 + [_P]),
 }
 
 _lib = None

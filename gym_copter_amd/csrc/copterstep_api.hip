@@ -131,6 +131,7 @@ cs::DevConst make_const(const cs_ctx* ctx) {
   c.g_the = k[10];
   c.gyro = g.rotor_gyro != 0 ? 1 : 0;
   c.act_f32 = g.action_arith == CS_ARITH_F32 ? 1 : 0;
+  c.ticks = g.track_time != 0 ? 1 : 0;
   // NumPy's float32 motor model: each Python scalar becomes the float32 nearest to it
   c.f32_maxrpm = (float)g.maxrpm;
   c.f32_pi = (float)kPi;
@@ -199,12 +200,13 @@ uint32_t env_u32(const char* name) {
 struct Staging {
   char* base = nullptr;
   size_t bytes = 0;
-  size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool want[8] = {false, false, false, false, false, false, false, false};
-  size_t size[8];
-  Staging(size_t n, const bool (&w)[8]) {
-    const size_t sz[8] = {12 * n * 8, n, n * 4, n * 8, 3 * n * 8, n, n * 8, n * 4};
-    for (int k = 0; k < 8; ++k) {
+  static constexpr int kArrays = 9;
+  size_t off[kArrays] = {};
+  bool want[kArrays] = {};
+  size_t size[kArrays];
+  Staging(size_t n, const bool (&w)[kArrays]) {
+    const size_t sz[kArrays] = {12 * n * 8, n, n * 4, n * 8, 3 * n * 8, n, n * 8, n * 4, n * 4};
+    for (int k = 0; k < kArrays; ++k) {
       want[k] = w[k];
       size[k] = sz[k];
       if (w[k]) {
@@ -222,7 +224,7 @@ struct Staging {
   }
   cs::StateArrays arrays() const {
     return cs::StateArrays{at<double>(0), at<uint8_t>(1), at<int32_t>(2), at<double>(3),
-                           at<double>(4), at<uint8_t>(5), at<double>(6), at<uint32_t>(7)};
+                           at<double>(4), at<uint8_t>(5), at<double>(6), at<uint32_t>(7), at<int32_t>(8)};
   }
 };
 
@@ -289,6 +291,7 @@ int cs_config_init(cs_config* cfg, int task) {
   cfg->action_arith = CS_ARITH_F64;
   cfg->thrust_model = CS_THRUST_B;
   cfg->rotor_gyro = 0;
+  cfg->track_time = 0;
   cfg->rho = 1.225;  // Earth air density, attic/mars/dynamics/__init__.py:86
   cfg->C_L = 0.4;    // attic/mars/dynamics/ingenuity.py:55
   return CS_OK;
@@ -667,10 +670,11 @@ int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
   return CS_OK;
 }
 
-int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, void* stream) {
+int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, int32_t* ticks_dev,
+                    void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   const cs::DevConst& c = constants(ctx);
-  hipError_t e = cs::launch_export_state(ctx->cfg.state_mode, c, ctx->st, x_dev, status_dev, steps_dev,
+  hipError_t e = cs::launch_export_state(ctx->cfg.state_mode, c, ctx->st, x_dev, status_dev, steps_dev, ticks_dev,
                                          (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_export_state: kernel launch");
   return CS_OK;
@@ -817,15 +821,16 @@ int cs_allgather(cs_comm* comm, const void* send_dev, void* recv_dev, int64_t by
 
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
-                 double* episode_return_host, uint32_t* episode_host, void* stream) {
+                 double* episode_return_host, uint32_t* episode_host, int32_t* ticks_host, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_get_state: episode_stats is disabled");
   DeviceGuard guard_dev(ctx->cfg.device);
-  void* host[8] = {x_host, status_host, steps_host, prev_shaping_host, force_xyz_host, flags_host,
-                   episode_return_host, episode_host};
-  bool want[8];
-  for (int k = 0; k < 8; ++k) want[k] = host[k] != nullptr;
+  constexpr int NA = Staging::kArrays;
+  void* host[NA] = {x_host, status_host, steps_host, prev_shaping_host, force_xyz_host, flags_host,
+                    episode_return_host, episode_host, ticks_host};
+  bool want[NA];
+  for (int k = 0; k < NA; ++k) want[k] = host[k] != nullptr;
   Staging st((size_t)ctx->st.n, want);
   if (st.bytes == 0) {
     CS_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -837,7 +842,7 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
   }
   hipError_t e = cs::launch_state_gather(ctx->cfg.state_mode, constants(ctx), ctx->st, st.arrays(), (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_get_state: kernel launch");
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < NA; ++k)
     if (want[k])
       CS_HIP(hipMemcpyAsync(host[k], st.base + st.off[k], st.size[k], hipMemcpyDeviceToHost, (hipStream_t)stream));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -847,10 +852,13 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
 int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
                  const int32_t* steps_host, const double* prev_shaping_host,
                  const double* force_xyz_host, const uint8_t* flags_host,
-                 const double* episode_return_host, const uint32_t* episode_host, void* stream) {
+                 const double* episode_return_host, const uint32_t* episode_host,
+                 const int32_t* ticks_host, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_set_state: episode_stats is disabled");
+  if (ticks_host && !ctx->cfg.track_time)
+    return fail(CS_ERR_ARG, "cs_set_state: track_time is disabled");
   const size_t n = ctx->st.n;
   if (status_host)
     for (size_t i = 0; i < n; ++i)
@@ -860,17 +868,18 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
       if (steps_host[i] < 0 || steps_host[i] > (int32_t)cs::kMetaStepsMask)
         return fail(CS_ERR_ARG, "cs_set_state: steps out of range");
   DeviceGuard guard_dev(ctx->cfg.device);
-  const void* host[8] = {x_host, status_host, steps_host, prev_shaping_host, force_xyz_host, flags_host,
-                         episode_return_host, episode_host};
-  bool want[8];
-  for (int k = 0; k < 8; ++k) want[k] = host[k] != nullptr;
+  constexpr int NA = Staging::kArrays;
+  const void* host[NA] = {x_host, status_host, steps_host, prev_shaping_host, force_xyz_host, flags_host,
+                          episode_return_host, episode_host, ticks_host};
+  bool want[NA];
+  for (int k = 0; k < NA; ++k) want[k] = host[k] != nullptr;
   Staging st(n, want);
   if (st.bytes == 0) return CS_OK;
   if (hipMalloc((void**)&st.base, st.bytes) != hipSuccess) {
     (void)hipGetLastError();
     return fail(CS_ERR_MEMORY, "cs_set_state: device staging allocation failed");
   }
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < NA; ++k)
     if (want[k])
       CS_HIP(hipMemcpyAsync(st.base + st.off[k], host[k], st.size[k], hipMemcpyHostToDevice, (hipStream_t)stream));
   hipError_t e = cs::launch_state_scatter(ctx->cfg.state_mode, constants(ctx), ctx->st, st.arrays(), (hipStream_t)stream);

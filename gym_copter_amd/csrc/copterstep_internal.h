@@ -27,8 +27,9 @@ namespace cs {
 //   R1  {phi, dphi, theta, dtheta}            rotational half ...
 //   R2  {psi, dpsi, gR, episode}              ... with its guard bits and the episode counter
 //   PS  prev_shaping (dword/qword row; NaN = upstream's None)
-//   FE  {force_x, force_y, force_z, 0}        EXPLICIT reset perturbation [N] (options['forces'],
-//                                             Dynamics.perturb); touched only while one is installed
+//   FE  {force_x, force_y, force_z, ticks}    EXPLICIT reset perturbation [N] (options['forces'],
+//                                             Dynamics.perturb); touched only while one is installed.
+//                                             ticks = Dynamics._ticks (only under cs_config.track_time)
 //   RET running episode return (dword row, episode_stats)
 //
 //   gT    = 5 guard bits of each of x, dx, y, dy, z, dz (bit 5j.. = slot j) | flight status (bits 30..31)
@@ -108,7 +109,7 @@ struct DevConst {
   uint32_t id_lo;                  // global id of local env 0
   int32_t gyro;                    // 1 = the rotor-inertia term is live (full-featured kernels only)
   int32_t act_f32;                 // 1 = NumPy's float32 evaluation of the motor model (f32_* below)
-  uint32_t pad_;
+  int32_t ticks;                   // 1 = keep Dynamics._ticks per env (cs_config.track_time; full-featured kernels only)
   // float32 motor model of a float32 action array under NumPy >= 2 promotion
   // (dynamics/__init__.py:120-132 with `motors` a float32 ndarray): every scalar is the float32
   // rounding of the Python value it multiplies or divides
@@ -199,7 +200,7 @@ hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevStat
                             uint8_t* trunc, int policy, const PidConst* pid, double* pid_state,
                             uint32_t pid_stride, const Tuning& tune, hipStream_t stream);
 hipError_t launch_export_state(int mode, const DevConst& c, const DevState& s, float* x, uint8_t* status,
-                               int32_t* steps, hipStream_t stream);
+                               int32_t* steps, int32_t* ticks, hipStream_t stream);
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,
                              hipStream_t stream);
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,
@@ -211,7 +212,8 @@ hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s
 hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* mask,
                                    const float* force_xyz, hipStream_t stream);
 // Running episode statistics: stats[0] = envs, [1] = envs airborne, [2] = sum of steps, [3] = max steps,
-// [4] = episodes started (sum), [5] = running episode return (sum; needs episode_stats), as float64.
+// [4] = episodes started (sum), [5] = running episode return (sum; needs episode_stats), [6] = envs with a
+// non-finite state word, as float64.
 hipError_t launch_episode_stats(int mode, const DevState& s, double* stats_dev, hipStream_t stream);
 
 // cs_get_state / cs_set_state: plain struct-of-arrays staging buffers on the DEVICE (any may be nullptr):
@@ -225,6 +227,7 @@ struct StateArrays {
   uint8_t* flags;
   double* ret;
   uint32_t* episode;
+  int32_t* ticks;
 };
 hipError_t launch_state_gather(int mode, const DevConst& c, const DevState& s, const StateArrays& a,
                                hipStream_t stream);

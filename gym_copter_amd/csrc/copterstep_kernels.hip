@@ -50,8 +50,9 @@ namespace {
 // LEAN = the common configuration (auto-reset DISABLED or NEXT_STEP, no episode statistics,
 // no done list / final_obs, time limit folded into `terminated`, uniform vehicle, float64 motor
 // model, no rotor-inertia term): the optional features are compiled out instead of being skipped
-// by uniform branches.  PREFETCH: cs_step_io.next_actions_dev is set.
-template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool PREFETCH, bool ONE_CALL>
+// by uniform branches.  (cs_step_io.next_actions_dev is accepted and ignored: the kernel-side touch of the
+// next action rows measured +3.5 % per step in round 2 and was removed in round 3.)
+template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL>
 __device__ __forceinline__ void step_body(
     char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
@@ -74,6 +75,7 @@ __device__ __forceinline__ void step_body(
   o.same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
   o.gyro = !LEAN && c.gyro;
   o.act_f32 = !LEAN && c.act_f32;
+  o.ticks = !LEAN && c.ticks;
   constexpr int OBS = task_obs_dim(TASK);
   __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
 
@@ -100,6 +102,8 @@ __device__ __forceinline__ void step_body(
   if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
   e.ep_ret = 0.f;
   if (o.stats) e.ep_ret = tile.load_ret();
+  e.ticks = 0u;
+  if (o.ticks) e.ticks = tile.load_ticks();
   unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   // The action row is used only by lanes that fly, i.e. inside a branch: left to itself the compiler
   // sinks the LOAD into that branch, behind the wait for the state -- two memory round trips in a
@@ -109,22 +113,6 @@ __device__ __forceinline__ void step_body(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   CS_STAMP(1);
-
-  // Open-loop callers may name the NEXT step's action batch: touch this tile's rows of it (one
-  // dword per 16-byte row = every 128-byte line of the 1 KiB block) so that the next launch -- same
-  // tile, same XCD -- may find them in this XCD's L2.  Issued behind the first-round loads' last wait
-  // (the fake operands tie it there: a wait counts loads in issue order, so an earlier position would
-  // make the physics wait for this one too); the destination stays reserved to the end of the kernel
-  // and is never read.
-  uint32_t prefetch_sink = 0;
-  if constexpr (PREFETCH) {
-    constexpr uint32_t row = (uint32_t)task_act_dim(TASK) * 4u;
-    asm volatile("global_load_dword %0, %1, %2"
-                 : "=v"(prefetch_sink)
-                 : "v"((valid ? i : 0u) * row), "s"(io.next_actions_dev), "v"(act.x), "v"(e.x[0]),
-                   "v"(e.x[4]), "v"(e.x[8]), "v"(e.x[10]), "v"(e.prev_sh)
-                 : "memory");
-  }
 
   // vehicle / world coefficients: uniform, or this env's own (full-featured build only)
   Coef q = uniform_coef(c);
@@ -139,13 +127,13 @@ __device__ __forceinline__ void step_body(
   store_env<MODE, TILE>(tile, e);
   if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (o.stats) tile.store_ret(e.ep_ret);
+  if (o.ticks) tile.store_ticks(e.ticks);
   if (valid) {
     if (io.reward_dev) CS_NT_STORE((float)out.reward, at32<float>(io.reward_dev, i << 2));
     if (io.terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(io.terminated_dev, i));
     if (io.truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(io.truncated_dev, i));
   }
   write_rows<OBS>(io.obs_dev, lds, lane, env0, n, valid, out.row);
-  if constexpr (PREFETCH) asm volatile("" ::"v"(prefetch_sink));  // the landing register is live up to here
   CS_STAMP(6);
 #ifdef CS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -159,9 +147,9 @@ __device__ __forceinline__ void step_body(
   char *const tiles, const uint32_t n_envs, const float *const actions_dev, float *const obs_dev,         \
       float *const reward_dev, uint8_t *const terminated_dev, uint8_t *const truncated_dev,               \
       const float *const next_actions_dev, const DevConst c, const DevState s_rest, const cs_step_io io_rest
-template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool PREFETCH, bool ONE_CALL>
+template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL>
 __global__ __launch_bounds__(kBlock) void step_kernel(CS_STEP_ARGS) {
-  step_body<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, ONE_CALL>(
+  step_body<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL>(
       tiles, n_envs, actions_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, next_actions_dev, c, s_rest,
       io_rest);
 }
@@ -258,7 +246,10 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
   const bool opt_stats = !LEAN && c.stats;
   e.ep_ret = opt_stats ? tile.load_ret() : 0.f;
+  const bool opt_ticks = !LEAN && c.ticks;
+  e.ticks = opt_ticks ? tile.load_ticks() : 0u;
   StepOpts o;
+  o.ticks = opt_ticks;
   o.stats = opt_stats;
   o.trunc = !LEAN && c.tl_trunc;
   o.done_list = false;
@@ -361,6 +352,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   store_env<MODE, TILE>(tile, e);
   if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
   if (opt_stats) tile.store_ret(e.ep_ret);
+  if (opt_ticks) tile.store_ticks(e.ticks);
   if constexpr (kPid) {
 #pragma unroll
     for (int j = 0; j < NCTL; ++j) {
@@ -397,11 +389,13 @@ __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, co
   }
   double px, py, pz;
   pending_perturbation<MODE>(c, q, tile, i, e.episode, e.pend, e.expl, px, py, pz);
+  uint32_t ticked;
   if (c.gyro) {
-    physics_substeps<FULL, true, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+    ticked = physics_substeps<FULL, true, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
   } else {
-    physics_substeps<FULL, false, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+    ticked = physics_substeps<FULL, false, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
   }
+  if (c.ticks) tile.store_ticks(tile.load_ticks() + ticked);
 #pragma unroll
   for (int k = 0; k < 12; ++k) e.x[k] = round_stored<MODE>(e.x[k]);
   // (meta: only the status and the pending flag change; unpack_env masked reset_pending by the
@@ -420,7 +414,8 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void export_state_kernel(const DevConst c, const DevState s,
                                                               float* __restrict__ x_out,
                                                               uint8_t* __restrict__ status_out,
-                                                              int32_t* __restrict__ steps_out) {
+                                                              int32_t* __restrict__ steps_out,
+                                                              int32_t* __restrict__ ticks_out) {
   const uint32_t tile_index = blockIdx.x;
   const uint32_t i = tile_index * kBlock + threadIdx.x;
   if (i >= s.n) return;
@@ -434,6 +429,7 @@ __global__ __launch_bounds__(kBlock) void export_state_kernel(const DevConst c, 
   }
   if (status_out != nullptr) status_out[i] = (uint8_t)e.fs;
   if (steps_out != nullptr) steps_out[i] = (int32_t)e.steps;
+  if (ticks_out != nullptr) ticks_out[i] = c.ticks ? (int32_t)tile.load_ticks() : -1;
 }
 
 // ---------------------------------------------------------------------------------
@@ -505,6 +501,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     }
     store_env<MODE, TILE>(tile, e);
     tile.store_ret(0.f);
+    if (c.ticks) tile.store_ticks(0u);  // a new Dynamics object (task.py:161)
   }
   if (obs != nullptr) {
 #pragma unroll
@@ -583,6 +580,7 @@ __global__ __launch_bounds__(kBlock) void state_gather_kernel(const DevConst c, 
   }
   if (a.ret) a.ret[i] = (double)tile.load_ret();
   if (a.episode) a.episode[i] = e.episode;
+  if (a.ticks) a.ticks[i] = c.ticks ? (int32_t)tile.load_ticks() : -1;
 }
 
 template <int MODE>
@@ -609,16 +607,23 @@ __global__ __launch_bounds__(kBlock) void state_scatter_kernel(const DevConst c,
     e.pend = (a.flags[i] & 1) != 0;
     e.reset_pending = (a.flags[i] & 2) != 0;
   }
-  if (a.force) {  // an explicitly installed force (Dynamics.perturb)
-    Vec4<T> fe;
-    fe.v[0] = (T)a.force[0 * n + i];
-    fe.v[1] = (T)a.force[1 * n + i];
-    fe.v[2] = (T)a.force[2 * n + i];
-    fe.v[3] = (T)0;
-    tile.store_fe(fe);
-    e.expl = true;
+  if (a.force) {
+    // A force is an EXPLICIT one (Dynamics.perturb; flags bit 2) unless the flags that come with it say it is
+    // the Philox draw that cs_get_state reported: that one is not stored -- it stays a function of (seed, env
+    // id, episode), so a checkpoint round trip set_state(**get_state()) keeps following cs_seed.
+    const bool expl = a.flags ? (a.flags[i] & 4) != 0 : true;
+    if (expl) {
+      Vec4<T> fe;
+      fe.v[0] = (T)a.force[0 * n + i];
+      fe.v[1] = (T)a.force[1 * n + i];
+      fe.v[2] = (T)a.force[2 * n + i];
+      fe.v[3] = (T)0;
+      tile.store_fe(fe);
+    }
+    e.expl = expl;
   }
   if (a.episode) e.episode = a.episode[i];
+  if (a.ticks && c.ticks) tile.store_ticks((uint32_t)a.ticks[i]);
   store_env<MODE, TILE>(tile, e);
   if (a.prev) tile.store_prev((T)a.prev[i]);
   if (a.ret) tile.store_ret((float)a.ret[i]);
@@ -633,6 +638,14 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
+template <class W>
+__device__ __forceinline__ bool word_nonfinite(W w) {  // exponent field all ones: inf or NaN
+  if constexpr (sizeof(W) == 4) {
+    return (w & 0x7F800000u) == 0x7F800000u;
+  } else {
+    return ((w >> 52) & 0x7FFull) == 0x7FFull;
+  }
+}
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevState s, double* __restrict__ out) {
   const uint32_t tile_index = blockIdx.x;
@@ -640,12 +653,19 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevState s,
   using TILE = TileIO<MODE>;
   const TILE tile(s, tile_index, threadIdx.x);
   const bool valid = i < s.n;
-  const typename TILE::Group t2 = tile.load_group(1), r2 = tile.load_group(3);
+  const typename TILE::Group t1 = tile.load_group(0), t2 = tile.load_group(1), r1 = tile.load_group(2),
+                             r2 = tile.load_group(3);
   const uint32_t meta = TILE::int_hi(t2);
   const double steps = valid ? (double)(meta & kMetaStepsMask) : 0.0;
   const double air = valid && (TILE::int_lo(t2) >> kStatusShift) == CS_STATUS_AIRBORNE ? 1.0 : 0.0;
   const double epi = valid ? (double)TILE::int_hi(r2) : 0.0;
   const double ret = valid ? (double)tile.load_ret() : 0.0;
+  // envs with a non-finite state word: upstream lets NaN / inf propagate silently (task.py:133 just casts);
+  // the batch counts them (wave ballot -> one atomic per wavefront)
+  bool bad = word_nonfinite(t2.v[0]) || word_nonfinite(t2.v[1]) || word_nonfinite(r2.v[0]) || word_nonfinite(r2.v[1]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) bad = bad || word_nonfinite(t1.v[k]) || word_nonfinite(r1.v[k]);
+  const double nonfinite = (double)__popcll(__ballot(bad && valid));
   double mx = steps;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
@@ -659,6 +679,7 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevState s,
     atomicMax(reinterpret_cast<unsigned long long*>(out + 3), (unsigned long long)__double_as_longlong(v[3]));
     atomicAdd(out + 4, v[4]);
     atomicAdd(out + 5, v[5]);
+    if (nonfinite != 0.0) atomicAdd(out + 6, nonfinite);
   }
 }
 
@@ -704,7 +725,7 @@ namespace {
 
 bool lean_config(const DevConst& c, const DevState& s) {
   return c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc && s.veh == nullptr && !c.gyro &&
-         !c.act_f32;
+         !c.act_f32 && !c.ticks;
 }
 
 // The headline combinations get every specialised instantiation of the lean kernel; the others one
@@ -720,30 +741,27 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, co
   const bool lean = lean_config(c, s) && io.done_count_dev == nullptr && io.final_obs_dev == nullptr;
   const uint32_t nt_act_max = tune.nt_action_max_envs ? tune.nt_action_max_envs : kNtActionMaxEnvs;
   const uint32_t nt_state_min = tune.nt_state_min_envs ? tune.nt_state_min_envs : kNtStateMinEnvs;
-#define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, ONE_CALL)                                        \
-  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, ONE_CALL>), grid, \
-                     block, 0, stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev,            \
-                     io.terminated_dev, io.truncated_dev, io.next_actions_dev, c, s, io)
-#define CS_STEP_N(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH)       \
-  do {                                                            \
-    if (c.nsub == 1)                                              \
-      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, true);    \
-    else                                                          \
-      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, PREFETCH, false);   \
+#define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL)                                                  \
+  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL>), grid, block, 0, \
+                     stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,   \
+                     io.truncated_dev, io.next_actions_dev, c, s, io)
+#define CS_STEP_N(LEAN, STREAM_ACT, STREAM_STATE)       \
+  do {                                                  \
+    if (c.nsub == 1)                                    \
+      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, true);    \
+    else                                                \
+      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, false);   \
   } while (0)
   if (!lean) {
-    CS_STEP(false, false, false, false, false);
+    CS_STEP(false, false, false, false);
   } else if constexpr (!is_tuned(TASK, MODE)) {
-    CS_STEP(true, false, false, false, false);
+    CS_STEP(true, false, false, false);
   } else if (s.n <= nt_act_max) {  // the state fits the L2s: keep the action stream out of them
-    if (io.next_actions_dev != nullptr)
-      CS_STEP_N(true, true, false, true);
-    else
-      CS_STEP_N(true, true, false, false);
+    CS_STEP_N(true, true, false);
   } else if (s.n >= nt_state_min) {  // the state exceeds the Infinity Cache: stream it past the caches
-    CS_STEP_N(true, false, true, false);
+    CS_STEP_N(true, false, true);
   } else {
-    CS_STEP_N(true, false, false, false);
+    CS_STEP_N(true, false, false);
   }
 #undef CS_STEP_N
 #undef CS_STEP
@@ -841,8 +859,8 @@ hipError_t launch_step_many(int task, int mode, const DevConst& c, const DevStat
 }
 
 hipError_t launch_export_state(int mode, const DevConst& c, const DevState& s, float* x, uint8_t* status,
-                               int32_t* steps, hipStream_t stream) {
-  CS_MODE_LAUNCH(export_state_kernel, c, s, x, status, steps);
+                               int32_t* steps, int32_t* ticks, hipStream_t stream) {
+  CS_MODE_LAUNCH(export_state_kernel, c, s, x, status, steps, ticks);
 }
 
 hipError_t launch_set_motors(int mode, const DevConst& c, const DevState& s, const float* motors,

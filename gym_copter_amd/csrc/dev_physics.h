@@ -172,18 +172,21 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, co
 // `nsub` x Dynamics.setMotors with one wrench.  The pending perturbation can only enter the FIRST
 // call: a call that freezes on ground contact keeps it, but the status it leaves (CRASHED / LEVELING)
 // makes the next call drop it.
+// Returns the calls that ticked (Dynamics._ticks, :197: every call but a ground-contact freeze).
 template <bool FULL, bool GYRO, bool ONE_CALL, bool IN_LOOP = false>
-__device__ __forceinline__ void physics_substeps(const DevConst& c, const Coef& q, const Wrench& w,
-                                                 double (&x)[12], int& fs, bool& pend, double px,
-                                                 double py, double pz) {
+__device__ __forceinline__ uint32_t physics_substeps(const DevConst& c, const Coef& q, const Wrench& w,
+                                                     double (&x)[12], int& fs, bool& pend, double px,
+                                                     double py, double pz) {
   if constexpr (ONE_CALL) {  // upstream's own configuration (substeps = 1): no loop
     const int what = physics_call<FULL, GYRO, IN_LOOP>(c, q, w, x, fs, px, py, pz);
     pend = pend && what == kCallFroze;
-    return;
+    return what == kCallFroze ? 0u : 1u;
   }
+  uint32_t ticked = 0;
 #pragma clang loop unroll(disable)
   for (int sub = 0; sub < c.nsub; ++sub) {
     const int what = physics_call<FULL, GYRO, IN_LOOP>(c, q, w, x, fs, px, py, pz);
+    ticked += what == kCallFroze ? 0u : 1u;
     // a call that froze keeps the perturbation (upstream's early return); it is inert
     // there (dt = 0) and the next call, which cannot integrate either, drops it
     const bool keep = pend && what == kCallFroze;
@@ -192,6 +195,7 @@ __device__ __forceinline__ void physics_substeps(const DevConst& c, const Coef& 
     py = keep ? py : 0.0;
     pz = keep ? pz : 0.0;
   }
+  return ticked;
 }
 
 // Lander shaping potential (lander.py:48-57) on the stored state, in its two parts

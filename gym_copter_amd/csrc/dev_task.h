@@ -58,6 +58,7 @@ struct Env {
   bool expl;           // ... and it is the explicit force of the FE group (else: the Philox draw)
   bool reset_pending;  // NEXT_STEP: finished, resets at the next step
   uint32_t episode;    // episodes started
+  uint32_t ticks;      // Dynamics._ticks of this episode (kept only under cs_config.track_time)
   double prev_sh;
   float ep_ret;
 };
@@ -71,7 +72,7 @@ struct StepOut {
 };
 
 struct StepOpts {  // uniform switches (compiled out in LEAN builds)
-  bool stats, trunc, done_list, same_step, gyro, act_f32;
+  bool stats, trunc, done_list, same_step, gyro, act_f32, ticks;
 };
 
 // the raw groups of one tile <-> Env
@@ -251,11 +252,13 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     pending_perturbation<MODE>(c, q, tile, i, e.episode, e.pend, e.expl, px, py, pz);
     bool gyro = false;
     if constexpr (!LEAN) gyro = o.gyro;
+    uint32_t ticked;
     if (gyro) {
-      physics_substeps<FULL, true, false, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+      ticked = physics_substeps<FULL, true, false, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
     } else {
-      physics_substeps<FULL, false, ONE_CALL, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+      ticked = physics_substeps<FULL, false, ONE_CALL, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
     }
+    if constexpr (!LEAN) e.ticks += ticked;
   }
 
   // ---- round to the stored precision; everything below sees exactly what is stored ----
@@ -322,6 +325,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     e.pend = true;
     e.expl = false;
     e.steps = 1;
+    e.ticks = 0;  // a new Dynamics object (task.py:161)
     e.ep_ret = 0.f;
     e.prev_sh = c.reset_shaping;
   }

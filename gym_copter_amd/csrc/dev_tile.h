@@ -133,12 +133,24 @@ struct TileIO {
   __device__ __forceinline__ void store_prev(T v) const { st(bw, L.ps, v); }
   __device__ __forceinline__ float load_ret() const { return ld<float>(b4, L.ret); }
   __device__ __forceinline__ void store_ret(float v) const { st(b4, L.ret, v); }
-  // FE group: the EXPLICIT pending force [N] (plain accesses: rare)
+  // FE group: the EXPLICIT pending force [N] in its first three words (plain accesses: rare); the fourth
+  // word is the Dynamics tick counter (cs_config.track_time), so a force is stored as three words
   __device__ __forceinline__ Vec4<T> load_fe() const {
     return *reinterpret_cast<const Vec4<T>*>(bg + ((int)L.fe - kBias));
   }
   __device__ __forceinline__ void store_fe(const Vec4<T>& v) const {
-    *reinterpret_cast<Vec4<T>*>(bg + ((int)L.fe - kBias)) = v;
+    T* p = reinterpret_cast<T*>(bg + ((int)L.fe - kBias));
+    p[0] = v.v[0];
+    p[1] = v.v[1];
+    p[2] = v.v[2];
+  }
+  // Dynamics._ticks (dynamics/__init__.py:98, :197): setMotors calls of this episode that did not freeze on
+  // ground contact.  Kept only under cs_config.track_time (full-featured kernels).
+  __device__ __forceinline__ uint32_t load_ticks() const {
+    return *reinterpret_cast<const uint32_t*>(bg + ((int)(L.fe + 3u * L.word) - kBias));
+  }
+  __device__ __forceinline__ void store_ticks(uint32_t t) const {
+    *reinterpret_cast<uint32_t*>(bg + ((int)(L.fe + 3u * L.word) - kBias)) = t;
   }
 
   // the two integer words of a T2 / R2 group

@@ -37,8 +37,13 @@ static PyObject* call_step(PyObject* self, PyObject* const* args, Py_ssize_t nar
     PyErr_SetString(PyExc_ValueError, "step(): null entry point or context");
     return NULL;
   }
-  const int rc = ((cs_step_fn)(uintptr_t)p[0])(p[1], (const float*)p[2], (float*)p[3], (float*)p[4],
-                                               (uint8_t*)p[5], (uint8_t*)p[6], p[7]);
+  /* without the GIL, as ctypes does: hosts that drive distinct contexts from distinct threads (allowed by
+     include/copterstep.h) then enqueue their launches concurrently */
+  int rc;
+  Py_BEGIN_ALLOW_THREADS
+  rc = ((cs_step_fn)(uintptr_t)p[0])(p[1], (const float*)p[2], (float*)p[3], (float*)p[4], (uint8_t*)p[5],
+                                     (uint8_t*)p[6], p[7]);
+  Py_END_ALLOW_THREADS
   return PyLong_FromLong(rc);
 }
 

@@ -218,7 +218,16 @@ class HalfBatchPipeline:
     def reset(self, seed=None, options=None):
         """-> ([obs half 0, obs half 1], {}); `options` is one dict per half (or None)."""
         options = options or (None, None)
+        if self._streams is not None:
+            # a step_async(h) that was never wait()ed for may still be running on its side stream: the
+            # reset kernels, enqueued on the caller's stream, touch the same tiles and output buffers
+            import torch
+            cur = torch.cuda.current_stream(self._dev)
+            for h in (0, 1):
+                if self._out[h] is not None:
+                    cur.wait_event(self._events[h])
         obs = [self.halves[h].reset(seed=seed, options=options[h])[0] for h in (0, 1)]
+        self._out = [None, None]
         return obs, {}
 
     def step_async(self, half, actions):

@@ -70,7 +70,7 @@ class CopterVecEnv:
                  time_limit_truncates=False, episode_stats=False, env_id_base=0,
                  max_steps=1000, vehicle_params=None, frames_per_second=None,
                  action_arith="float64", thrust_model="B", rotor_gyro=False, world_params=None,
-                 **task_kwargs):
+                 track_time=False, **task_kwargs):
         lib = _lib.load()
         torch = _torch()
         if task not in _TASKS:
@@ -115,6 +115,7 @@ class CopterVecEnv:
         cfg.action_arith = _ARITH[action_arith]
         cfg.thrust_model = _THRUST[thrust_model]
         cfg.rotor_gyro = int(bool(rotor_gyro))
+        cfg.track_time = int(bool(track_time))      # Dynamics._ticks / getTime(), dynamics/__init__.py:197, :219-221
         for k, v in task_kwargs.items():
             if k not in _TASK_KEYS:
                 raise TypeError("unexpected keyword argument %r" % k)
@@ -124,6 +125,7 @@ class CopterVecEnv:
         self.num_envs = int(num_envs)
         self.autoreset_mode = autoreset_mode
         self.episode_stats = bool(episode_stats)
+        self.track_time = bool(track_time)
         self.device = torch.device("cuda", int(device))
         first, self.obs_dim, self.action_dim = _TASK_SHAPES[self.task]
         self.STATE_NAMES = STATE_NAMES_12[first:first + self.obs_dim]   # lander.py:30-31
@@ -226,6 +228,7 @@ class CopterVecEnv:
     def set_altitude(self, altitude):                           # task.py:67-69
         self._check_open()
         _lib.check(self._lib.cs_set_altitude(self._ctx, float(altitude)))
+        self.config.initial_altitude = float(altitude)     # reset(options={'perturb': False}) starts from it
 
     def reset(self, seed=None, options=None):
         """Reset every env (or options['mask']); returns (obs[N,obs_dim], {}).
@@ -300,8 +303,7 @@ class CopterVecEnv:
                 _lib.check(rc)
             self._keep = a
             if was_numpy:
-                return (self._obs.cpu().numpy(), self._reward.cpu().numpy(), self._term_b.cpu().numpy(),
-                        self._trunc_b.cpu().numpy(), {})
+                return self._outputs_to_numpy() + ({},)
             return self._obs, self._reward, self._term_b, self._trunc_b, {}
         with torch.cuda.device(self.device):
             if self._final_obs is None and self._done is None:
@@ -333,9 +335,29 @@ class CopterVecEnv:
             infos["episode"] = self._done
         term, trunc = self._term_b, self._trunc_b
         if was_numpy:
-            return (self._obs.cpu().numpy(), self._reward.cpu().numpy(), term.cpu().numpy(),
-                    trunc.cpu().numpy(), {k: _to_numpy(v) for k, v in infos.items()})
+            return self._outputs_to_numpy() + ({k: _to_numpy(v) for k, v in infos.items()},)
         return self._obs, self._reward, term, trunc, infos
+
+    def _outputs_to_numpy(self):
+        """The NumPy convenience path: obs, reward and both flags cross PCIe as ONE device-to-host copy of a
+        packed byte buffer (one device-side gather into it, one blocking copy) instead of four."""
+        torch = _torch()
+        n, od = self.num_envs, self.obs_dim
+        pk = getattr(self, "_pack", None)
+        if pk is None:
+            o_r, o_t = n * od * 4, n * od * 4 + n * 4
+            dev = torch.empty(o_t + 2 * n, dtype=torch.uint8, device=self.device)
+            host = torch.empty(o_t + 2 * n, dtype=torch.uint8).pin_memory()
+            pk = self._pack = (dev, host, o_r, o_t)
+        dev, host, o_r, o_t = pk
+        dev[:o_r].view(torch.float32).view(n, od).copy_(self._obs)
+        dev[o_r:o_t].view(torch.float32).copy_(self._reward)
+        dev[o_t:o_t + n].copy_(self._term)
+        dev[o_t + n:].copy_(self._trunc)
+        host.copy_(dev)                                   # the one blocking D2H
+        h = host.numpy()
+        return (h[:o_r].view(np.float32).reshape(n, od).copy(), h[o_r:o_t].view(np.float32).copy(),
+                h[o_t:o_t + n].astype(bool), h[o_t + n:].astype(bool))
 
     def step_prefetch(self, actions, next_actions):
         """step(actions) for open-loop callers that already hold the NEXT action batch as a device
@@ -539,42 +561,58 @@ class CopterVecEnv:
     def state_tensors(self):
         """Dynamics.getState() / getStatus() for the batch as DEVICE tensors, asynchronous on the
         current stream: {'x': float32 [12, N] (upstream slot order, incl. psi / dpsi), 'status':
-        uint8 [N], 'steps': int32 [N]}.  The tensors are persistent buffers of this env."""
+        uint8 [N], 'steps': int32 [N], 'ticks': int32 [N] (Dynamics._ticks; -1 without track_time)}.  The
+        tensors are persistent buffers of this env."""
         self._check_open()
         torch = _torch()
         if getattr(self, "_state_t", None) is None:
             n = self.num_envs
             self._state_t = {"x": torch.empty((12, n), dtype=torch.float32, device=self.device),
                              "status": torch.empty(n, dtype=torch.uint8, device=self.device),
-                             "steps": torch.empty(n, dtype=torch.int32, device=self.device)}
+                             "steps": torch.empty(n, dtype=torch.int32, device=self.device),
+                             "ticks": torch.empty(n, dtype=torch.int32, device=self.device)}
         t = self._state_t
         with torch.cuda.device(self.device):
             _lib.check(self._lib.cs_export_state(self._ctx, C.c_void_p(t["x"].data_ptr()),
                                                  C.c_void_p(t["status"].data_ptr()),
-                                                 C.c_void_p(t["steps"].data_ptr()), self._stream()))
+                                                 C.c_void_p(t["steps"].data_ptr()),
+                                                 C.c_void_p(t["ticks"].data_ptr()), self._stream()))
         return t
+
+    def get_time(self):
+        """Dynamics.getTime() (dynamics/__init__.py:219-221) for the batch: ticks * dt as a float64 device
+        tensor [N]; needs track_time=True."""
+        if not self.track_time:
+            raise RuntimeError("get_time() needs CopterVecEnv(track_time=True)")
+        dt = 1.0 / (float(self.config.frames_per_second) * int(self.config.substeps))
+        return self.state_tensors()["ticks"].double() * dt
 
     def get_state(self):
         """Whole-batch state as NumPy (synchronises): dict with x[12,N] f64, status, steps,
         prev_shaping (NaN = None), force[3,N] newtons (this episode's reset perturbation: an installed one, or
         the Philox draw of (seed, global env id, episode - 1)), flags (bit 0 perturbation pending, bit 1 reset
-        pending, bit 2 the perturbation was installed explicitly), episode, (episode_return)."""
+        pending, bit 2 the perturbation was installed explicitly), episode, (episode_return), (ticks).
+        set_state(**get_state()) is a faithful restore: a `force` that comes with `flags` is installed only
+        where bit 2 says it was explicit; the other envs stay on their Philox draw."""
         self._check_open()
         n = self.num_envs
         out = {"x": np.empty((12, n)), "status": np.empty(n, np.uint8), "steps": np.empty(n, np.int32),
                "prev_shaping": np.empty(n), "force": np.empty((3, n)), "flags": np.empty(n, np.uint8),
                "episode": np.empty(n, np.uint32)}
         er = np.empty(n) if self.episode_stats else None
+        tk = np.empty(n, np.int32) if self.track_time else None
         p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         _lib.check(self._lib.cs_get_state(self._ctx, p(out["x"]), p(out["status"]), p(out["steps"]),
                                           p(out["prev_shaping"]), p(out["force"]), p(out["flags"]),
-                                          p(er), p(out["episode"]), self._stream()))
+                                          p(er), p(out["episode"]), p(tk), self._stream()))
         if er is not None:
             out["episode_return"] = er
+        if tk is not None:
+            out["ticks"] = tk
         return out
 
     def set_state(self, x=None, status=None, steps=None, prev_shaping=None, force=None, flags=None,
-                  episode_return=None, episode=None):
+                  episode_return=None, episode=None, ticks=None):
         self._check_open()
         n = self.num_envs
 
@@ -588,7 +626,7 @@ class CopterVecEnv:
         arrs = [prep(x, (12, n), np.float64), prep(status, (n,), np.uint8), prep(steps, (n,), np.int32),
                 prep(prev_shaping, (n,), np.float64), prep(force, (3, n), np.float64),
                 prep(flags, (n,), np.uint8), prep(episode_return, (n,), np.float64),
-                prep(episode, (n,), np.uint32)]
+                prep(episode, (n,), np.uint32), prep(ticks, (n,), np.int32)]
         ptrs = [None if a is None else a.ctypes.data_as(C.c_void_p) for a in arrs]
         _lib.check(self._lib.cs_set_state(self._ctx, *ptrs, self._stream()))
 
@@ -599,6 +637,15 @@ class CopterVecEnv:
         (applied twice in that call, as upstream does).  One kernel launch on the current stream."""
         self._check_open()
         torch = _torch()
+        if self.config.state_mode == _lib.STATE_F64 and mask is None and not isinstance(force_xyz, torch.Tensor):
+            # float64 state words: keep the force in float64 (upstream's force / M is float64); the device
+            # entry point takes float32 rows, the host one float64
+            f64 = np.ascontiguousarray(np.asarray(force_xyz, dtype=np.float64))
+            if f64.shape != (3, self.num_envs):
+                raise ValueError("force_xyz must have shape (3, %d)" % self.num_envs)
+            flags = self.get_state()["flags"]
+            self.set_state(force=f64, flags=(flags | 1 | 4).astype(np.uint8))
+            return
         f, _ = self._dev_f32(force_xyz, (3, self.num_envs), "force_xyz")
         mask_t, mask_p = None, None
         if mask is not None:
@@ -613,12 +660,13 @@ class CopterVecEnv:
 
     perturb = set_perturbation
 
-    STATS_NAMES = ("envs", "airborne", "steps_sum", "steps_max", "episodes_started", "return_sum")
+    STATS_NAMES = ("envs", "airborne", "steps_sum", "steps_max", "episodes_started", "return_sum", "nonfinite")
 
     def batch_stats(self):
-        """Batch bookkeeping reduced on the device (cs_episode_stats): a float64 tensor [6] =
+        """Batch bookkeeping reduced on the device (cs_episode_stats): a float64 tensor [7] =
         (envs, envs airborne, sum and max of the episode step counters, episodes started, sum of the
-        running episode returns), asynchronous on the current stream."""
+        running episode returns, envs with a NaN / inf state word -- the guard counter for what upstream
+        lets propagate silently, task.py:133), asynchronous on the current stream."""
         self._check_open()
         torch = _torch()
         if getattr(self, "_stats_t", None) is None:

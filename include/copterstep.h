@@ -58,7 +58,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 2
+#define CS_ABI_VERSION 3
 
 typedef enum cs_status {
   CS_OK = 0,
@@ -149,7 +149,10 @@ typedef struct cs_config {
   int32_t thrust_model;     /* CS_THRUST_* */
   int32_t rotor_gyro;       /* 0 = upstream's Omega = 0 (dynamics/__init__.py:135); 1 = the retired Mars
                                model's Omega = u4(omegas) in the Jr terms (attic/mars/dynamics/__init__.py:143) */
-  int32_t reserved_;
+  int32_t track_time;       /* 1 = keep Dynamics._ticks per env (dynamics/__init__.py:98, :197: the setMotors calls of
+                               the episode that did not freeze on ground contact; Dynamics.getTime() = ticks * dt,
+                               :219-221) and report it through cs_export_state / cs_get_state.  Selects the
+                               full-featured step kernel (4 more bytes read and written per env-step). */
   double rho, C_L;          /* air density [kg/m^3] and lift coefficient of CS_THRUST_LIFT
                                (attic/mars/dynamics/__init__.py:84-88, ingenuity.py:55,72-73) */
 } cs_config;
@@ -174,8 +177,8 @@ typedef struct cs_step_io {
   int32_t* done_length_dev;  /* [N] */
   /* Optional hint for open-loop workloads (recorded / pre-generated action batches, the "resident
      ring" of the benchmark): the action batch the NEXT step will be given, [N,A] like actions_dev.
-     The kernel only touches its cache lines so that they are near the compute units when the next
-     launch asks for them; nothing is computed from it and results do not depend on it. */
+     Nothing is computed from it and results do not depend on it.  Accepted and IGNORED since ABI 3: the
+     kernel-side touch of those rows measured +3.5 % per step on MI355X. */
   const float* next_actions_dev;
 } cs_step_io;
 
@@ -296,8 +299,10 @@ int cs_set_perturbation(cs_ctx* ctx, const uint8_t* mask_dev, const float* force
 
 /* Running statistics of the batch as CS_EPISODE_STATS float64 values on the DEVICE (enqueue only):
  * [0] envs, [1] envs AIRBORNE, [2] sum and [3] max of the episode step counters, [4] episodes started
- * (sum over envs), [5] sum of the running episode returns (0 without cfg.episode_stats). */
-enum { CS_EPISODE_STATS = 6 };
+ * (sum over envs), [5] sum of the running episode returns (0 without cfg.episode_stats), [6] envs with a
+ * non-finite (NaN / inf) state word -- upstream raises nothing on the path and lets them propagate
+ * (task.py:133 only casts); this is the batch's guard counter for them. */
+enum { CS_EPISODE_STATS = 7 };
 int cs_episode_stats(cs_ctx* ctx, double* stats_dev, void* stream);
 
 /* Launcher thresholds that depend on the batch size (0 = built-in default).  They select between
@@ -330,30 +335,37 @@ int cs_allgather(cs_comm* comm, const void* send_dev, void* recv_dev, int64_t by
  * values (no clipping, no task logic). */
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream);
 
-/* Dynamics.getState() / getStatus() (dynamics/__init__.py:199-207, :223-225) for the batch, on the
- * DEVICE and asynchronous (enqueue only, graph-capturable): x_dev [12,N] float32 struct-of-arrays in
+/* Dynamics.getState() / getStatus() / getTime() (dynamics/__init__.py:199-207, :219-225) for the batch, on
+ * the DEVICE and asynchronous (enqueue only, graph-capturable): x_dev [12,N] float32 struct-of-arrays in
  * upstream slot order (the full state, incl. psi / dpsi, which the Lander observation omits),
- * status_dev [N] (CS_STATUS_*), steps_dev [N].  Each pointer may be NULL. */
-int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, void* stream);
+ * status_dev [N] (CS_STATUS_*), steps_dev [N] (the task's step counter), ticks_dev [N] (Dynamics._ticks;
+ * getTime() = ticks * dt; -1 without cfg.track_time).  Each pointer may be NULL. */
+int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, int32_t* ticks_dev,
+                    void* stream);
 
 /* Whole-batch state exchange with HOST buffers (parity tests, checkpoint/restore): a kernel (de)tiles
  * the state into / from struct-of-arrays staging buffers on the device, and only the arrays asked for
  * cross PCIe.
  * Any pointer may be NULL.  x_host is [12,N] float64 struct-of-arrays in upstream slot
  * order (x,dx,y,dy,z,dz,phi,dphi,theta,dtheta,psi,dpsi); force_xyz_host is [3,N] newtons;
- * flags_host bit0 = perturbation pending, bit1 = reset pending (NEXT_STEP), bit2 (get only) = the
+ * flags_host bit0 = perturbation pending, bit1 = reset pending (NEXT_STEP), bit2 = the
  * episode's perturbation is an explicitly installed force rather than the Philox draw of
- * (seed, global env id, episode - 1); force_xyz_host reports that force either way, and
- * cs_set_state(force_xyz_host) installs an explicit one;
+ * (seed, global env id, episode - 1); force_xyz_host reports that force either way.
+ * cs_set_state(force_xyz_host) WITHOUT flags_host installs an explicit force for every env; WITH
+ * flags_host it installs one only where bit2 is set and leaves the other envs on their Philox draw,
+ * so that cs_set_state(everything cs_get_state returned) is a faithful restore (pending draws keep
+ * following cs_seed);
  * prev_shaping NaN = upstream's None; episode_host [N] = episodes started so far per env
- * (the Philox counter word of the next reset draw). */
+ * (the Philox counter word of the next reset draw); ticks_host [N] = Dynamics._ticks
+ * (cfg.track_time; -1 / ignored without it). */
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
-                 double* episode_return_host, uint32_t* episode_host, void* stream);
+                 double* episode_return_host, uint32_t* episode_host, int32_t* ticks_host, void* stream);
 int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
                  const int32_t* steps_host, const double* prev_shaping_host,
                  const double* force_xyz_host, const uint8_t* flags_host,
-                 const double* episode_return_host, const uint32_t* episode_host, void* stream);
+                 const double* episode_return_host, const uint32_t* episode_host,
+                 const int32_t* ticks_host, void* stream);
 
 #ifdef __cplusplus
 }

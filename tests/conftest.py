@@ -25,8 +25,8 @@ def pytest_sessionstart(session):
     host = os.path.join(ROOT, "tests", "host", "abi_host")
     hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
     if (not os.path.exists(lib) or not os.path.exists(host)) and hipcc:
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gym_copter_amd", "csrc"), "all"],
-                              stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "gym_copter_amd", "csrc"), "all",
+                               "PYTHON=" + sys.executable], stdout=subprocess.DEVNULL)
 
 
 class Cases:

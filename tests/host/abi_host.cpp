@@ -126,7 +126,7 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> status(n);
   std::vector<int32_t> steps(n);
   OK(cs_get_state(ctx, nullptr, status.data(), steps.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
-                  stream));
+                  nullptr, stream));
   for (int64_t i = 0; i < n; ++i) CHECK(status[i] == CS_STATUS_CRASHED && steps[i] == done_at + 1);
 
   // ---- K steps in one launch == what the single steps did ----
@@ -181,6 +181,7 @@ int main(int argc, char** argv) {
     // after reset + one step: every env airborne, step counter 2, four episodes started so far (four cs_reset calls)
     CHECK(h_stats[0] == (double)n && h_stats[1] == (double)n && h_stats[2] == 2.0 * n && h_stats[3] == 2.0);
     CHECK(h_stats[4] == 4.0 * n && h_stats[5] == 0.0);
+    CHECK(h_stats[6] == 0.0);  // no env holds a NaN / inf state word
     HIP(hipFree(stats));
   }
 

@@ -16,7 +16,7 @@ Tuning default_tuning() { return Tuning{98304u, 3670016u, 65536u}; }
 hipError_t launch_step(int, int, const DevConst&, const DevState&, const cs_step_io&, const Tuning&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_step_many(int, int, const DevConst&, const DevState&, int, float*, float*, float*, uint8_t*, uint8_t*, int,
                             const PidConst*, double*, uint32_t, const Tuning&, hipStream_t) { return hipErrorUnknown; }
-hipError_t launch_export_state(int, const DevConst&, const DevState&, float*, uint8_t*, int32_t*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_export_state(int, const DevConst&, const DevState&, float*, uint8_t*, int32_t*, int32_t*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_set_motors(int, const DevConst&, const DevState&, const float*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_reset(int, int, const DevConst&, const DevState&, const uint8_t*, const float*, float*, double*, uint32_t,
                         const float*, int, hipStream_t) { return hipErrorUnknown; }
@@ -95,11 +95,12 @@ int main() {
 
   // ---- the staging plan of cs_get_state / cs_set_state: requested arrays only, 256-byte aligned, disjoint ----
   {
-    const bool want[8] = {true, false, true, true, false, true, false, true};
+    const bool want[Staging::kArrays] = {true, false, true, true, false, true, false, true, true};
     const Staging st(1000, want);
     REQUIRE(st.off[0] == 0 && st.size[0] == 96000 && st.off[2] == 96000 && st.off[3] == 96000 + 4096);
     REQUIRE(st.bytes % 256 == 0 && st.at<double>(1) == nullptr && st.arrays().status == nullptr);
-    const bool none[8] = {false, false, false, false, false, false, false, false};
+    REQUIRE(st.arrays().ticks != nullptr && st.size[8] == 4000 && st.off[8] + 4096 == st.bytes);
+    const bool none[Staging::kArrays] = {};
     REQUIRE(Staging(5, none).bytes == 0);
   }
 

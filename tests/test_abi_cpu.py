@@ -71,7 +71,7 @@ def test_argument_errors_without_touching_a_device():
     assert lib.cs_rollout_random(None, 4, None, None, None, None, None, None) == -1
     assert lib.cs_reset(None, None, None, None, None) == -1
     assert lib.cs_reset_pose(None, None, None, 1, None, None, None) == -1
-    assert lib.cs_export_state(None, None, None, None, None) == -1
+    assert lib.cs_export_state(None, None, None, None, None, None) == -1
     assert lib.cs_set_vehicle_params(None, None) == -1
     assert lib.cs_pid_configure(None, None) == -1
     assert lib.cs_last_error().decode() != ""
