@@ -162,6 +162,7 @@ class VecOracle:
         self.done_pending = np.zeros(n, dtype=bool)       # NEXT_STEP: reset on next step
         self.ep_return = np.zeros(n)
         self.ep_length = np.zeros(n, dtype=np.int32)
+        self.ticks = np.zeros(n, dtype=np.int32)          # Dynamics._ticks (dynamics/__init__.py:98, :197)
 
     # ------------------------------------------------------------------ physics
     def _physics(self, x, status, pend, k, motors, active):
@@ -244,8 +245,9 @@ class VecOracle:
         st[leveling] = LANDED
         st[contact] = np.where(hard[contact], CRASHED, LEVELING)
         status[:] = st
-        # perturbation is consumed by every call that does not freeze on contact
+        # perturbation is consumed, and the clock ticks, in every call that does not freeze on contact
         pend[active & ~contact] = False
+        self.ticks[active & ~contact] += 1
 
     # ------------------------------------------------------------------ reset
     def _reset_lanes(self, m, forces=None, poses=None, perturb=True):
@@ -281,6 +283,7 @@ class VecOracle:
         else:
             self.prev_shaping[m] = np.nan
         self.steps[m] = 1
+        self.ticks[m] = 0                                  # a new Dynamics object (task.py:161)
         self.ep_return[m] = 0
         self.ep_length[m] = 0
 

@@ -32,7 +32,8 @@ def make_pair(task="lander3d", n=1, mode="float32", autoreset="disabled", subste
                                       episode_stats=episode_stats, **task_kwargs)
     # (model switches of the device env that the task-parameter record of the oracle does not hold)
     tp = TaskParams(**{k: v for k, v in task_kwargs.items()
-                       if k not in ("action_arith", "thrust_model", "rotor_gyro", "vehicle_params", "world_params")})
+                       if k not in ("action_arith", "thrust_model", "rotor_gyro", "vehicle_params", "world_params",
+                                    "track_time")})
     orc = VecOracle(task, n, tp, substeps=substeps, store_mode=mode, autoreset=AUTORESET[autoreset],
                     seed=seed, env_id_base=env_id_base, time_limit_truncates=time_limit_truncates)
     return env, orc

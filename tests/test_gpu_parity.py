@@ -110,7 +110,7 @@ def test_golden_dynamics_traces(fps, mode):
         x0[:, i] = g["x0"]
         status0[i] = g["status0"]
         force[:, i] = g["force"][:3]
-        flags[i] = 1 if np.any(g["force"]) else 0
+        flags[i] = 5 if np.any(g["force"]) else 0      # pending (bit 0) + explicitly installed (bit 2)
         motors[:len(g["motors"]), i] = g["motors"]
     env.set_state(x=x0, status=status0, force=force, flags=flags, steps=np.ones(n, np.int32))
     tol = 1e-9 if mode == "float64" else BAR
@@ -161,7 +161,7 @@ def test_single_step_random_states(task, mode):
     orc.pending[:] = flags.astype(bool)
     env.set_state(x=orc.x.astype(np.float64), status=status, steps=steps,
                   prev_shaping=orc.prev_shaping.astype(np.float64),
-                  force=orc.force.astype(np.float64), flags=flags)
+                  force=orc.force.astype(np.float64), flags=flags | 4)   # bit 2: install the given forces
     st = env.get_state()
     assert np.array_equal(st["x"], orc.x.astype(np.float64))      # set/get round trip is exact
     assert np.array_equal(np.isnan(st["prev_shaping"]), np.isnan(prev))

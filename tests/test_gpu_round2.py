@@ -159,7 +159,7 @@ def test_golden_mars_dynamics_as_one_batch(mode):
     x0 = np.stack([MARS[c]["x0"] for c in cs], axis=1)
     status0 = np.array([int(MARS[c]["status0"]) for c in cs], np.uint8)
     force = np.stack([MARS[c]["force"][:3] for c in cs], axis=1)
-    flags = np.array([1 if np.any(MARS[c]["force"]) else 0 for c in cs], np.uint8)
+    flags = np.array([5 if np.any(MARS[c]["force"]) else 0 for c in cs], np.uint8)   # pending + explicit
     env.set_state(x=x0, status=status0, force=force, flags=flags, steps=np.ones(n, np.int32))
     motors = np.zeros((T, n, 4), dtype=np.float32)
     for i, c in enumerate(cs):

@@ -105,6 +105,7 @@ def test_vec_dynamics_traces_bit_exact_in_batch(fps):
             if t < len(g["status"]):
                 assert np.array_equal(o.x[:, i], g["x"][t]), (c, t)
                 assert o.status[i] == g["status"][t], (c, t)
+                assert o.ticks[i] == g["ticks"][t], (c, t)      # Dynamics._ticks: a contact freeze does not tick
 
 
 def test_substeps_match_fps1000_trace():
