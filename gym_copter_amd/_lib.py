@@ -79,6 +79,15 @@ class Tuning(C.Structure):
                 ("nt_state_min_envs", C.c_uint32), ("direct_rows_max_envs", C.c_uint32)]
 
 
+class ServeView(C.Structure):
+    """cs_serve_view (include/copterstep.h): the wire description of a served session."""
+    _fields_ = [("act_ring", C.c_void_p), ("out_ring", C.c_void_p), ("out_init", C.c_void_p),
+                ("ctrl", C.c_void_p), ("spin_limit", C.c_uint64), ("tiles", C.c_uint32), ("ring", C.c_uint32),
+                ("act_pieces", C.c_uint32), ("out_pieces", C.c_uint32), ("obs_dim", C.c_uint32),
+                ("act_dim", C.c_uint32), ("num_envs", C.c_uint32), ("num_steps", C.c_uint32)]
+
+
+ERR_TIMEOUT = -6
 PID_LANDER, PID_HOVER = 0, 1
 PID_ROWS = 24          # 6 controllers x {errorI, lastError, deltaError1, deltaError2}
 
@@ -116,6 +125,13 @@ SYMBOLS = {
     "cs_pid_set_state": (C.c_int, [_P, _P, _P]),
     "cs_rollout_pid": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_rollout_random": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "cs_serve_max_envs": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "cs_serve_begin": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, C.POINTER(ServeView)]),
+    "cs_serve_submit": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "cs_serve_collect": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "cs_serve_policy_pid": (C.c_int, [_P, C.c_int32, _P]),
+    "cs_serve_end": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
+    "cs_serve_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cs_get_state": (C.c_int, [_P] + [_P] * 9 + [_P]),
     "cs_set_state": (C.c_int, [_P] + [_P] * 9 + [_P]),
 }

@@ -29,6 +29,15 @@ struct cs_ctx {
   // the per-launch constants, derived from cfg once and again after cs_seed / cs_set_altitude
   cs::DevConst dc;
   bool dc_valid = false;
+  // served stepping: the stream the persistent env kernel runs on, the fork / join events, ONE allocation
+  // holding [control words | action ring | output ring | initial rows], and the session's description
+  hipStream_t serve_stream = nullptr;
+  hipEvent_t serve_fork = nullptr, serve_join = nullptr;
+  char* serve_mem = nullptr;
+  size_t serve_bytes = 0;
+  cs_serve_view serve{};
+  bool serve_active = false;
+  int64_t serve_cap[4] = {0, 0, 0, 0};  // cs_serve_max_envs by kernel variant (queried once: begin may be captured)
 };
 
 namespace {
@@ -379,6 +388,13 @@ int cs_destroy(cs_ctx* ctx) {
   if (ctx->st.tiles) (void)hipFree(ctx->st.tiles);
   if (ctx->pid_state) (void)hipFree(ctx->pid_state);
   if (ctx->veh) (void)hipFree(ctx->veh);
+  if (ctx->serve_stream) {
+    (void)hipStreamSynchronize(ctx->serve_stream);
+    (void)hipStreamDestroy(ctx->serve_stream);
+  }
+  if (ctx->serve_fork) (void)hipEventDestroy(ctx->serve_fork);
+  if (ctx->serve_join) (void)hipEventDestroy(ctx->serve_join);
+  if (ctx->serve_mem) (void)hipFree(ctx->serve_mem);
   delete ctx;
   return CS_OK;
 }
@@ -717,6 +733,179 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out) {
   out->direct_rows_max_envs =
       ctx->tune.direct_rows_max_envs ? ctx->tune.direct_rows_max_envs : d.direct_rows_max_envs;
   return CS_OK;
+}
+
+
+// ---- served stepping: one persistent env kernel per session (copterstep_serve.hip) ---------------------
+namespace {
+
+bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+int serve_read_ctrl(cs_ctx* ctx, uint32_t (&w)[CS_SERVE_CTRL_WORDS]) {
+  CS_HIP(hipMemcpy(w, ctx->serve.ctrl, sizeof w, hipMemcpyDeviceToHost));
+  return CS_OK;
+}
+
+}  // namespace
+
+int cs_serve_max_envs(const cs_ctx* cctx, int64_t* out) {
+  cs_ctx* ctx = const_cast<cs_ctx*>(cctx);
+  if (check_ctx(ctx) || out == nullptr) return fail(CS_ERR_ARG, "cs_serve_max_envs: null argument");
+  const cs::DevConst& c = constants(ctx);
+  const int variant = (c.nsub == 1 ? 1 : 0) | (ctx->st.veh != nullptr ? 2 : 0);
+  if (ctx->serve_cap[variant] == 0) {
+    DeviceGuard guard(ctx->cfg.device);
+    int per_cu = 0, cus = 0;
+    hipError_t e = cs::serve_occupancy(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, &per_cu);
+    if (e != hipSuccess) return hip_fail(e, "cs_serve_max_envs: occupancy query");
+    CS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->cfg.device));
+    // every env wavefront must be resident for the whole session, next to the caller's own kernels: half of
+    // what the device admits (and at most 16 wavefronts per compute unit) is handed out
+    if (per_cu > 32) per_cu = 32;
+    ctx->serve_cap[variant] = (int64_t)(per_cu / 2) * cus * cs::kTileEnvs;
+  }
+  *out = ctx->serve_cap[variant];
+  return CS_OK;
+}
+
+int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_s, void* stream_,
+                   cs_serve_view* view_out) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_begin: a session is already open (cs_serve_end first)");
+  if (num_steps < 1) return fail(CS_ERR_ARG, "cs_serve_begin: num_steps must be >= 1");
+  if (ring == 0) ring = 4;
+  if (ring < 2 || ring > 64 || (ring & (ring - 1)) != 0)
+    return fail(CS_ERR_ARG, "cs_serve_begin: ring must be a power of two in [2, 64]");
+  int64_t max_envs = 0;
+  if (int rc = cs_serve_max_envs(ctx, &max_envs)) return rc;
+  if (ctx->cfg.num_envs > max_envs)
+    return fail(CS_ERR_ARG, "cs_serve_begin: served stepping keeps every tile's wavefront resident: at most " +
+                                std::to_string(max_envs) + " envs per context on this device");
+  DeviceGuard guard(ctx->cfg.device);
+  const uint32_t tiles = (ctx->st.n + 63u) / 64u;
+  const uint32_t od = (uint32_t)cs::task_obs_dim(ctx->cfg.task), ad = (uint32_t)cs::task_act_dim(ctx->cfg.task);
+  const uint32_t ap = (ad + 1u) / 2u, op = (od + 2u) / 2u;
+  const size_t ctrl_bytes = 256, act_bytes = (size_t)ring * tiles * ap * 1024, out_bytes = (size_t)ring * tiles * op * 1024,
+               init_bytes = (size_t)tiles * op * 1024, total = ctrl_bytes + act_bytes + out_bytes + init_bytes;
+  if (out_bytes > 0xFFFFFFFFull) return fail(CS_ERR_ARG, "cs_serve_begin: ring too deep for this batch");
+  const bool cap = capturing(stream);
+  if (ctx->serve_stream == nullptr || ctx->serve_bytes < total) {
+    if (cap)
+      return fail(CS_ERR_ARG, "cs_serve_begin: the first session of this size allocates; run one outside stream capture");
+    if (ctx->serve_stream == nullptr) {
+      CS_HIP(hipStreamCreateWithFlags(&ctx->serve_stream, hipStreamNonBlocking));
+      CS_HIP(hipEventCreateWithFlags(&ctx->serve_fork, hipEventDisableTiming));
+      CS_HIP(hipEventCreateWithFlags(&ctx->serve_join, hipEventDisableTiming));
+    }
+    if (ctx->serve_bytes < total) {
+      CS_HIP(hipStreamSynchronize(ctx->serve_stream));
+      if (ctx->serve_mem) (void)hipFree(ctx->serve_mem);
+      ctx->serve_mem = nullptr;
+      ctx->serve_bytes = 0;
+      if (hipMalloc((void**)&ctx->serve_mem, total) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(CS_ERR_MEMORY, "cs_serve_begin: device allocation failed");
+      }
+      ctx->serve_bytes = total;
+    }
+  }
+  cs_serve_view& v = ctx->serve;
+  v.ctrl = reinterpret_cast<uint32_t*>(ctx->serve_mem);
+  v.act_ring = ctx->serve_mem + ctrl_bytes;
+  v.out_ring = ctx->serve_mem + ctrl_bytes + act_bytes;
+  v.out_init = ctx->serve_mem + ctrl_bytes + act_bytes + out_bytes;
+  v.spin_limit = (uint64_t)((timeout_s > 0.0 ? timeout_s : 2.0) * 1e8);  // s_memrealtime: 100 MHz
+  v.tiles = tiles;
+  v.ring = (uint32_t)ring;
+  v.act_pieces = ap;
+  v.out_pieces = op;
+  v.obs_dim = od;
+  v.act_dim = ad;
+  v.num_envs = ctx->st.n;
+  v.num_steps = (uint32_t)num_steps;
+  // every polled word (tags, control) is zeroed per session: tags are session-relative, so a replayed
+  // hipGraph of a whole session starts from clean rings
+  CS_HIP(hipMemsetAsync(ctx->serve_mem, 0, total, stream));
+  CS_HIP(hipEventRecord(ctx->serve_fork, stream));
+  CS_HIP(hipStreamWaitEvent(ctx->serve_stream, ctx->serve_fork, 0));
+  hipError_t e = cs::launch_serve(ctx->cfg.task, ctx->cfg.state_mode, constants(ctx), ctx->st, v, ctx->serve_stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_serve_begin: kernel launch");
+  ctx->serve_active = true;
+  if (view_out != nullptr) *view_out = v;
+  return CS_OK;
+}
+
+int cs_serve_submit(cs_ctx* ctx, int32_t step, const float* actions_dev, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (!ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_submit: no open session");
+  if (actions_dev == nullptr || step < 0 || (uint32_t)step >= ctx->serve.num_steps)
+    return fail(CS_ERR_ARG, "cs_serve_submit: actions_dev is required and step must be in [0, num_steps)");
+  hipError_t e = cs::launch_serve_submit(ctx->serve, (uint32_t)step, actions_dev, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_serve_submit: kernel launch");
+  return CS_OK;
+}
+
+int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
+                     uint8_t* truncated_dev, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (!ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_collect: no open session");
+  if (step < -1 || step >= (int32_t)ctx->serve.num_steps)
+    return fail(CS_ERR_ARG, "cs_serve_collect: step must be in [-1, num_steps)");
+  hipError_t e = cs::launch_serve_collect(ctx->serve, step, obs_dev, reward_dev, terminated_dev, truncated_dev,
+                                          (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_serve_collect: kernel launch");
+  return CS_OK;
+}
+
+int cs_serve_policy_pid(cs_ctx* ctx, int32_t step, void* stream) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (!ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_policy_pid: no open session");
+  if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_serve_policy_pid: call cs_pid_configure first");
+  if (cs::task_act_dim(ctx->cfg.task) != 4)
+    return fail(CS_ERR_ARG, "cs_serve_policy_pid: the heuristic flies the 3D tasks only");
+  if (step < 0 || (uint32_t)step >= ctx->serve.num_steps)
+    return fail(CS_ERR_ARG, "cs_serve_policy_pid: step must be in [0, num_steps)");
+  hipError_t e = cs::launch_serve_pid(ctx->serve, (uint32_t)step, ctx->pid, ctx->pid_state, ctx->pid_stride,
+                                      (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "cs_serve_policy_pid: kernel launch");
+  return CS_OK;
+}
+
+int cs_serve_status(cs_ctx* ctx, int32_t* steps_done_min, int32_t* steps_done_max, int32_t* timeouts) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (ctx->serve_stream == nullptr) return fail(CS_ERR_ARG, "cs_serve_status: no session was ever opened");
+  DeviceGuard guard(ctx->cfg.device);
+  CS_HIP(hipStreamSynchronize(ctx->serve_stream));
+  uint32_t w[CS_SERVE_CTRL_WORDS];
+  if (int rc = serve_read_ctrl(ctx, w)) return rc;
+  if (steps_done_min) *steps_done_min = (int32_t)(ctx->serve.num_steps - w[CS_SERVE_CTRL_SHORTFALL]);
+  if (steps_done_max) *steps_done_max = (int32_t)w[CS_SERVE_CTRL_MAXDONE];
+  if (timeouts) *timeouts = (int32_t)w[CS_SERVE_CTRL_TIMEOUTS];
+  if (w[CS_SERVE_CTRL_TIMEOUTS] != 0)
+    return fail(CS_ERR_TIMEOUT, "served stepping: " + std::to_string(w[CS_SERVE_CTRL_TIMEOUTS]) +
+                                    " wavefront(s) gave up waiting; every tile completed " +
+                                    std::to_string(ctx->serve.num_steps - w[CS_SERVE_CTRL_SHORTFALL]) + " of " +
+                                    std::to_string(ctx->serve.num_steps) + " steps");
+  return CS_OK;
+}
+
+int cs_serve_end(cs_ctx* ctx, void* stream_, int32_t* steps_done) {
+  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (!ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_end: no open session");
+  hipStream_t stream = (hipStream_t)stream_;
+  DeviceGuard guard(ctx->cfg.device);
+  hipError_t e = cs::launch_serve_stop(ctx->serve.ctrl, stream);  // behind everything the caller enqueued
+  if (e != hipSuccess) return hip_fail(e, "cs_serve_end: kernel launch");
+  CS_HIP(hipEventRecord(ctx->serve_join, ctx->serve_stream));
+  CS_HIP(hipStreamWaitEvent(stream, ctx->serve_join, 0));
+  ctx->serve_active = false;
+  if (capturing(stream)) return CS_OK;
+  CS_HIP(hipStreamSynchronize(stream));
+  return cs_serve_status(ctx, steps_done, nullptr, nullptr);
 }
 
 // ---- RCCL all-gather for C / C++ hosts: librccl is loaded on first use --------------------------

@@ -216,6 +216,17 @@ hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* m
 // non-finite state word, as float64.
 hipError_t launch_episode_stats(int mode, const DevState& s, double* stats_dev, hipStream_t stream);
 
+// served stepping (copterstep_serve.hip; include/copterstep.h: cs_serve_*)
+hipError_t launch_serve(int task, int mode, const DevConst& c, const DevState& s, const cs_serve_view& v,
+                        hipStream_t stream);
+hipError_t serve_occupancy(int task, int mode, const DevConst& c, const DevState& s, int* blocks_per_cu);
+hipError_t launch_serve_submit(const cs_serve_view& v, uint32_t step, const float* actions, hipStream_t stream);
+hipError_t launch_serve_collect(const cs_serve_view& v, int step, float* obs, float* reward, uint8_t* term,
+                                uint8_t* trunc, hipStream_t stream);
+hipError_t launch_serve_pid(const cs_serve_view& v, uint32_t step, const PidConst& pc, double* pid_state,
+                            uint32_t pid_stride, hipStream_t stream);
+hipError_t launch_serve_stop(uint32_t* ctrl, hipStream_t stream);
+
 // cs_get_state / cs_set_state: plain struct-of-arrays staging buffers on the DEVICE (any may be nullptr):
 // x [12,N] float64 in upstream slot order, force [3,N] newtons, the rest [N].
 struct StateArrays {

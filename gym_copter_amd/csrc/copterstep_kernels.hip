@@ -185,40 +185,10 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // controller gains, reward constants) are made vector-resident up front instead.
   DevConst c = c_arg;
   PidConst pc = pc_arg;
-  constexpr bool FULL = MODE == CS_STATE_F64;
-#pragma unroll
-  for (int j = 0; j < 25; ++j) {
-    const bool used = j < 4 || (FULL ? j < 16 : j >= 16);
-    if (used) c.trig[j] = in_vgpr(c.trig[j]);
-  }
-  c.xyz_pen = in_vgpr(c.xyz_pen);
-  c.yaw_pen = in_vgpr(c.yaw_pen);
-  c.dz_max = in_vgpr(c.dz_max);
-  c.dz_pen = in_vgpr(c.dz_pen);
-  c.target_r2 = in_vgpr(c.target_r2);
-  c.bonus = in_vgpr(c.bonus);
-  c.oob_penalty = in_vgpr(c.oob_penalty);
+  park_constants<MODE == CS_STATE_F64>(c);
   constexpr bool kPid = POLICY == kPolicyPid || POLICY == kPolicyPidHover;
   constexpr int NCTL = POLICY == kPolicyPidHover ? kPidControllers : 4;
-  if constexpr (kPid) {
-    pc.rate_kp = in_vgpr(pc.rate_kp);
-    pc.rate_ki = in_vgpr(pc.rate_ki);
-    pc.rate_kd = in_vgpr(pc.rate_kd);
-    pc.rate_windup = in_vgpr(pc.rate_windup);
-    pc.rate_big = in_vgpr(pc.rate_big);
-    pc.pos_kp = in_vgpr(pc.pos_kp);
-    pc.pos_ki = in_vgpr(pc.pos_ki);
-    pc.pos_kd = in_vgpr(pc.pos_kd);
-    pc.pos_target = in_vgpr(pc.pos_target);
-    pc.pos_windup = in_vgpr(pc.pos_windup);
-    pc.descent_kp = in_vgpr(pc.descent_kp);
-    pc.descent_kd = in_vgpr(pc.descent_kd);
-    pc.alt_kp = in_vgpr(pc.alt_kp);
-    pc.alt_ki = in_vgpr(pc.alt_ki);
-    pc.alt_kd = in_vgpr(pc.alt_kd);
-    pc.alt_target = in_vgpr(pc.alt_target);
-    pc.alt_windup = in_vgpr(pc.alt_windup);
-  }
+  if constexpr (kPid) park_gains(pc);
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
@@ -683,56 +653,13 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevState s,
   }
 }
 
-inline int grid_for(uint32_t n) { return (int)((n + kBlock - 1) / kBlock); }
-
 }  // namespace
+}  // namespace cs
 
-// (task, mode) -> template instantiation
-#define CS_CASE3(FN, TASK, ...)                                         \
-  case TASK * 3 + CS_STATE_F32G:                                        \
-    return FN<TASK, CS_STATE_F32G>(__VA_ARGS__);                        \
-  case TASK * 3 + CS_STATE_F32_RN:                                      \
-    return FN<TASK, CS_STATE_F32_RN>(__VA_ARGS__);                      \
-  case TASK * 3 + CS_STATE_F64:                                         \
-    return FN<TASK, CS_STATE_F64>(__VA_ARGS__);
-#define CS_DISPATCH(FN, ...)                      \
-  switch (task * 3 + mode) {                      \
-    CS_CASE3(FN, CS_TASK_LANDER3D, __VA_ARGS__)   \
-    CS_CASE3(FN, CS_TASK_HOVER3D, __VA_ARGS__)    \
-    CS_CASE3(FN, CS_TASK_LANDER2D, __VA_ARGS__)   \
-    CS_CASE3(FN, CS_TASK_LANDER1D, __VA_ARGS__)   \
-    CS_CASE3(FN, CS_TASK_HOVER2D, __VA_ARGS__)    \
-    CS_CASE3(FN, CS_TASK_HOVER1D, __VA_ARGS__)    \
-    default:                                      \
-      return hipErrorInvalidValue;                \
-  }
-static_assert(CS_STATE_F32G == 0 && CS_STATE_F32_RN == 1 && CS_STATE_F64 == 2, "dispatch index");
-#define CS_MODE_LAUNCH(KERNEL, ...)                                                               \
-  do {                                                                                            \
-    const dim3 grid(grid_for(s.n)), block(kBlock);                                                \
-    if (mode == CS_STATE_F32G)                                                                    \
-      hipLaunchKernelGGL((KERNEL<CS_STATE_F32G>), grid, block, 0, stream, __VA_ARGS__);           \
-    else if (mode == CS_STATE_F32_RN)                                                             \
-      hipLaunchKernelGGL((KERNEL<CS_STATE_F32_RN>), grid, block, 0, stream, __VA_ARGS__);         \
-    else if (mode == CS_STATE_F64)                                                                \
-      hipLaunchKernelGGL((KERNEL<CS_STATE_F64>), grid, block, 0, stream, __VA_ARGS__);            \
-    else                                                                                          \
-      return hipErrorInvalidValue;                                                                \
-    return hipGetLastError();                                                                     \
-  } while (0)
+#include "dev_launch.h"
 
+namespace cs {
 namespace {
-
-bool lean_config(const DevConst& c, const DevState& s) {
-  return c.autoreset != CS_AUTORESET_SAME_STEP && !c.stats && !c.tl_trunc && s.veh == nullptr && !c.gyro &&
-         !c.act_f32 && !c.ticks;
-}
-
-// The headline combinations get every specialised instantiation of the lean kernel; the others one
-// generic lean build (keeps the code object and its build time in bounds).
-constexpr bool is_tuned(int task, int mode) {
-  return (task == CS_TASK_LANDER3D || task == CS_TASK_HOVER3D) && mode == CS_STATE_F32G;
-}
 
 template <int TASK, int MODE>
 hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, const Tuning& tune,

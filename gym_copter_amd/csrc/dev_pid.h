@@ -90,5 +90,45 @@ __device__ __forceinline__ float4 pid_policy(const PidConst& p, PidCtl (&ctl)[NC
                      (float)((t - r) + q));
 }
 
+// The loop body of a K-step kernel needs more uniform values than there are scalar registers (the kernel
+// argument block alone is > 100 dwords); what the compiler cannot keep it parks in VGPR lanes and fetches
+// back with v_readlane in every iteration.  Vector registers are plentiful at this occupancy, so the
+// constants used deep inside the step (sin/cos coefficients, reward constants, controller gains) are made
+// vector-resident up front instead.
+template <bool FULL>
+__device__ __forceinline__ void park_constants(DevConst& c) {
+#pragma unroll
+  for (int j = 0; j < 25; ++j) {
+    const bool used = j < 4 || (FULL ? j < 16 : j >= 16);
+    if (used) c.trig[j] = in_vgpr(c.trig[j]);
+  }
+  c.xyz_pen = in_vgpr(c.xyz_pen);
+  c.yaw_pen = in_vgpr(c.yaw_pen);
+  c.dz_max = in_vgpr(c.dz_max);
+  c.dz_pen = in_vgpr(c.dz_pen);
+  c.target_r2 = in_vgpr(c.target_r2);
+  c.bonus = in_vgpr(c.bonus);
+  c.oob_penalty = in_vgpr(c.oob_penalty);
+}
+__device__ __forceinline__ void park_gains(PidConst& pc) {
+  pc.rate_kp = in_vgpr(pc.rate_kp);
+  pc.rate_ki = in_vgpr(pc.rate_ki);
+  pc.rate_kd = in_vgpr(pc.rate_kd);
+  pc.rate_windup = in_vgpr(pc.rate_windup);
+  pc.rate_big = in_vgpr(pc.rate_big);
+  pc.pos_kp = in_vgpr(pc.pos_kp);
+  pc.pos_ki = in_vgpr(pc.pos_ki);
+  pc.pos_kd = in_vgpr(pc.pos_kd);
+  pc.pos_target = in_vgpr(pc.pos_target);
+  pc.pos_windup = in_vgpr(pc.pos_windup);
+  pc.descent_kp = in_vgpr(pc.descent_kp);
+  pc.descent_kd = in_vgpr(pc.descent_kd);
+  pc.alt_kp = in_vgpr(pc.alt_kp);
+  pc.alt_ki = in_vgpr(pc.alt_ki);
+  pc.alt_kd = in_vgpr(pc.alt_kd);
+  pc.alt_target = in_vgpr(pc.alt_target);
+  pc.alt_windup = in_vgpr(pc.alt_windup);
+}
+
 }  // namespace
 }  // namespace cs

@@ -502,6 +502,74 @@ class CopterVecEnv:
         out = (buf[0], buf[1], buf[2].view(torch.bool), buf[3].view(torch.bool))
         return out + (buf[4],) if return_actions else out
 
+    # -- served stepping: one persistent env kernel per session (cs_serve_*) -------------------
+    def serve_max_envs(self):
+        """Largest batch a served session accepts on this device (every tile's wavefront stays resident)."""
+        out = C.c_int64()
+        _lib.check(self._lib.cs_serve_max_envs(self._ctx, C.byref(out)))
+        return out.value
+
+    def serve_begin(self, num_steps, ring=4, timeout=2.0):
+        """Open a served session of `num_steps` steps: ONE persistent kernel keeps every env in registers
+        and takes each step's action rows from, and publishes its outputs to, tagged granule rings in
+        device memory -- the policy <-> step() loop (reference lander.py:40-65) without a kernel launch
+        per env step.  Feed it with serve_submit / serve_collect (plain tensors), serve_policy_pid (a
+        policy kernel per step) or your own HIP kernels (include/copterstep_serve.h); close with
+        serve_end().  Enqueued on the current stream; the whole session may be captured into a graph.
+        Returns the wire description (a _lib.ServeView)."""
+        self._check_open()
+        torch = _torch()
+        view = _lib.ServeView()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_serve_begin(self._ctx, int(num_steps), int(ring), float(timeout),
+                                                self._stream(), C.byref(view)))
+        return view
+
+    def serve_submit(self, step, actions):
+        """Plain action rows [N,A] (device float32) of step `step` -> the session's action ring."""
+        a, _ = self._dev_f32(actions, (self.num_envs, self.action_dim), "actions")
+        with _torch().cuda.device(self.device):
+            _lib.check(self._lib.cs_serve_submit(self._ctx, int(step), C.c_void_p(a.data_ptr()), self._stream()))
+        self._keep = a
+
+    def serve_collect(self, step, out=None):
+        """Wait (on the device) for the outputs of step `step` (-1: the observation before step 0) and
+        return them as step() would: (obs, reward, terminated, truncated), by default in this env's
+        persistent output buffers, or in `out` = (obs, reward, terminated u8, truncated u8) tensors."""
+        torch = _torch()
+        obs, rew, term, trunc = out if out is not None else (self._obs, self._reward, self._term, self._trunc)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.cs_serve_collect(self._ctx, int(step), p(obs), p(rew), p(term), p(trunc),
+                                                  self._stream()))
+        return obs, rew, term.view(torch.bool), trunc.view(torch.bool)
+
+    def serve_policy_pid(self, step):
+        """One closed-loop policy step as its own kernel: the PID heuristic of configure_pid() on the
+        outputs of step - 1 -> the actions of `step`."""
+        if not getattr(self, "_pid", False):
+            self.configure_pid()
+        with _torch().cuda.device(self.device):
+            _lib.check(self._lib.cs_serve_policy_pid(self._ctx, int(step), self._stream()))
+
+    def serve_end(self):
+        """Close the session: order the current stream behind the env kernel's exit and (outside graph
+        capture) wait for it.  -> steps every tile completed; raises CopterStepError(code ERR_TIMEOUT) if
+        a wavefront gave up waiting for its actions."""
+        done = C.c_int32(-1)
+        with _torch().cuda.device(self.device):
+            _lib.check(self._lib.cs_serve_end(self._ctx, self._stream(), C.byref(done)))
+        return done.value
+
+    def serve_status(self):
+        """(steps completed by every tile, by the fastest tile, wavefronts that gave up) of the last
+        session; synchronises the env kernel's stream."""
+        lo, hi, to = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = self._lib.cs_serve_status(self._ctx, C.byref(lo), C.byref(hi), C.byref(to))
+        if rc not in (0, _lib.ERR_TIMEOUT):
+            _lib.check(rc)
+        return lo.value, hi.value, to.value
+
     def pid_get_state(self):
         """Controller state as a host array [24, N] float64 (rows: see include/copterstep.h)."""
         self._check_open()

@@ -32,6 +32,7 @@
  *   cs_pid_* / cs_rollout_pid  the PID landing heuristic loop   attic/mars/pidcontrollers/__init__.py:12-146,
  *                                                               attic/mars/lander3d.py:32-36,64-87
  *   cs_rollout_random        the `--random` action loop         lander.py:40-65 (action = MOTORVAL*randn / action_space.sample())
+ *   cs_serve_*               the caller's policy <-> step loop  lander.py:40-65, attic/drl/3dtest.py:44-59 (persistent env kernel)
  *
  * Conventions
  *   - Every function returns CS_OK (0) or a negative cs_status; cs_last_error() then
@@ -66,7 +67,8 @@ typedef enum cs_status {
   CS_ERR_DEVICE = -2,   /* no usable HIP device / device ordinal out of range */
   CS_ERR_MEMORY = -3,   /* device or host allocation failed */
   CS_ERR_HIP = -4,      /* a HIP runtime call failed */
-  CS_ERR_ABI = -5       /* cs_config.struct_size / abi_version mismatch */
+  CS_ERR_ABI = -5,      /* cs_config.struct_size / abi_version mismatch */
+  CS_ERR_TIMEOUT = -6   /* served stepping: a wavefront gave up waiting (cs_serve_end / cs_serve_status) */
 } cs_status;
 
 /* 3D tasks: action [4] = the four motors; observation 10 (Lander3D: x..dtheta) or 12 (Hover3D).
@@ -318,6 +320,66 @@ typedef struct cs_tuning {
 } cs_tuning;
 int cs_set_tuning(cs_ctx* ctx, const cs_tuning* tuning);
 int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out); /* the values in effect */
+
+/* ---- served stepping: one PERSISTENT env kernel for caller-supplied actions -------------------------
+ * Replaces the caller's policy <-> env.step() loop (lander.py:40-65, attic/drl/3dtest.py:44-59) without a
+ * kernel launch per env step: cs_serve_begin leaves ONE kernel running on a stream of the context's own,
+ * one wavefront per tile of 64 envs with the env state in registers, for `num_steps` steps.  A step's action
+ * rows reach it, and its observation / reward / flag rows leave it, as tagged 16-byte granules in two rings
+ * in device memory (wire format, device-side helpers and rules: include/copterstep_serve.h).  Results are
+ * bit-identical to `num_steps` calls of cs_step (both run the same step code on a register-resident env).
+ *
+ *   cs_serve_begin(ctx, K, ring, timeout_s, stream, &view)   zero the rings (on `stream`), fork, launch
+ *   per step s = 0 .. K-1, on `stream` or on any stream ordered behind cs_serve_begin:
+ *       EITHER the caller's own policy kernel speaking the wire format (copterstep_serve.h),
+ *       e.g. cs_serve_policy_pid(ctx, s, stream): out(s-1) -> PID heuristic -> act(s), one launch per step
+ *       OR  cs_serve_submit(ctx, s, actions_dev, stream)  +  cs_serve_collect(ctx, s, obs, ..., stream)
+ *           (plain [N,A] rows in, plain rows out: one small kernel each)
+ *   cs_serve_end(ctx, stream, &steps_done)                    (stop,) join `stream` behind the env kernel
+ *
+ * What it costs and when it pays is measured in DESIGN.md section 8 (tools/serve_ubench.hip): a hand-off
+ * between two wavefronts through device memory takes ~2 us on MI355X under this load, so a closed loop runs
+ * at ~4.7 us per step against 6.5 us for policy kernel + cs_step; a caller with ONE plain kernel per step is
+ * still best served by cs_step itself.
+ *
+ * All env wavefronts must be resident at once: num_envs <= cs_serve_max_envs().  A whole session (begin ..
+ * end with everything between) may be captured into a hipGraph and replayed; cs_serve_begin must then be
+ * captured too (the rings are zeroed by it).  Every wait on the device is bounded by timeout_s: a step whose
+ * actions never arrive ends the session with CS_ERR_TIMEOUT from cs_serve_end / cs_serve_status, the env
+ * state as of the last completed step of each tile, and *steps_done = the steps EVERY tile completed. */
+#define CS_SERVE_TAG_INIT 0x80000000u
+enum { CS_SERVE_CTRL_STOP = 0, CS_SERVE_CTRL_TIMEOUTS = 1, CS_SERVE_CTRL_SHORTFALL = 2, CS_SERVE_CTRL_MAXDONE = 3,
+       CS_SERVE_CTRL_WORDS = 16 };
+typedef struct cs_serve_view {
+  void* act_ring;        /* [ring][tiles][act_pieces][64] x 16 B */
+  void* out_ring;        /* [ring][tiles][out_pieces][64] x 16 B */
+  void* out_init;        /* [tiles][out_pieces][64] x 16 B: the observation before step 0 */
+  uint32_t* ctrl;        /* CS_SERVE_CTRL_WORDS control words */
+  uint64_t spin_limit;   /* bound of every device-side wait, in 100 MHz ticks */
+  uint32_t tiles, ring;  /* tiles = ceil(num_envs / 64); ring = a power of two */
+  uint32_t act_pieces, out_pieces;  /* ceil(action_dim / 2), (obs_dim + 2) / 2 */
+  uint32_t obs_dim, act_dim, num_envs, num_steps;
+} cs_serve_view;
+int cs_serve_max_envs(const cs_ctx* ctx, int64_t* out);
+/* ring: slots per ring, a power of two in [2, 64] (0 = 4).  timeout_s <= 0 = 2 s.  view_out may be NULL. */
+int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_s, void* stream,
+                   cs_serve_view* view_out);
+/* plain action rows [N,A] of step `step` -> the action ring (waits for the ring slot, see copterstep_serve.h) */
+int cs_serve_submit(cs_ctx* ctx, int32_t step, const float* actions_dev, void* stream);
+/* wait for the outputs of step `step` (-1 = the observation before step 0) and write them as cs_step would
+ * (each pointer nullable) */
+int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
+                     uint8_t* truncated_dev, void* stream);
+/* One closed-loop policy step as its own kernel: the PID heuristic of cs_pid_configure on the outputs of step
+ * `step` - 1 -> the actions of `step` (controller state in the context, as cs_rollout_pid keeps it).  K of
+ * these against a served session are bit-identical to cs_rollout_pid(K). */
+int cs_serve_policy_pid(cs_ctx* ctx, int32_t step, void* stream);
+/* Ask the env kernel to stop at the first step whose actions are not there, and order `stream` behind its
+ * exit.  Outside stream capture it then synchronises `stream` and reports: CS_OK, or CS_ERR_TIMEOUT if a
+ * wavefront gave up; *steps_done (nullable) = steps completed by every tile.  Inside a capture it only
+ * enqueues (CS_OK); ask cs_serve_status after the replay. */
+int cs_serve_end(cs_ctx* ctx, void* stream, int32_t* steps_done);
+int cs_serve_status(cs_ctx* ctx, int32_t* steps_done_min, int32_t* steps_done_max, int32_t* timeouts);
 
 /* ---- multi-GPU return path for C / C++ hosts: one RCCL all-gather over xGMI -------------------
  * The env batch shards trivially (no collective in stepping); the only exchange is the optional

@@ -220,6 +220,56 @@ int main(int argc, char** argv) {
     HIP(hipFree(gathered));
   }
 
+  // ---- served stepping from a plain C++ host: a session of 8 steps == 8 x cs_step on a twin context ----
+  {
+    cs_ctx* twin = nullptr;
+    OK(cs_create(&cfg, &twin));
+    OK(cs_reset(ctx, nullptr, force, obs, stream));
+    OK(cs_reset(twin, nullptr, force, obs, stream));
+    const int K = 8;
+    float *obs2, *rew2;
+    HIP(hipMalloc((void**)&obs2, n * od * sizeof(float)));
+    HIP(hipMalloc((void**)&rew2, n * sizeof(float)));
+    int64_t cap = 0;
+    OK(cs_serve_max_envs(ctx, &cap));
+    CHECK(cap >= n);
+    cs_serve_view view;
+    OK(cs_serve_begin(ctx, K, 2, 1.0, stream, &view));
+    CHECK(view.tiles == (uint32_t)((n + 63) / 64) && view.ring == 2 && view.obs_dim == (uint32_t)od && view.act_dim == 4 &&
+          view.out_pieces == (uint32_t)(od + 2) / 2 && view.num_steps == (uint32_t)K);
+    CHECK(cs_serve_begin(ctx, K, 2, 1.0, stream, nullptr) == CS_ERR_ARG);   // one session at a time
+    CHECK(cs_serve_submit(ctx, K, act, stream) == CS_ERR_ARG);              // step out of range
+    std::vector<float> a_obs(n * od), b_obs(n * od), a_rew(n), b_rew(n);
+    for (int k = 0; k < K; ++k) {
+      OK(cs_serve_submit(ctx, k, act, stream));
+      OK(cs_serve_collect(ctx, k, obs, rew, term, trunc, stream));
+      OK(cs_step(twin, act, obs2, rew2, nullptr, nullptr, stream));
+      HIP(hipMemcpyAsync(a_obs.data(), obs, a_obs.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(b_obs.data(), obs2, b_obs.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(a_rew.data(), rew, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(b_rew.data(), rew2, n * sizeof(float), hipMemcpyDeviceToHost, stream));
+      HIP(hipStreamSynchronize(stream));
+      CHECK(std::memcmp(a_obs.data(), b_obs.data(), a_obs.size() * sizeof(float)) == 0);
+      CHECK(std::memcmp(a_rew.data(), b_rew.data(), n * sizeof(float)) == 0);
+    }
+    int32_t done = -1, lo = -1, hi = -1, to = -1;
+    OK(cs_serve_end(ctx, stream, &done));
+    CHECK(done == K);
+    OK(cs_serve_status(ctx, &lo, &hi, &to));
+    CHECK(lo == K && hi == K && to == 0);
+    CHECK(cs_serve_end(ctx, stream, nullptr) == CS_ERR_ARG);  // no open session
+    // a session nobody feeds: bounded wait, CS_ERR_TIMEOUT, nothing stepped
+    OK(cs_serve_begin(ctx, 3, 0, 0.05, stream, nullptr));
+    CHECK(cs_serve_end(ctx, stream, &done) == CS_OK && done == 0);           // the stop word got there first ...
+    OK(cs_serve_begin(ctx, 3, 0, 0.05, stream, nullptr));
+    HIP(hipStreamSynchronize(stream));
+    CHECK(cs_serve_status(ctx, &lo, &hi, &to) == CS_ERR_TIMEOUT && lo == 0 && to > 0);   // ... or nobody stopped it
+    CHECK(cs_serve_end(ctx, stream, &done) == CS_ERR_TIMEOUT && done == 0);
+    HIP(hipFree(obs2));
+    HIP(hipFree(rew2));
+    OK(cs_destroy(twin));
+  }
+
   // ---- errors come back as codes + messages, never as exceptions or aborts ----
   CHECK(cs_step(ctx, nullptr, obs, rew, term, trunc, stream) != 0);
   CHECK(cs_last_error()[0] != '\0');

@@ -149,3 +149,216 @@ def test_state_round_trip_keeps_philox_perturbations_on_the_seed():
     assert torch.equal(oa, ob)
     a.close()
     b.close()
+
+
+# ---------------------------------------------------------------------------------------
+# served stepping: one persistent env kernel per session (cs_serve_*, include/copterstep_serve.h)
+# ---------------------------------------------------------------------------------------
+def _twin(task, n, mode, **kw):
+    import gym_copter_amd
+    mk = lambda: gym_copter_amd.CopterVecEnv(task=task, num_envs=n, state_dtype=mode, seed=21, **kw)
+    a, b = mk(), mk()
+    a.reset()
+    b.reset()
+    return a, b
+
+
+def _assert_same_state(a, b):
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("task,mode,kw", [
+    ("lander3d", "float32", dict(autoreset_mode="next_step")),
+    ("hover3d", "float32", dict(autoreset_mode="next_step")),
+    ("lander3d", "float64", dict(autoreset_mode="same_step", episode_stats=True, track_time=True)),
+    ("lander3d", "float32_rn", dict(autoreset_mode="disabled", substeps=3)),
+    ("lander2d", "float32", dict(autoreset_mode="next_step")),
+    ("hover1d", "float32", dict(autoreset_mode="next_step", time_limit_truncates=True, max_steps=40)),
+])
+def test_served_steps_are_bit_identical_to_cs_step(task, mode, kw):
+    """K served steps (plain rows in through cs_serve_submit, out through cs_serve_collect) against the same
+    K steps of cs_step on a twin env: every output of every step and the final state, bit for bit, under
+    reset churn, on a ragged batch, for lean and full-featured configurations."""
+    import torch
+    n, K = 2000 + 37, 240
+    served, plain = _twin(task, n, mode, **kw)
+    ad = served.action_dim
+    g = torch.Generator(device=served.device)
+    g.manual_seed(5)
+    acts = torch.rand((K, n, ad), generator=g, device=served.device) * 2 - 1
+    acts[:, ::3] = HOVER * (1 + 0.02 * torch.randn((K, (n + 2) // 3, ad), generator=g, device=served.device))
+    view = served.serve_begin(K, ring=4, timeout=5.0)
+    assert (view.tiles, view.obs_dim, view.act_dim, view.num_steps) == ((n + 63) // 64, served.obs_dim, ad, K)
+    o0 = served.serve_collect(-1)[0].clone()
+    assert torch.equal(o0, plain._obs)                     # the observation before step 0 = what reset returned
+    n_done = 0
+    for s in range(K):
+        served.serve_submit(s, acts[s])
+        got = [t.clone() for t in served.serve_collect(s)]
+        want = plain.step(acts[s])[:4]
+        for k, (x, y) in enumerate(zip(got, want)):
+            assert torch.equal(x, y), (s, k)
+        n_done += int(got[2].sum()) + int(got[3].sum())
+    assert served.serve_end() == K
+    assert served.serve_status() == (K, K, 0)
+    assert n_done > n // 4 or kw.get("autoreset_mode") == "disabled"      # the churn really happened
+    _assert_same_state(served, plain)
+    # the env goes on with ordinary steps afterwards
+    a = acts[0]
+    for x, y in zip(served.step(a)[:4], plain.step(a)[:4]):
+        assert torch.equal(x, y)
+    served.close()
+    plain.close()
+
+
+def test_served_steps_at_full_size_vs_cs_step_and_oracle():
+    """BASELINE config 2's size: 65 536 envs, 1 000 served steps with reset churn, every step bit-identical to
+    cs_step on a twin; the first 60 steps also against the CPU oracle."""
+    import torch
+    n, K = 65536, 1000
+    served, orc = make_pair("lander3d", n, "float32", autoreset="next_step", seed=9)
+    plain, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=9)
+    for e in (served, plain, orc):
+        e.reset()
+    assert served.serve_max_envs() >= n
+    g = torch.Generator(device=served.device)
+    g.manual_seed(1)
+    ring = torch.rand((16, n, 4), generator=g, device=served.device) * 2 - 1
+    served.serve_begin(K, ring=8, timeout=5.0)
+    bad = torch.zeros((), dtype=torch.int64, device=served.device)
+    for s in range(K):
+        a = ring[s % 16]
+        served.serve_submit(s, a)
+        got = served.serve_collect(s)
+        want = plain.step(a)[:4]
+        for x, y in zip(got, want):
+            bad += (x != y).sum()
+        if s < 60:
+            obs, r, term, trunc = (to_np(t).copy() for t in got)
+            assert_step_close((obs, r, term, trunc), orc.step(to_np(a).astype(np.float64)), MODE_TOL["float32"] * 100,
+                              r_abs=2e-3, ctx="step %d" % s)
+    assert served.serve_end() == K
+    assert int(bad) == 0
+    _assert_same_state(served, plain)
+    served.close()
+    plain.close()
+
+
+@pytest.mark.parametrize("task,heuristic", [("lander3d", "lander"), ("hover3d", "hover"), ("hover3d", "lander")])
+def test_served_closed_loop_policy_kernel_equals_rollout_pid(task, heuristic):
+    """A closed loop whose policy is its OWN kernel per step (cs_serve_policy_pid: outputs of step s-1 ->
+    PID heuristic -> actions of step s, through the granule rings) against the same loop fused into one
+    kernel (cs_rollout_pid): bit-identical outputs, state and controller state."""
+    import torch
+    n, K = 2500, 160
+    a, b = _twin(task, n, "float32", autoreset_mode="next_step")
+    for e in (a, b):
+        e.configure_pid(heuristic=heuristic)
+        e.reset()
+    want = [t.clone() for t in b.rollout_pid(K)]
+    a.serve_begin(K, ring=2, timeout=5.0)
+    outs = [torch.empty_like(t) for t in want]
+    for s in range(K):
+        a.serve_policy_pid(s)
+        a.serve_collect(s, out=(outs[0][s], outs[1][s], outs[2][s].view(torch.uint8), outs[3][s].view(torch.uint8)))
+    assert a.serve_end() == K
+    for k, (x, y) in enumerate(zip(outs, want)):
+        assert torch.equal(x, y), k
+    _assert_same_state(a, b)
+    assert np.array_equal(a.pid_get_state(), b.pid_get_state())
+    a.close()
+    b.close()
+
+
+def test_served_session_gives_up_after_its_timeout_and_says_so():
+    """A step whose actions never arrive: every wavefront's wait is bounded, the session ends with
+    CS_ERR_TIMEOUT, the steps that were served are kept, and the env is usable afterwards."""
+    import time
+    import torch
+    from gym_copter_amd._lib import CopterStepError, ERR_TIMEOUT
+    n = 4096
+    served, plain = _twin("lander3d", n, "float32", autoreset_mode="next_step")
+    acts = torch.full((n, 4), HOVER, dtype=torch.float32, device=served.device)
+    served.serve_begin(6, ring=2, timeout=0.25)
+    for s in range(3):
+        served.serve_submit(s, acts)
+        served.serve_collect(s)
+        plain.step(acts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    status = served.serve_status()          # waits for the env kernel: it gives up after 0.25 s
+    waited = time.perf_counter() - t0
+    assert status == (3, 3, (n + 63) // 64) and 0.2 < waited < 2.0
+    served._lib.cs_serve_end(served._ctx, served._stream(), None)
+    with pytest.raises(CopterStepError) as ei:
+        served.serve_begin(2, timeout=0.05)
+        served.serve_end()                  # nothing submitted at all
+    assert ei.value.code == ERR_TIMEOUT
+    _assert_same_state(served, plain)
+    for x, y in zip(served.step(acts)[:4], plain.step(acts)[:4]):
+        assert torch.equal(x, y)
+    served.close()
+    plain.close()
+
+
+def test_served_session_stops_early_on_request():
+    import torch
+    n = 3000
+    served, plain = _twin("hover3d", n, "float32", autoreset_mode="next_step")
+    acts = torch.rand((n, 4), device=served.device)
+    served.serve_begin(500, timeout=10.0)
+    for s in range(7):
+        served.serve_submit(s, acts)
+        plain.step(acts)
+    assert served.serve_end() == 7          # the stop word ends the session well before the 10 s timeout
+    assert served.serve_status() == (7, 7, 0)
+    _assert_same_state(served, plain)
+    served.close()
+    plain.close()
+
+
+def test_served_session_captured_in_a_hipgraph_replays():
+    """begin + K x (submit, collect) + end as ONE hipGraph, replayed: tags are session-relative and the rings
+    are zeroed by the captured cs_serve_begin, so every replay is a clean session."""
+    import torch
+    n, K = 8192, 24
+    served, plain = _twin("lander3d", n, "float32", autoreset_mode="next_step")
+    acts = torch.rand((K, n, 4), device=served.device) * 2 - 1
+    outs = (torch.empty((K, n, served.obs_dim), device=served.device), torch.empty((K, n), device=served.device),
+            torch.empty((K, n), dtype=torch.uint8, device=served.device),
+            torch.empty((K, n), dtype=torch.uint8, device=served.device))
+
+    def session():
+        served.serve_begin(K, ring=4, timeout=5.0)
+        for s in range(K):
+            served.serve_submit(s, acts[s])
+            served.serve_collect(s, out=tuple(t[s] for t in outs))
+        served.serve_end()
+
+    side = torch.cuda.Stream(device=served.device)
+    side.wait_stream(torch.cuda.current_stream(served.device))
+    with torch.cuda.stream(side):
+        session()                            # allocates the rings (not allowed inside a capture)
+    torch.cuda.current_stream(served.device).wait_stream(side)
+    torch.cuda.synchronize()
+    want = [[t.clone() for t in plain.step(acts[s])[:4]] for s in range(K)]
+    for k in range(4):
+        assert torch.equal(outs[k].view(want[0][k].dtype) if k >= 2 else outs[k], torch.stack([w[k] for w in want]))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        session()
+    for rep in range(3):
+        for t in outs:
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert served.serve_status() == (K, K, 0)
+        want = [[t.clone() for t in plain.step(acts[s])[:4]] for s in range(K)]
+        for k in range(4):
+            got = outs[k].view(torch.bool) if k >= 2 else outs[k]
+            assert torch.equal(got, torch.stack([w[k] for w in want])), (rep, k)
+    _assert_same_state(served, plain)
+    served.close()
+    plain.close()
