@@ -24,6 +24,12 @@ hipError_t launch_set_perturbation(int, const DevState&, const uint8_t*, const f
 hipError_t launch_episode_stats(int, const DevState&, double*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_state_gather(int, const DevConst&, const DevState&, const StateArrays&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_state_scatter(int, const DevConst&, const DevState&, const StateArrays&, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_serve(int, int, const DevConst&, const DevState&, const cs_serve_view&, hipStream_t) { return hipErrorUnknown; }
+hipError_t serve_occupancy(int, int, const DevConst&, const DevState&, int*) { return hipErrorUnknown; }
+hipError_t launch_serve_submit(const cs_serve_view&, uint32_t, const float*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_serve_collect(const cs_serve_view&, int, float*, float*, uint8_t*, uint8_t*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_serve_pid(const cs_serve_view&, uint32_t, const PidConst&, double*, uint32_t, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_serve_stop(uint32_t*, hipStream_t) { return hipErrorUnknown; }
 }  // namespace cs
 
 #define REQUIRE(cond)                                                        \
