@@ -83,12 +83,17 @@ def parse(argv=None):
                         "from the ring into one buffer) instead of being read from the resident ring")
     p.add_argument("--min-region-ms", type=float, default=50.0, help="GPU work per timed region")
     p.add_argument("--regions", type=int, default=5, help="timed regions (the median is reported)")
-    p.add_argument("--gather", action="store_true", help="also time with the RCCL obs all-gather")
+    p.add_argument("--gather", action="store_true",
+                   help="also time with the RCCL all-gathers of the concatenated return (default when --gpus > 1; on "
+                        "one GPU it runs them in a 1-rank RCCL group)")
+    p.add_argument("--no-gather", action="store_true", help="--gpus > 1 without the collective legs")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-sweep", action="store_true", help="skip the batch-size / task sweep and config 5")
     p.add_argument("--pid", type=int, default=100,
                    help="also time cs_rollout_pid / cs_rollout_random with this many steps per launch (0 = skip)")
+    p.add_argument("--served", type=int, default=100,
+                   help="also time served stepping (cs_serve_*) with this many steps per session (0 = skip)")
     p.add_argument("--many", type=int, default=100,
                    help="also time cs_step_many with this many steps per launch (0 = skip)")
     p.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
@@ -240,6 +245,46 @@ class PipeStepper:
         if done < count:
             self.chunk(count - done, self.pos)
             self.pos += count - done
+
+
+class ServedSession:
+    """K env steps as ONE served session (gym_copter_amd.CopterVecEnv.serve_*): cs_serve_begin leaves a
+    persistent env kernel running, `body(s)` feeds step s (a policy kernel, or submit + collect kernels),
+    cs_serve_end joins.  The whole session is one hipGraph; run(count) replays it count // K times."""
+
+    def __init__(self, torch, env, K, body, ring, use_graph=True):
+        self.torch, self.env, self.K, self.body, self.ring = torch, env, K, body, ring
+        self.graph = None
+        dev = env.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.session()                    # the first session allocates the rings: outside any capture
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        self.check()
+        if use_graph:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.session()
+
+    def session(self):
+        self.env.serve_begin(self.K, ring=self.ring, timeout=5.0)
+        for s in range(self.K):
+            self.body(s)
+        self.env.serve_end()
+
+    def check(self):
+        st = self.env.serve_status()
+        if st != (self.K, self.K, 0):
+            raise RuntimeError("served session incomplete: (min, max, timeouts) = %r of %d steps" % (st, self.K))
+
+    def run(self, count):
+        for _ in range(max(1, count // self.K)):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self.session()
 
 
 class LaunchFloor:
@@ -402,6 +447,20 @@ def cpu_baseline(task, law, seconds):
                                  "sample": "oracle/refvec.py VecOracle, %d envs x %d steps" % (nv, k)}}
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the device sources of the step kernels: what profiles/traffic.json is stamped
+    with (scripts/collect_profiles.py), so that a PMC figure is never reported for kernels it was not taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "gym_copter_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "dev_*.h")) + [os.path.join(csrc, "copterstep_kernels.hip"),
+                                                                  os.path.join(csrc, "copterstep_internal.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def graph_chunk_for(steps, graph_chunk):
     """Launches per captured hipGraph: whole passes of the K steps, as many as fit `graph_chunk`
     (a 20-step graph pays its ~4 us replay boundary every 20 launches: 0.2 us per step)."""
@@ -452,18 +511,36 @@ def main(argv=None):
 
     import torch
     dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # launched by torch.distributed.run
+    launched = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # by torch.distributed.run
+    if world > 1 and not a.no_gather:
+        a.gather = True            # N > 1: the collective legs are part of the default report
+    if launched or a.gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not launched:           # --gather on one GPU: a real RCCL group of ONE rank
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if world == 1:
+            # world 1: gym_copter_amd.sharded would shortcut the all-gathers to a return / a device copy;
+            # the legs below are there to exercise RCCL, so ask for the collective
+            os.environ.setdefault("COPTERSTEP_FORCE_COLLECTIVE", "1")
         torch.cuda.set_device(local)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     timer = Timer(torch, dist, device)
+    rccl = None
     with stdout_to_stderr():
         if dist is not None:
             dist.init_process_group("nccl", device_id=device)
         timer.barrier()      # (N > 1: the communicator is set up here, outside every timed region)
+        if dist is not None:
+            # what RCCL itself saw: an all-reduce of ones over the group (the driver can check N ranks took part)
+            ones = torch.ones(1, device=device, dtype=torch.float32)
+            dist.all_reduce(ones)
+            rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                    "ranks_seen": int(round(float(ones.item())))}
 
     import gym_copter_amd as gca
     n = a.envs
@@ -531,6 +608,7 @@ def main(argv=None):
             del pr
             pipe.close()
         extra["allgather_launch_mode"] = modes
+        extra["allgather_is_a_collective"] = bool(world > 1 or os.environ.get("COPTERSTEP_FORCE_COLLECTIVE") == "1")
 
     def k_step_leg(name, k, call, bytes_step, note):
         class Runner:
@@ -568,6 +646,65 @@ def main(argv=None):
         k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 136.0 / k,
                    "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
                    "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)")
+    if a.served > 0:
+        # served stepping (cs_serve_*): ONE persistent env kernel per K-step session, the env state in
+        # registers throughout; action rows in and result rows out as tagged 16-byte granules through device
+        # memory.  Reported beside the headline with their own byte models (what crosses memory per env-step).
+        k = a.served
+        ap, op = (env.action_dim + 1) // 2, (od + 2) // 2
+        wire = 2 * 16 * (ap + op)                                   # every granule pair is written once and read once
+
+        def served_leg(name, body, ring, bytes_step, note, prepare=None):
+            try:
+                if prepare is not None:
+                    prepare()
+                env.reset()
+                ses = ServedSession(torch, env, k, body, ring, use_graph)
+                g = timer.measure(ses, max(k, a.steps // k * k), 2 * k, min_region_s, a.regions, quantum=k)
+                torch.cuda.synchronize()
+                ses.check()
+                extra[name] = {"steps_per_session": k, "ring": ring, "value": total_envs / g["s_per_step"],
+                               "unit": "env-steps/s", "us_per_step": g["launch_s"] * 1e6, "repeats": g["repeats"],
+                               "bytes_per_env_step": bytes_step, "achieved_GBps": bytes_step * n / g["launch_s"] / 1e9,
+                               "note": note}
+                del ses
+            except Exception as e:          # an extra never costs the headline
+                extra[name] = {"error": repr(e)}
+                try:
+                    torch.cuda.synchronize()
+                    env._lib.cs_serve_end(env._ctx, env._stream(), None)
+                except Exception:
+                    pass
+
+        if a.task in ("lander3d", "hover3d"):
+            served_leg("served_closed_loop", lambda s: env.serve_policy_pid(s), 2, wire + 256.0,
+                       "closed loop with the policy as its OWN kernel per step (cs_serve_policy_pid: outputs of step "
+                       "s-1 -> PID heuristic -> actions of step s) against the persistent env kernel: one launch per "
+                       "step, two hand-offs through device memory; bit-identical to cs_rollout_pid "
+                       "(tests/test_gpu_round3.py::test_served_closed_loop_policy_kernel_equals_rollout_pid); compare "
+                       "with a policy kernel + cs_step per step (config.actions_produced_by_a_preceding_kernel)",
+                       prepare=lambda: env.configure_pid())
+        served_leg("served_submit_collect",
+                   lambda s: (env.serve_submit(s, actions[s % actions.shape[0]]), env.serve_collect(s)), 4,
+                   wire + 4 * env.action_dim + 4 * od + 6,
+                   "plain tensors in and out: cs_serve_submit + cs_serve_collect per step (two small launches on one "
+                   "stream) against the persistent env kernel; bit-identical to cs_step "
+                   "(tests/test_gpu_round3.py::test_served_steps_are_bit_identical_to_cs_step)")
+        side = [torch.cuda.Stream(device=device) for _ in (0, 1)]
+
+        def submit_two_streams(s):
+            # no launch dependency between consecutive producers: even / odd steps on two streams
+            cur = torch.cuda.current_stream(device)
+            if s < 2:
+                side[s].wait_stream(cur)
+            with torch.cuda.stream(side[s % 2]):
+                env.serve_submit(s, actions[s % actions.shape[0]])
+            if s >= k - 2:
+                cur.wait_stream(side[s % 2])
+        served_leg("served_producers_ahead", submit_two_streams, 8, wire + 4 * env.action_dim,
+                   "producers that run ahead of the env (open-loop rows submitted from two alternating streams, only ring "
+                   "back-pressure; outputs left in the output ring for a device-side consumer): what the persistent env "
+                   "kernel sustains when it never waits for a policy")
     env.close()
     del stepper, env, actions
     torch.cuda.empty_cache()
@@ -575,8 +712,9 @@ def main(argv=None):
     # ---- the same kernel at the other single-GPU points (driver-visible; N = 1 only) ----
     if not a.no_sweep and world == 1:
         sweep = []
-        points = [("lander3d", 262144, "uniform", 16), ("lander3d", 262144, "near_hover", 16),
-                  ("hover3d", 262144, "uniform", 16), ("lander3d", 1048576, "uniform", 8),
+        points = [("hover3d", 262144, "uniform", 16),            # BASELINE configs[2] first
+                  ("lander3d", 262144, "uniform", 16), ("lander3d", 262144, "near_hover", 16),
+                  ("lander3d", 1048576, "uniform", 8),
                   ("hover3d", 1048576, "uniform", 8), ("lander3d", 4194304, "uniform", 4),
                   ("hover3d", 4194304, "uniform", 4)]
         for task, nn, law, ring in points:
@@ -637,10 +775,17 @@ def main(argv=None):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("%s_%d" % (a.task, n))
-            if traffic is not None:
-                tsrc = ("profiles/traffic.json: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes) of this "
-                        "kernel and batch, committed with the profiles -- NOT measured by this run")
+            tj = json.load(open(tpath))
+            here = kernel_source_hash()
+            if tj.get("kernel_source_sha16") != here:
+                tsrc = ("profiles/traffic.json was measured on kernel sources %s, this tree has %s: traffic withheld"
+                        % (tj.get("kernel_source_sha16"), here))
+            else:
+                traffic = tj.get("%s_%d" % (a.task, n))
+                if traffic is not None:
+                    tsrc = ("profiles/traffic.json: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes) of this "
+                            "kernel and batch at commit %s (kernel sources %s = this tree's) -- NOT measured by this run"
+                            % (tj.get("commit"), here))
         except Exception:
             traffic = None
 
@@ -651,6 +796,9 @@ def main(argv=None):
         "warmup": a.warmup, "ms_per_step": m["s_per_step"] * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "repeats": m["repeats"], "regions": m["regions"], "timed_steps_per_region": m["steps"] * m["repeats"],
+        # `steps` echoes --steps; what was actually timed (the driver's consistency arithmetic should use these):
+        "timed_steps_total": m["steps"] * m["repeats"] * m["regions"],
+        "timed_region_s": m["wall_s"],
         "timing": "median of %d regions of %d x %d steps (hipGraphs of %d launches), each bracketed by barrier + "
                   "synchronize, MAX over ranks" % (m["regions"], m["repeats"], m["steps"], chunk),
         "single_pass": m["single_pass"],
@@ -669,6 +817,24 @@ def main(argv=None):
     out.update(extra)
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    if rccl is not None:
+        out["rccl"] = rccl
+    # a compact digest as the LAST key (a log tail keeps the end of the line) and inside `roofline` (a contract key)
+    pick = lambda d, *ks: {k: d[k] for k in ks if isinstance(d, dict) and k in d}
+    digest = {"timed_steps_total": out["timed_steps_total"], "timed_region_s": out["timed_region_s"],
+              "headline": pick(out["roofline"], "launch_us", "frac"),
+              "sweep_frac": {"%s_%d_%s" % (e.get("task"), e.get("envs", 0), e.get("actions")): round(e["frac"], 4)
+                             for e in extra.get("sweep", []) if "frac" in e},
+              "config5": [pick(b, "bound", "frac") for b in extra.get("config5", {}).get("bounds", [])],
+              "config5_launch_us": extra.get("config5", {}).get("launch_us"),
+              "k_step_us": {k: round(extra[k]["us_per_step"], 3) for k in ("step_many", "rollout_pid", "rollout_random")
+                            if "us_per_step" in extra.get(k, {})},
+              "served_us": {k: round(extra[k]["us_per_step"], 3)
+                            for k in ("served_closed_loop", "served_submit_collect", "served_producers_ahead")
+                            if "us_per_step" in extra.get(k, {})},
+              "rccl": rccl}
+    out["roofline"]["digest"] = digest
+    out["summary"] = digest
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

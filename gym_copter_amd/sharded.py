@@ -15,7 +15,16 @@ gym_copter/envs/task.py:161 builds one Dynamics per env), so the batch shards tr
     before the collective.  It is issued on the current stream right behind the step kernel.
     A caller whose policy is replicated per GPU should leave gather off.
 """
+import os
+
 import numpy as np
+
+
+def _force_collective(flag):
+    """With a process group of ONE rank the all-gathers below are identities and are shortcut; asked to
+    (force_collective=True, or COPTERSTEP_FORCE_COLLECTIVE=1 in the environment) they are issued all the same,
+    so that the RCCL path -- eager and hipGraph-captured -- can be exercised on a single GPU."""
+    return bool(flag) if flag is not None else os.environ.get("COPTERSTEP_FORCE_COLLECTIVE", "0") == "1"
 
 
 def shard_bounds(total_envs, world_size, rank):
@@ -32,14 +41,15 @@ class ShardGather:
     """Pre-allocated all-gather of per-env rows: local [n_local, ...] -> global [N, ...]
     in global env-id order (rank-major)."""
 
-    def __init__(self, n_local, world_size, group=None):
+    def __init__(self, n_local, world_size, group=None, force_collective=None):
         self.n_local, self.world, self.group = n_local, world_size, group
+        self.force = _force_collective(force_collective)
         self._out = {}
 
     def __call__(self, name, local):
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not (self.force and dist.is_initialized()):
             return local
         key = (name, tuple(local.shape[1:]), local.dtype, local.device)
         out = self._out.get(key)
@@ -57,9 +67,10 @@ class PackedOutputs:
     sections are the tensors the step kernel writes; the global ones are strided views of the
     gathered buffer, so one collective moves everything."""
 
-    def __init__(self, n_local, obs_dim, world_size, device, group=None):
+    def __init__(self, n_local, obs_dim, world_size, device, group=None, force_collective=None):
         import torch
         self.n, self.od, self.world, self.group = n_local, obs_dim, world_size, group
+        self.force = _force_collective(force_collective)
         up = lambda b: (b + 15) // 16 * 16
         self.off_obs = 0
         self.off_rew = up(n_local * obs_dim * 4)
@@ -85,7 +96,7 @@ class PackedOutputs:
         """-> (obs [world, n, od], reward [world, n], terminated [world, n] u8, truncated u8):
         views of the gathered buffer, rank-major = global env-id order."""
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not (self.force and dist.is_initialized()):
             self.gathered[0].copy_(self.local)
         else:
             dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=self.group)
@@ -97,7 +108,7 @@ class ShardedCopterVecEnv:
     group.  step()/reset() take and return LOCAL rows unless gather is enabled."""
 
     def __init__(self, task="lander3d", total_envs=1, gather="none", group=None, device=None,
-                 env_id_offset=0, flat=True, **env_kwargs):
+                 env_id_offset=0, flat=True, force_collective=None, **env_kwargs):
         import torch.distributed as dist
         if gather not in ("none", "obs", "all"):
             raise ValueError("gather must be 'none', 'obs' or 'all'")
@@ -120,12 +131,12 @@ class ShardedCopterVecEnv:
         # sections of the packed per-rank chunks are not adjacent); flat=False returns the zero-copy
         # [world, n_local, ...] views of the gathered buffer, rank-major = global env-id order
         self.flat = bool(flat)
-        self._gather = ShardGather(self.n_local, self.world, group)
+        self._gather = ShardGather(self.n_local, self.world, group, force_collective)
         self._packed = None
         if gather == "all":
             import torch
             dev = getattr(self.local, "device", torch.device("cpu"))
-            self._packed = PackedOutputs(self.n_local, self.local.obs_dim, self.world, dev, group)
+            self._packed = PackedOutputs(self.n_local, self.local.obs_dim, self.world, dev, group, force_collective)
             if hasattr(self.local, "bind_outputs"):      # the kernel writes into the packed buffer
                 pk = self._packed
                 self.local.bind_outputs(pk.obs, pk.reward, pk.term, pk.trunc)

@@ -68,8 +68,8 @@ def test_ticks_through_env_steps_match_the_oracle(substeps):
     env.reset()
     orc.reset()
     rng = np.random.default_rng(4)
-    for t in range(160):
-        a = (HOVER * (0.97 + 0.04 * rng.random((n, 4)))).astype(np.float32)      # settle, land, some crash
+    for t in range(240):
+        a = (HOVER * (0.93 + 0.05 * rng.random((n, 1))) * np.ones((1, 4))).astype(np.float32)   # sink: soft landings and crashes
         if t % 3 == 0:
             got = env.step_many(torch.from_numpy(a[None]).to(env.device))
             want = orc.step(a.astype(np.float64))
@@ -362,3 +362,104 @@ def test_served_session_captured_in_a_hipgraph_replays():
     _assert_same_state(served, plain)
     served.close()
     plain.close()
+
+
+# ---------------------------------------------------------------------------------------
+# a REAL RCCL collective on the one GPU there is: a 1-rank nccl group whose
+# all-gathers are issued (force_collective) instead of being shortcut
+# ---------------------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_RCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import gym_copter_amd
+from gym_copter_amd.sharded import ShardedCopterVecEnv, ShardGather, PackedOutputs
+n = 4096
+calls = {"n": 0}
+real = dist.all_gather_into_tensor
+def counted(*a, **k):
+    calls["n"] += 1
+    return real(*a, **k)
+dist.all_gather_into_tensor = counted
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+acts = torch.rand((12, n, 4), generator=g, device="cuda") * 2 - 1
+for gather in ("obs", "all"):
+    plain = gym_copter_amd.CopterVecEnv("lander3d", n, seed=5, autoreset_mode="next_step")
+    env = ShardedCopterVecEnv("lander3d", total_envs=n, gather=gather, seed=5, autoreset_mode="next_step",
+                              force_collective=True)
+    assert env.world == 1 and env._gather.force
+    env.reset(); plain.reset()
+    before = calls["n"]
+    for t in range(12):                                   # eager: one RCCL all-gather per step
+        for u, v in zip(env.step(acts[t])[:4], plain.step(acts[t])[:4]):
+            assert torch.equal(u.reshape(v.shape), v), (gather, t)
+    assert calls["n"] - before == 12, calls
+    # the same step + collective captured into a hipGraph and replayed
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        env.step(acts[0]); plain.step(acts[0])
+    torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    captured = "graph"
+    try:
+        with torch.cuda.graph(graph):
+            out = env.step(acts[1])
+    except Exception as e:
+        captured = "refused: " + type(e).__name__
+        torch.cuda.synchronize()
+    if captured == "graph":
+        want = [x.clone() for x in plain.step(acts[1])[:4]]
+        graph.replay(); torch.cuda.synchronize()
+        for u, v in zip(out[:4], want):
+            assert torch.equal(u.reshape(v.shape), v), (gather, "replay")
+    print("RCCL_LEG", gather, captured)
+    env.close(); plain.close()
+ones = torch.ones(1, device="cuda"); dist.all_reduce(ones)
+assert int(ones.item()) == dist.get_world_size() == 1
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_a_real_rccl_all_gather_runs_on_one_gpu(tmp_path):
+    """force_collective=True: the 1-rank nccl group issues dist.all_gather_into_tensor (counted) for the
+    observation rows and for the packed outputs, eagerly and hipGraph-captured, with unchanged results."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl_child.py"
+    script.write_text(_RCCL_CHILD % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    legs = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("RCCL_LEG")]
+    assert [l[1] for l in legs] == ["obs", "all"]
+    print("RCCL capture:", legs)
+
+
+def test_bench_gather_on_one_gpu_reports_what_rccl_saw(tmp_path):
+    """`bench.py --gather` on one GPU without a launcher: it opens a 1-rank RCCL group itself, forces the
+    collectives, and the JSON line says what RCCL saw and which legs were captured."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--gather",
+           "--no-sweep", "--no-cpu-baseline", "--pid", "0", "--many", "0", "--served", "0", "--min-region-ms", "5",
+           "--regions", "3"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("COPTERSTEP_FORCE_COLLECTIVE", None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["rccl"] == {"backend": "nccl", "world_size": 1, "ranks_seen": 1}
+    assert d["allgather_is_a_collective"] is True
+    assert set(d["allgather_launch_mode"]) == {"obs", "packed", "pipelined"}
+    assert d["summary"]["rccl"] == d["rccl"] and list(d)[-1] == "summary"
+    assert d["timed_steps_total"] >= 3 * 20 and d["timed_region_s"] > 0
+    for k in ("value_with_allgather", "value_with_packed_allgather", "value_with_pipelined_allgather"):
+        assert 0 < d[k] <= d["value"] * 1.05, (k, d[k], d["value"])
