@@ -92,7 +92,7 @@ def parse(argv=None):
     p.add_argument("--no-sweep", action="store_true", help="skip the batch-size / task sweep and config 5")
     p.add_argument("--pid", type=int, default=100,
                    help="also time cs_rollout_pid / cs_rollout_random with this many steps per launch (0 = skip)")
-    p.add_argument("--served", type=int, default=100,
+    p.add_argument("--served", type=int, default=500,
                    help="also time served stepping (cs_serve_*) with this many steps per session (0 = skip)")
     p.add_argument("--many", type=int, default=100,
                    help="also time cs_step_many with this many steps per launch (0 = skip)")
@@ -250,7 +250,9 @@ class PipeStepper:
 class ServedSession:
     """K env steps as ONE served session (gym_copter_amd.CopterVecEnv.serve_*): cs_serve_begin leaves a
     persistent env kernel running, `body(s)` feeds step s (a policy kernel, or submit + collect kernels),
-    cs_serve_end joins.  The whole session is one hipGraph; run(count) replays it count // K times."""
+    cs_serve_end joins.  begin / end are eager calls (HIP may serialise the branches of one hipGraph, so the env
+    kernel must not sit in the same graph as its feeders); the K feeder launches are captured once and
+    replayed against every session.  run(count) runs count // K sessions back to back."""
 
     def __init__(self, torch, env, K, body, ring, use_graph=True):
         self.torch, self.env, self.K, self.body, self.ring = torch, env, K, body, ring
@@ -259,20 +261,28 @@ class ServedSession:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            self.session()                    # the first session allocates the rings: outside any capture
+            self.session()                    # the first session allocates the rings
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
         self.check()
         if use_graph:
+            env.serve_begin(K, ring=ring, timeout=5.0)      # feeders are captured against an open session ...
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.session()
+                for s in range(K):
+                    body(s)
+            self.graph.replay()                              # ... which this replay then feeds
+            env.serve_end()
+            self.check()
 
     def session(self):
         self.env.serve_begin(self.K, ring=self.ring, timeout=5.0)
-        for s in range(self.K):
-            self.body(s)
-        self.env.serve_end()
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            for s in range(self.K):
+                self.body(s)
+        self.env.serve_end(wait=False)
 
     def check(self):
         st = self.env.serve_status()
@@ -281,10 +291,7 @@ class ServedSession:
 
     def run(self, count):
         for _ in range(max(1, count // self.K)):
-            if self.graph is not None:
-                self.graph.replay()
-            else:
-                self.session()
+            self.session()
 
 
 class LaunchFloor:
@@ -498,6 +505,12 @@ def main(argv=None):
     a = parse(argv)
     if needs_self_launch(a.gpus, os.environ):
         sys.exit(self_launch(a, argv))
+
+    # stdout carries ONE JSON line and nothing else: from here on file descriptor 1 is stderr (RCCL's version
+    # banner, any library chatter, C stdio buffers flushed at exit), and the line goes to the saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -836,7 +849,8 @@ def main(argv=None):
     out["roofline"]["digest"] = digest
     out["summary"] = digest
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    os.close(real_stdout)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -792,10 +792,13 @@ int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_
   const size_t ctrl_bytes = 256, act_bytes = (size_t)ring * tiles * ap * 1024, out_bytes = (size_t)ring * tiles * op * 1024,
                init_bytes = (size_t)tiles * op * 1024, total = ctrl_bytes + act_bytes + out_bytes + init_bytes;
   if (out_bytes > 0xFFFFFFFFull) return fail(CS_ERR_ARG, "cs_serve_begin: ring too deep for this batch");
-  const bool cap = capturing(stream);
+  // HIP may run the branches of one hipGraph one after the other: an env kernel captured into the same graph as
+  // its feeders could be queued in front of them and wait for actions that can never come.  Sessions are opened
+  // and closed eagerly; what may be captured is everything between (the feeders).
+  if (capturing(stream))
+    return fail(CS_ERR_ARG, "cs_serve_begin: `stream` is being captured; open and close sessions eagerly and capture "
+                            "only the feeder launches between cs_serve_begin and cs_serve_end");
   if (ctx->serve_stream == nullptr || ctx->serve_bytes < total) {
-    if (cap)
-      return fail(CS_ERR_ARG, "cs_serve_begin: the first session of this size allocates; run one outside stream capture");
     if (ctx->serve_stream == nullptr) {
       CS_HIP(hipStreamCreateWithFlags(&ctx->serve_stream, hipStreamNonBlocking));
       CS_HIP(hipEventCreateWithFlags(&ctx->serve_fork, hipEventDisableTiming));
@@ -827,8 +830,8 @@ int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_
   v.act_dim = ad;
   v.num_envs = ctx->st.n;
   v.num_steps = (uint32_t)num_steps;
-  // every polled word (tags, control) is zeroed per session: tags are session-relative, so a replayed
-  // hipGraph of a whole session starts from clean rings
+  // every polled word (tags, control) is zeroed per session: tags are session-relative, so a hipGraph of the
+  // feeders of one session can be replayed against every later session
   CS_HIP(hipMemsetAsync(ctx->serve_mem, 0, total, stream));
   CS_HIP(hipEventRecord(ctx->serve_fork, stream));
   CS_HIP(hipStreamWaitEvent(ctx->serve_stream, ctx->serve_fork, 0));
@@ -897,13 +900,14 @@ int cs_serve_end(cs_ctx* ctx, void* stream_, int32_t* steps_done) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (!ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_end: no open session");
   hipStream_t stream = (hipStream_t)stream_;
+  if (capturing(stream)) return fail(CS_ERR_ARG, "cs_serve_end: `stream` is being captured (see cs_serve_begin)");
   DeviceGuard guard(ctx->cfg.device);
   hipError_t e = cs::launch_serve_stop(ctx->serve.ctrl, stream);  // behind everything the caller enqueued
   if (e != hipSuccess) return hip_fail(e, "cs_serve_end: kernel launch");
   CS_HIP(hipEventRecord(ctx->serve_join, ctx->serve_stream));
   CS_HIP(hipStreamWaitEvent(stream, ctx->serve_join, 0));
   ctx->serve_active = false;
-  if (capturing(stream)) return CS_OK;
+  if (steps_done == nullptr) return CS_OK;  // enqueue only: cs_serve_status reports later
   CS_HIP(hipStreamSynchronize(stream));
   return cs_serve_status(ctx, steps_done, nullptr, nullptr);
 }

@@ -515,7 +515,8 @@ class CopterVecEnv:
         device memory -- the policy <-> step() loop (reference lander.py:40-65) without a kernel launch
         per env step.  Feed it with serve_submit / serve_collect (plain tensors), serve_policy_pid (a
         policy kernel per step) or your own HIP kernels (include/copterstep_serve.h); close with
-        serve_end().  Enqueued on the current stream; the whole session may be captured into a graph.
+        serve_end().  Enqueued on the current stream.  serve_begin / serve_end are eager calls; the feeder
+        launches between them may be captured into a graph once and replayed against every later session.
         Returns the wire description (a _lib.ServeView)."""
         self._check_open()
         torch = _torch()
@@ -552,14 +553,14 @@ class CopterVecEnv:
         with _torch().cuda.device(self.device):
             _lib.check(self._lib.cs_serve_policy_pid(self._ctx, int(step), self._stream()))
 
-    def serve_end(self):
-        """Close the session: order the current stream behind the env kernel's exit and (outside graph
-        capture) wait for it.  -> steps every tile completed; raises CopterStepError(code ERR_TIMEOUT) if
-        a wavefront gave up waiting for its actions."""
+    def serve_end(self, wait=True):
+        """Close the session: order the current stream behind the env kernel's exit.  wait=True also waits for
+        it -> steps every tile completed; raises CopterStepError(code ERR_TIMEOUT) if a wavefront gave up
+        waiting for its actions.  wait=False only enqueues (-> None; serve_status() reports later)."""
         done = C.c_int32(-1)
         with _torch().cuda.device(self.device):
-            _lib.check(self._lib.cs_serve_end(self._ctx, self._stream(), C.byref(done)))
-        return done.value
+            _lib.check(self._lib.cs_serve_end(self._ctx, self._stream(), C.byref(done) if wait else None))
+        return done.value if wait else None
 
     def serve_status(self):
         """(steps completed by every tile, by the fastest tile, wavefronts that gave up) of the last

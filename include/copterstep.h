@@ -335,18 +335,21 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out); /* the values in effect */
  *       e.g. cs_serve_policy_pid(ctx, s, stream): out(s-1) -> PID heuristic -> act(s), one launch per step
  *       OR  cs_serve_submit(ctx, s, actions_dev, stream)  +  cs_serve_collect(ctx, s, obs, ..., stream)
  *           (plain [N,A] rows in, plain rows out: one small kernel each)
- *   cs_serve_end(ctx, stream, &steps_done)                    (stop,) join `stream` behind the env kernel
+ *   cs_serve_end(ctx, stream, &steps_done)                    stop word, join `stream` behind the env kernel
  *
  * What it costs and when it pays is measured in DESIGN.md section 8 (tools/serve_ubench.hip): a hand-off
  * between two wavefronts through device memory takes ~2 us on MI355X under this load, so a closed loop runs
  * at ~4.7 us per step against 6.5 us for policy kernel + cs_step; a caller with ONE plain kernel per step is
  * still best served by cs_step itself.
  *
- * All env wavefronts must be resident at once: num_envs <= cs_serve_max_envs().  A whole session (begin ..
- * end with everything between) may be captured into a hipGraph and replayed; cs_serve_begin must then be
- * captured too (the rings are zeroed by it).  Every wait on the device is bounded by timeout_s: a step whose
- * actions never arrive ends the session with CS_ERR_TIMEOUT from cs_serve_end / cs_serve_status, the env
- * state as of the last completed step of each tile, and *steps_done = the steps EVERY tile completed. */
+ * All env wavefronts must be resident at once: num_envs <= cs_serve_max_envs().  cs_serve_begin and
+ * cs_serve_end are eager calls (they refuse a stream that is being captured: HIP may run the branches of one
+ * hipGraph one after the other, and an env kernel queued in front of its own feeders would wait for ever);
+ * everything BETWEEN them may be captured once and replayed against every later session of the same shape
+ * (tags are session-relative and cs_serve_begin zeroes the rings).  Every wait on the device is bounded by
+ * timeout_s: a step whose actions never arrive ends the session with CS_ERR_TIMEOUT from cs_serve_end /
+ * cs_serve_status, the env state as of the last completed step of each tile, and *steps_done = the steps
+ * EVERY tile completed. */
 #define CS_SERVE_TAG_INIT 0x80000000u
 enum { CS_SERVE_CTRL_STOP = 0, CS_SERVE_CTRL_TIMEOUTS = 1, CS_SERVE_CTRL_SHORTFALL = 2, CS_SERVE_CTRL_MAXDONE = 3,
        CS_SERVE_CTRL_WORDS = 16 };
@@ -375,9 +378,9 @@ int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_de
  * these against a served session are bit-identical to cs_rollout_pid(K). */
 int cs_serve_policy_pid(cs_ctx* ctx, int32_t step, void* stream);
 /* Ask the env kernel to stop at the first step whose actions are not there, and order `stream` behind its
- * exit.  Outside stream capture it then synchronises `stream` and reports: CS_OK, or CS_ERR_TIMEOUT if a
- * wavefront gave up; *steps_done (nullable) = steps completed by every tile.  Inside a capture it only
- * enqueues (CS_OK); ask cs_serve_status after the replay. */
+ * exit.  With steps_done != NULL it then synchronises `stream` and reports: CS_OK, or CS_ERR_TIMEOUT if a
+ * wavefront gave up; *steps_done = steps completed by every tile.  With steps_done == NULL it only enqueues
+ * (CS_OK): the next session can be opened right behind it, and cs_serve_status reports when asked. */
 int cs_serve_end(cs_ctx* ctx, void* stream, int32_t* steps_done);
 int cs_serve_status(cs_ctx* ctx, int32_t* steps_done_min, int32_t* steps_done_max, int32_t* timeouts);
 
