@@ -266,13 +266,14 @@ class ServedSession:
         torch.cuda.synchronize()
         self.check()
         if use_graph:
-            env.serve_begin(K, ring=ring, timeout=5.0)      # feeders are captured against an open session ...
+            # captured while no session is open (torch's capture starts with a device-wide synchronize, which an
+            # open session's env kernel would sit out until its timeout); valid for every session of this shape
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 for s in range(K):
                     body(s)
-            self.graph.replay()                              # ... which this replay then feeds
-            env.serve_end()
+            self.session()
+            torch.cuda.synchronize()
             self.check()
 
     def session(self):

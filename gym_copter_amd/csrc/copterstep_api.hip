@@ -244,6 +244,10 @@ int check_ctx(const cs_ctx* ctx) {
 
 }  // namespace
 
+#ifdef CS_SPAN
+extern "C" int cs_debug_reset_spans(cs_ctx* ctx);
+#endif
+
 extern "C" {
 
 int cs_version(void) { return CS_ABI_VERSION; }
@@ -365,6 +369,10 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
     delete ctx;
     return fail(CS_ERR_MEMORY, "cs_create: device allocation failed");
   }
+#ifdef CS_SPAN
+  (void)hipMalloc((void**)&s.span, (size_t)cs::kSpanSlots * 2 * sizeof(unsigned long long));
+  (void)cs_debug_reset_spans(ctx);
+#endif
 #ifdef CS_STAMPS
   (void)hipMalloc((void**)&s.stamps, (size_t)s.ntiles * 8 * sizeof(unsigned long long));
   (void)hipMemset(s.stamps, 0, (size_t)s.ntiles * 8 * sizeof(unsigned long long));
@@ -372,6 +380,25 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   *out = ctx;
   return CS_OK;
 }
+
+#ifdef CS_SPAN
+// diagnostic build only (make span): {earliest wavefront start, latest wavefront end} per launch slot, 100 MHz ticks
+extern "C" int cs_debug_read_spans(cs_ctx* ctx, unsigned long long* host, uint32_t slots, void* stream) {
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  return hipMemcpy(host, ctx->st.span, (size_t)slots * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) ==
+                 hipSuccess ? 0 : -4;
+}
+extern "C" int cs_debug_reset_spans(cs_ctx* ctx) {
+  std::vector<unsigned long long> init((size_t)cs::kSpanSlots * 2);
+  for (size_t k = 0; k < init.size(); k += 2) {
+    init[k] = ~0ull;
+    init[k + 1] = 0ull;
+  }
+  ctx->st.span_slot = 0;
+  return hipMemcpy(ctx->st.span, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) ==
+                 hipSuccess ? 0 : -4;
+}
+#endif
 
 #ifdef CS_STAMPS
 // diagnostic build only: copy the [ntiles][8] stamp buffer to the host
@@ -467,6 +494,9 @@ int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream) {
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, *io, ctx->tune,
                                  (hipStream_t)stream);
+#ifdef CS_SPAN
+  ctx->st.span_slot = (ctx->st.span_slot + 1u) % cs::kSpanSlots;  // one slot per (eager) launch
+#endif
   if (e != hipSuccess) return hip_fail(e, "cs_step: kernel launch");
   return CS_OK;
 }
@@ -844,7 +874,7 @@ int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_
 
 int cs_serve_submit(cs_ctx* ctx, int32_t step, const float* actions_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
-  if (!ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_submit: no open session");
+  if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_submit: no session has been opened yet");
   if (actions_dev == nullptr || step < 0 || (uint32_t)step >= ctx->serve.num_steps)
     return fail(CS_ERR_ARG, "cs_serve_submit: actions_dev is required and step must be in [0, num_steps)");
   hipError_t e = cs::launch_serve_submit(ctx->serve, (uint32_t)step, actions_dev, (hipStream_t)stream);
@@ -855,7 +885,7 @@ int cs_serve_submit(cs_ctx* ctx, int32_t step, const float* actions_dev, void* s
 int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
                      uint8_t* truncated_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
-  if (!ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_collect: no open session");
+  if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_collect: no session has been opened yet");
   if (step < -1 || step >= (int32_t)ctx->serve.num_steps)
     return fail(CS_ERR_ARG, "cs_serve_collect: step must be in [-1, num_steps)");
   hipError_t e = cs::launch_serve_collect(ctx->serve, step, obs_dev, reward_dev, terminated_dev, truncated_dev,
@@ -866,7 +896,7 @@ int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_de
 
 int cs_serve_policy_pid(cs_ctx* ctx, int32_t step, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
-  if (!ctx->serve_active) return fail(CS_ERR_ARG, "cs_serve_policy_pid: no open session");
+  if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_policy_pid: no session has been opened yet");
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_serve_policy_pid: call cs_pid_configure first");
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_serve_policy_pid: the heuristic flies the 3D tasks only");

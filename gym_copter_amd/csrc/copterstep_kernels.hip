@@ -87,6 +87,7 @@ __device__ __forceinline__ void step_body(
   const bool valid = i < n;  // lanes past the end run on zeroed padding and never write out
   using TILE = TileIO<MODE, STREAM_STATE>;
   const TILE tile(s, tile_index, lane);
+  CS_SPAN_BEGIN();
   CS_STAMP(0);
 
   // ---- loads: 4 x 16 B (state, guards, counters) + prev_shaping + the action row ----
@@ -139,6 +140,7 @@ __device__ __forceinline__ void step_body(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   CS_STAMP(7);
+  CS_SPAN_END();
 }
 
 #define CS_STEP_ARGS                                                                                      \

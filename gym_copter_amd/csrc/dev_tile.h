@@ -22,6 +22,21 @@ namespace {
 #define CS_STAMP(slot) ((void)0)
 #endif
 
+#ifdef CS_SPAN
+#define CS_SPAN_BEGIN()                                                                                       \
+  do {                                                                                                        \
+    if (lane == 0 && s.span) atomicMin(s.span + 2 * (size_t)s.span_slot, __builtin_amdgcn_s_memrealtime());   \
+  } while (0)
+#define CS_SPAN_END()                                                                                         \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the wavefront's stores have been acknowledged */      \
+    if (lane == 0 && s.span) atomicMax(s.span + 2 * (size_t)s.span_slot + 1, __builtin_amdgcn_s_memrealtime()); \
+  } while (0)
+#else
+#define CS_SPAN_BEGIN() ((void)0)
+#define CS_SPAN_END() ((void)0)
+#endif
+
 constexpr int kBlock = 64;  // one wavefront = one tile = one workgroup (measured best at 65 536 envs: tools/ab.sh)
 constexpr int kWave = 64;
 

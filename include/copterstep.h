@@ -342,11 +342,14 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out); /* the values in effect */
  * at ~4.7 us per step against 6.5 us for policy kernel + cs_step; a caller with ONE plain kernel per step is
  * still best served by cs_step itself.
  *
+ * While a session is open its kernel is RUNNING: a device-wide synchronisation (hipDeviceSynchronize,
+ * torch.cuda.synchronize) waits for the session to end or time out; synchronise streams or events instead.
  * All env wavefronts must be resident at once: num_envs <= cs_serve_max_envs().  cs_serve_begin and
  * cs_serve_end are eager calls (they refuse a stream that is being captured: HIP may run the branches of one
  * hipGraph one after the other, and an env kernel queued in front of its own feeders would wait for ever);
- * everything BETWEEN them may be captured once and replayed against every later session of the same shape
- * (tags are session-relative and cs_serve_begin zeroes the rings).  Every wait on the device is bounded by
+ * the feeder launches of a session may be captured once -- also while no session is open: they are checked
+ * against the most recent cs_serve_begin -- and replayed against every later session of the same shape
+ * (num_steps, ring; tags are session-relative and cs_serve_begin zeroes the rings).  Every wait on the device is bounded by
  * timeout_s: a step whose actions never arrive ends the session with CS_ERR_TIMEOUT from cs_serve_end /
  * cs_serve_status, the env state as of the last completed step of each tile, and *steps_done = the steps
  * EVERY tile completed. */

@@ -267,7 +267,13 @@ def test_served_closed_loop_policy_kernel_equals_rollout_pid(task, heuristic):
     for k, (x, y) in enumerate(zip(outs, want)):
         assert torch.equal(x, y), k
     _assert_same_state(a, b)
-    assert np.array_equal(a.pid_get_state(), b.pid_get_state())
+    # controller state: the fused kernel restarts the controllers of an env that began a new episode in the LAST
+    # step before it stores them; the policy kernel does that when it next acts (step K, never launched here)
+    pa, pb = a.pid_get_state(), b.pid_get_state()
+    reset_last = to_np(outs[2][K - 2] | outs[3][K - 2])           # NEXT_STEP: done at K-2 => reset in step K-1
+    assert (pb[:, reset_last] == 0).all()
+    pa[:, reset_last] = 0
+    assert np.array_equal(pa, pb)
     a.close()
     b.close()
 
@@ -286,7 +292,7 @@ def test_served_session_gives_up_after_its_timeout_and_says_so():
         served.serve_submit(s, acts)
         served.serve_collect(s)
         plain.step(acts)
-    torch.cuda.synchronize()
+    torch.cuda.current_stream(served.device).synchronize()     # (a DEVICE-wide synchronize would wait for the session)
     t0 = time.perf_counter()
     status = served.serve_status()          # waits for the env kernel: it gives up after 0.25 s
     waited = time.perf_counter() - t0
@@ -350,15 +356,13 @@ def test_served_feeders_captured_in_a_hipgraph_replay_against_every_session():
         feed()
         assert served.serve_end() == K
         expect("eager")
-        served.serve_begin(K, ring=4, timeout=5.0)        # feeders captured against an open session
+        # the feeders of a session of this shape, captured while NO session is open (torch's capture begins
+        # with a device-wide synchronize, which an open session's env kernel would sit out until its timeout)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             feed()
             with pytest.raises(CopterStepError):          # sessions are not opened or closed inside a capture
-                served.serve_end()
-        graph.replay()
-        assert served.serve_end() == K
-        expect("first replay")
+                served.serve_begin(K, ring=4, timeout=5.0)
         for rep in range(3):
             for t in outs:
                 t.zero_()
