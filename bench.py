@@ -277,7 +277,7 @@ class ServedSession:
             self.check()
 
     def session(self):
-        self.env.serve_begin(self.K, ring=self.ring, timeout=5.0)
+        self.env.serve_begin(self.K, ring=self.ring, timeout=1.0)
         if self.graph is not None:
             self.graph.replay()
         else:
@@ -673,7 +673,12 @@ def main(argv=None):
                 if prepare is not None:
                     prepare()
                 env.reset()
+                print("bench.py: served leg %s: building" % name, file=sys.stderr, flush=True)
                 ses = ServedSession(torch, env, k, body, ring, use_graph)
+                ses.run(2 * k)                     # two sessions back to back, checked before anything is timed
+                torch.cuda.synchronize()
+                ses.check()
+                print("bench.py: served leg %s: timing" % name, file=sys.stderr, flush=True)
                 g = timer.measure(ses, max(k, a.steps // k * k), 2 * k, min_region_s, a.regions, quantum=k)
                 torch.cuda.synchronize()
                 ses.check()

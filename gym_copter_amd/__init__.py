@@ -35,3 +35,35 @@ def make(env_id, num_envs=1, **kwargs):
 
 def make_vec(env_id, num_envs=1, **kwargs):
     return make(env_id, num_envs=num_envs, **kwargs)
+
+
+def register_with_gymnasium(namespace="gym_copter_amd"):
+    """Register the ids above with Gymnasium when it is importable, as the reference registers 'Lander-v0'
+    (reference gym_copter/__init__.py:9-13): gymnasium.make_vec('gym_copter_amd/Lander-v0', num_envs=N) then
+    builds a CopterVecEnv through `vector_entry_point`.  Returns the ids registered ([] without gymnasium: it
+    is not a dependency, and it is absent from the image this was built in -- untested there)."""
+    try:
+        from gymnasium.envs.registration import register, registry
+    except Exception:
+        return []
+    done = []
+    for env_id, spec in _REGISTRY.items():
+        full = "%s/%s" % (namespace, env_id)
+        if full in registry:
+            done.append(full)
+            continue
+        try:
+            register(id=full, vector_entry_point="gym_copter_amd:_vector_entry_point",
+                     max_episode_steps=spec["max_steps"], kwargs={"copter_id": env_id})
+            done.append(full)
+        except Exception:
+            pass
+    return done
+
+
+def _vector_entry_point(copter_id, num_envs=1, **kwargs):
+    kwargs.pop("max_episode_steps", None)
+    return make(copter_id, num_envs=num_envs, **kwargs)
+
+
+_GYMNASIUM_IDS = register_with_gymnasium()

@@ -1,69 +1,54 @@
 #!/usr/bin/env python3
 """Copy the judged evidence of a profiling run from gpurun_out/ (scratch) into profiles/ (tracked).
 
-  python scripts/collect_profiles.py <prof_tag> <round>     # e.g. prof_r02a r02
+  python scripts/collect_profiles.py <prof_tag> <round>     # e.g. prof_r03a r03
 
-expects gpurun_out/<prof_tag>/ as written by scripts/profile_gpu.sh (incl. bench_unprofiled.json, the
-bench line of the same build taken without a profiler)."""
-import csv
+expects gpurun_out/<prof_tag>/ as written by scripts/profile_gpu.sh (incl. bench_unprofiled.json, the bench
+line of the same build taken without a profiler).  profiles/traffic.json is rewritten with the PMC traffic
+figures AND the stamp bench.py checks before it reports them: the commit and a hash of the kernel sources the
+figures were measured on (bench.kernel_source_hash)."""
 import glob
 import json
 import os
-import re
 import shutil
+import subprocess
 import sys
 
-import numpy as np
-
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
 prof, RND = sys.argv[1], sys.argv[2]
 P = os.path.join(R, "gpurun_out", prof)
 
 
 def one(pat):
-    return glob.glob(P + pat)[0]
+    f = glob.glob(P + pat)
+    return f[0] if f else None
 
 
-shutil.copy(one("/trace/*/*_kernel_stats.csv"), R + "/profiles/%s_kernel_stats_bench_default.csv" % RND)
-shutil.copy(one("/trace_4m/*/*_kernel_stats.csv"), R + "/profiles/%s_kernel_stats_4m_envs.csv" % RND)
-shutil.copy(P + "/summary.txt", R + "/profiles/%s_summary.txt" % RND)
-shutil.copy(P + "/summary.json", R + "/profiles/%s_summary.json" % RND)
+for src, dst in (("/trace/*/*_kernel_stats.csv", "kernel_stats_bench_default.csv"),
+                 ("/trace_4m/*/*_kernel_stats.csv", "kernel_stats_4m_envs.csv"),
+                 ("/trace_rccl/*/*_kernel_stats.csv", "kernel_stats_rccl_one_gpu.csv")):
+    f = one(src)
+    if f:
+        shutil.copy(f, R + "/profiles/%s_%s" % (RND, dst))
+for name in ("summary.txt", "summary.json"):
+    shutil.copy(P + "/" + name, R + "/profiles/%s_%s" % (RND, name))
 shutil.copy(P + "/bench_unprofiled.json", R + "/profiles/%s_bench_default.json" % RND)
+for f in sorted(glob.glob(P + "/span_*.json")):
+    shutil.copy(f, R + "/profiles/%s_%s" % (RND, os.path.basename(f)))
 
-rows = list(csv.DictReader(open(one("/trace/*/*_kernel_trace.csv"))))
-
-
-def durations(name):
-    rr = [r for r in rows if name in r["Kernel_Name"]]
-    return rr, np.array([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rr])
-
-
-rr, d = durations("step_kernel<0, 0, true, true, false, false, true>")
-line = ("step_kernel<Lander3D,F32G,LEAN,stream actions> dispatch durations from rocprofv3 --kernel-trace, "
-        "65 536 envs (ns): n=%d mean=%.1f median=%.1f min=%d max=%d p10=%d p90=%d\n"
-        % (len(d), d.mean(), np.median(d), d.min(), d.max(), np.percentile(d, 10), np.percentile(d, 90)))
-m = rr[0]
-line += "VGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s\n" % (
-    m["VGPR_Count"], m["SGPR_Count"], m["LDS_Block_Size"], m["Scratch_Size"], m["Grid_Size_X"], m["Workgroup_Size_X"])
-for name, desc in (("step_many_kernel<0, 0, true, 0,", "open loop, 64 steps per launch"),
-                   ("step_many_kernel<0, 0, true, 1,", "PID policy, 100 steps per launch"),
-                   ("step_many_kernel<0, 0, true, 2,", "random policy, 100 steps per launch")):
-    rr, dd = durations(name)
-    if len(dd):
-        line += "%s (%s): n=%d mean=%.0f ns  VGPR=%s SGPR=%s\n" % (name, desc, len(dd), dd.mean(),
-                                                                  rr[0]["VGPR_Count"], rr[0]["SGPR_Count"])
-open(R + "/profiles/%s_step_kernel_durations.txt" % RND, "w").write(line)
-print(line)
-
-txt = open(P + "/summary.txt").read()
-t = json.load(open(R + "/profiles/traffic.json"))
-for n, f, w in re.findall(r"N=\s*(\d+)\s+FETCH_SIZE=([\d.]+) KiB.*WRITE_SIZE=([\d.]+) KiB", txt):
-    t["lander3d_%s" % n] = (2 * float(f) + float(w)) * 1024
+import bench  # noqa: E402  (kernel_source_hash only; nothing touches a GPU)
+summ = json.load(open(P + "/summary.json"))
+commit = subprocess.run(["git", "-C", R, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+t = {"commit": commit, "kernel_source_sha16": bench.kernel_source_hash(),
+     "note": "HBM bytes per launch by rocprofv3 PMC: 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate passes (scripts/profile_gpu.sh); "
+             "bench.py reports a figure only while the kernel sources hash to kernel_source_sha16"}
+for k, v in summ.items():
+    if isinstance(v, (int, float)) and (k.startswith("lander3d_") or k.startswith("hover3d_")):
+        t[k] = v
 json.dump(t, open(R + "/profiles/traffic.json", "w"), indent=1)
-for ln in txt.splitlines():
-    if "step_kernel" in ln or "HIP-event" in ln or "FETCH" in ln or "step_many" in ln:
-        print(ln[:48], "...", ln[-74:])
+print(json.dumps(t, indent=1))
 b = json.load(open(P + "/bench_unprofiled.json"))
 print("bench default: %.2f G env-steps/s, %.3f us/step, frac %.3f" % (b["value"] / 1e9, b["ms_per_step"] * 1e3,
-                                                                    b["roofline"]["frac"]),
-      [(k, round(b[k]["value"] / 1e9, 2), round(b[k]["us_per_step"], 3)) for k in ("step_many", "rollout_pid", "rollout_random")])
+                                                                    b["roofline"]["frac"]))
+print(json.dumps(b.get("summary"), indent=1))

@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 CSVs written by scripts/profile_gpu.sh into a text summary and
-profiles-ready JSON (per-launch averages for the step kernel)."""
+"""Condense the rocprofv3 CSVs written by scripts/profile_gpu.sh into a text summary from which every roofline
+figure of bench.py can be recomputed by arithmetic (profiles/rNN_summary.txt) and profiles-ready JSON."""
 import collections
 import csv
 import glob
 import json
 import os
+import re
 import sys
+
+import numpy as np
 
 out = sys.argv[1]
 res = {}
+ALGO = 176          # algorithmic bytes per env-step, Lander3D and Hover3D
+PEAK = 8e12
 
 
 def find(sub, pat):
@@ -17,30 +22,84 @@ def find(sub, pat):
     return f[0] if f else None
 
 
-import re
-# the instantiations of the lean Lander3D kernel: <task, mode, lean, stream actions, stream state, prefetch, one call>
-HEADLINE = {"trace": "step_kernel<0, 0, true, true, false, false, true>",        # 65 536 envs
-            "trace_4m": "step_kernel<0, 0, true, false, true, false, true>"}     # 4 194 304 envs (streamed state)
-for sub, label in (("trace", "bench default command, 65 536 envs"), ("trace_4m", "4 194 304 envs")):
-    f = find(sub, "*kernel_stats.csv")
+def short(name):
+    name = re.sub(r"void cs::\(anonymous namespace\)::", "", name)
+    return re.sub(r"\(.*$", "", name)[:96]
+
+
+# the instantiations: step_kernel<task, mode, lean, stream actions, stream state, one call>
+TASKS = {"0": "lander3d", "1": "hover3d"}
+
+# ---- 1. kernel trace grouped by (kernel, grid): every sweep point has its own row --------------------------
+for sub, label in (("trace", "bench default command (65 536 envs + sweep + config 5 + K-step extras)"),
+                   ("trace_4m", "headline kernel alone, 4 194 304 envs"),
+                   ("trace_rccl", "bench.py --gather on one GPU: 1-rank RCCL group, collectives forced")):
+    f = find(sub, "*kernel_trace.csv")
     if not f:
         continue
-    print("== rocprofv3 --kernel-trace --stats (%s) ==" % label)
+    groups = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        print("%-110s calls=%6s avg_ns=%10s min=%8s max=%8s pct=%s" % (
-            r["Name"][:110], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
-        if HEADLINE[sub] in r["Name"]:
-            res[sub + "_step_kernel_avg_ns"] = float(r["AverageNs"])
-            res[sub + "_step_kernel_calls"] = int(r["Calls"])
+        groups[(r["Kernel_Name"], int(r["Grid_Size_X"]) if r.get("Grid_Size_X") else int(r.get("Grid_Size", 0)))].append(
+            int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    print("== rocprofv3 --kernel-trace, dispatches grouped by (kernel, grid size): %s ==" % label)
+    print("%-96s %10s %7s %10s %10s %10s   %s" % ("kernel", "grid", "calls", "mean_ns", "median_ns", "min_ns",
+                                                  "176 B x envs / mean / 8 TB/s"))
+    table = []
+    for (name, grid), d in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        d = np.array(d)
+        m = re.search(r"step_kernel<(\d), (\d), (true|false), (true|false), (true|false), (true|false)>", name)
+        frac = ""
+        if m and len(d) >= 20:
+            envs = grid          # one thread per env, whole tiles
+            frac = "%.3f" % (ALGO * envs / (d.mean() * 1e-9) / PEAK)
+            table.append({"kernel": short(name), "task": TASKS.get(m.group(1), m.group(1)), "one_call": m.group(6) == "true",
+                          "grid": grid, "calls": int(len(d)), "mean_ns": float(d.mean()), "median_ns": float(np.median(d)),
+                          "min_ns": float(d.min()), "frac_from_mean": float(frac)})
+        if sub == "trace_rccl" and not ("nccl" in name.lower() or "rccl" in name.lower() or "step_kernel" in name):
+            continue
+        if len(d) >= 20 or "nccl" in name.lower():
+            print("%-96s %10d %7d %10.0f %10.0f %10d   %s" % (short(name), grid, len(d), d.mean(), np.median(d), d.min(), frac))
+    res[sub + "_by_kernel_and_grid"] = table
+    if sub == "trace_rccl":
+        names = sorted({short(k[0]) for k in groups if "nccl" in k[0].lower() or "rccl" in k[0].lower()})
+        res["rccl_kernels_seen"] = names
+        print("   RCCL kernels in the trace: %s" % (names or "NONE"))
     log = os.path.join(out, sub + ".log")
     if os.path.exists(log):
-        m = re.search(r'"launch_us": ([0-9.]+)', open(log).read())
+        txt = open(log).read()
+        m = re.search(r'"launch_us": ([0-9.]+)', txt)
         if m:
             res[sub + "_hip_event_launch_us_in_profiled_run"] = float(m.group(1))
-            print("   bench.py's own HIP-event launch time in this (profiled) run: %s us" % m.group(1))
+            print("   bench.py's own HIP-event launch time of the headline in this (profiled) run: %s us" % m.group(1))
+        m = re.search(r'"allgather_launch_mode": (\{[^}]*\})', txt)
+        if m:
+            print("   all-gather legs captured as: %s" % m.group(1))
+        m = re.search(r'"rccl": (\{[^}]*\})', txt)
+        if m:
+            print("   rccl echo: %s" % m.group(1))
+    print()
+
+# ---- 2. the kernel's own duration, un-profiled (span build) -------------------------------------------------
+spans = sorted(glob.glob(os.path.join(out, "span_*.json")))
+if spans:
+    print("== kernel span per launch, un-profiled (tools/kernel_span.py: first wavefront start -> last wavefront end, 100 MHz clock) ==")
+    for f in spans:
+        try:
+            d = json.loads(open(f).read().strip().splitlines()[-1])
+        except Exception as e:
+            print("   %s: unreadable (%r)" % (os.path.basename(f), e))
+            continue
+        k = d["kernel_span_ns"]
+        key = "%s_%d%s" % (d["task"], d["envs"], "_substeps%d" % d["substeps"] if d["substeps"] > 1 else "")
+        res["span_" + key] = d
+        print("%-34s span median %7.0f ns (p10 %6.0f, p90 %6.0f, min %6.0f)  gap to next eager launch %6.0f ns  eager pace %.3f us/step"
+              "  -> 176 B x envs / span = %.3f of 8 TB/s" % (key, k["median"], k["p10"], k["p90"], k["min"],
+                                                        d["gap_between_eager_launches_ns"]["median"],
+                                                        d["eager_pace_us_per_step_hip_events"], d["frac_of_8TBps_over_the_span"]))
+    print()
 
 
-def counters(sub, kernel="step_kernel<0, 0, true"):
+def counters(sub, kernel):
     f = find(sub, "*counter_collection.csv")
     acc = collections.defaultdict(list)
     if f:
@@ -50,31 +109,48 @@ def counters(sub, kernel="step_kernel<0, 0, true"):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-print("\n== PMC, per launch of step_kernel (means) ==")
-for n in (65536, 4194304):
-    fs = counters("fetch_%d" % n).get("FETCH_SIZE")
-    ws = counters("write_%d" % n).get("WRITE_SIZE")
+# ---- 3. HBM traffic by PMC ------------------------------------------------------------------------------------
+print("== PMC, HBM traffic per launch of step_kernel (means; FETCH_SIZE doubled: the gfx950 correction of MI355X_MICROARCH.md) ==")
+for name, kern, n in (("lander3d_65536", "step_kernel<0, 0, true", 65536), ("lander3d_4194304", "step_kernel<0, 0, true", 4194304),
+                      ("hover3d_262144", "step_kernel<1, 0, true", 262144),
+                      ("lander3d_65536_substeps10", "step_kernel<0, 0, true", 65536)):
+    fs = counters("fetch_" + name, kern).get("FETCH_SIZE")
+    ws = counters("write_" + name, kern).get("WRITE_SIZE")
     if fs is None or ws is None:
         continue
-    # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
-    # exactly half of the bytes of a coalesced streaming read -> double it; WRITE_SIZE is exact.
-    fetch_b, write_b = 2 * fs * 1024, ws * 1024
-    algo = 176 * n
-    print("N=%8d  FETCH_SIZE=%.1f KiB (x2 corrected: %.2f MB)  WRITE_SIZE=%.1f KiB (%.2f MB)  "
-          "traffic=%.2f MB  algorithmic=%.2f MB  ratio=%.3f" % (
-              n, fs, fetch_b / 1e6, ws, write_b / 1e6, (fetch_b + write_b) / 1e6, algo / 1e6,
-              (fetch_b + write_b) / algo))
-    res["lander3d_%d" % n] = fetch_b + write_b
-    res["lander3d_%d_detail" % n] = {"fetch_bytes_corrected": fetch_b, "write_bytes": write_b,
-                                      "algorithmic_bytes": algo}
-for sub in ("sq1", "sq2", "l2"):
-    c = counters(sub)
+    fetch_b, write_b = 2 * fs * 1024, ws * 1024      # KiB -> bytes; FETCH_SIZE reads half of a wide coalesced stream
+    algo = ALGO * n
+    print("%-28s FETCH_SIZE=%.1f KiB (x2: %.2f MB)  WRITE_SIZE=%.1f KiB (%.2f MB)  traffic=%.2f MB  algorithmic=%.2f MB  ratio=%.3f"
+          % (name, fs, fetch_b / 1e6, ws, write_b / 1e6, (fetch_b + write_b) / 1e6, algo / 1e6, (fetch_b + write_b) / algo))
+    res[name] = fetch_b + write_b
+    res[name + "_detail"] = {"fetch_bytes_corrected": fetch_b, "write_bytes": write_b, "algorithmic_bytes": algo}
+print()
+
+# ---- 4. SQ counters -----------------------------------------------------------------------------------------------
+for tag, kern, label in (("", "step_kernel<0, 0, true", "headline: Lander3D 65 536"),
+                         ("_c5", "step_kernel<0, 0, true", "BASELINE configs[4]: Lander3D 65 536, 10 substeps, near hover"),
+                         ("_c3", "step_kernel<1, 0, true", "BASELINE configs[2]: Hover3D 262 144")):
+    c = {}
+    for sub in ("sq1" + tag, "sq2" + tag) + (("l2",) if tag == "" else ()):
+        c.update(counters(sub, kern))
+    if not c:
+        continue
+    print("== PMC, SQ / TCC counters per launch (%s) ==" % label)
     for k, v in sorted(c.items()):
         print("%-24s %14.1f" % (k, v))
-    res.update({"pmc_" + k: v for k, v in c.items()})
+    if c.get("SQ_WAVES"):
+        w = c["SQ_WAVES"]
+        per = {k: c[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+                                     "SQ_INSTS_LDS", "SQ_WAVE_CYCLES") if k in c}
+        print("per wavefront: " + "  ".join("%s %.1f" % (k.replace("SQ_INSTS_", "").replace("SQ_", ""), v) for k, v in per.items()))
+        if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+            print("SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f" % (c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]))
+        res["pmc_per_wave" + tag] = per
+    res.update({"pmc%s_%s" % (tag, k): v for k, v in c.items()})
+    print()
 
 # the K-step kernels of the same runs (bench.py extras): executed instructions per wavefront and env-step
-print("\n== PMC, K-step kernels: per wavefront and env-step ==")
+print("== PMC, K-step kernels: per wavefront and env-step ==")
 res["pmc_k_step"] = {}
 for name, label, k in (("step_many_kernel<0, 0, true, 0,", "open loop", 64),
                        ("step_many_kernel<0, 0, true, 1,", "PID policy", 100),

@@ -300,8 +300,11 @@ def test_served_session_gives_up_after_its_timeout_and_says_so():
     served._lib.cs_serve_end(served._ctx, served._stream(), None)
     with pytest.raises(CopterStepError) as ei:
         served.serve_begin(2, timeout=0.05)
-        served.serve_end()                  # nothing submitted at all
+        time.sleep(0.3)                     # nothing submitted at all, and nobody stops it in time
+        served.serve_end()
     assert ei.value.code == ERR_TIMEOUT
+    served.serve_begin(2, timeout=5.0)
+    assert served.serve_end() == 0          # closed at once: the stop word ends it, no timeout
     _assert_same_state(served, plain)
     for x, y in zip(served.step(acts)[:4], plain.step(acts)[:4]):
         assert torch.equal(x, y)

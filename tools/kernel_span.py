@@ -56,7 +56,7 @@ torch.cuda.synchronize()
 buf = np.zeros((L, 2), dtype=np.uint64)
 lib.cs_debug_read_spans(env._ctx, buf.ctypes.data_as(C.c_void_p), L, None)
 b = buf.astype(np.int64)                     # launch j after the reset used slot j
-ok = (b[:, 1] > 0) & (b[:, 0] < (1 << 62))
+ok = (buf[:, 1] > 0) & (buf[:, 0] != np.uint64(0xFFFFFFFFFFFFFFFF))
 span = (b[ok, 1] - b[ok, 0]) * 10.0          # ns
 gap = (b[ok, 0][1:] - b[ok, 1][:-1]) * 10.0  # ns between one launch's last end and the next one's first start
 out = {"task": task, "envs": N, "actions": law, "substeps": nsub, "launches": int(ok.sum()),
