@@ -507,6 +507,9 @@ def main(argv=None):
     if needs_self_launch(a.gpus, os.environ):
         sys.exit(self_launch(a, argv))
 
+    if os.environ.get("BENCH_DUMP_STACKS_AFTER_S"):     # diagnostic: where is the host when a run seems stuck?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_DUMP_STACKS_AFTER_S"]), repeat=True, file=sys.stderr)
     # stdout carries ONE JSON line and nothing else: from here on file descriptor 1 is stderr (RCCL's version
     # banner, any library chatter, C stdio buffers flushed at exit), and the line goes to the saved descriptor
     sys.stdout.flush()

@@ -830,7 +830,13 @@ int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_
                             "only the feeder launches between cs_serve_begin and cs_serve_end");
   if (ctx->serve_stream == nullptr || ctx->serve_bytes < total) {
     if (ctx->serve_stream == nullptr) {
-      CS_HIP(hipStreamCreateWithFlags(&ctx->serve_stream, hipStreamNonBlocking));
+      // The env kernel must never share a hardware queue with a stream that feeds it: HIP multiplexes streams
+      // onto a few hardware queues, and a feeder queued behind the persistent kernel would wait for it while it
+      // waits for the feeder.  Queues are per priority level: the env kernel's stream is the context's only
+      // high-priority stream, the feeders' streams are the caller's (default priority).
+      int least = 0, greatest = 0;
+      CS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      CS_HIP(hipStreamCreateWithPriority(&ctx->serve_stream, hipStreamNonBlocking, greatest));
       CS_HIP(hipEventCreateWithFlags(&ctx->serve_fork, hipEventDisableTiming));
       CS_HIP(hipEventCreateWithFlags(&ctx->serve_join, hipEventDisableTiming));
     }

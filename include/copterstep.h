@@ -342,6 +342,10 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out); /* the values in effect */
  * at ~4.7 us per step against 6.5 us for policy kernel + cs_step; a caller with ONE plain kernel per step is
  * still best served by cs_step itself.
  *
+ * The env kernel runs on a HIGH-PRIORITY stream of the context's own, so that it never shares a hardware
+ * queue with the streams that feed it (HIP multiplexes streams onto a few hardware queues per priority level; a
+ * feeder queued behind the persistent kernel would wait for it while it waits for the feeder): feed a session
+ * from default-priority streams.
  * While a session is open its kernel is RUNNING: a device-wide synchronisation (hipDeviceSynchronize,
  * torch.cuda.synchronize) waits for the session to end or time out; synchronise streams or events instead.
  * All env wavefronts must be resident at once: num_envs <= cs_serve_max_envs().  cs_serve_begin and

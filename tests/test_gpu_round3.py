@@ -508,3 +508,28 @@ def test_pure_relative_parity_per_component(mode):
     over = {pr.NAMES[k]: int(v) for k, v in enumerate(rep["over_bar"]) if v}
     assert set(over) <= {"z", "dx", "dy", "dz", "x", "y"} and "z" in over, over
     assert rep["worst"][4] < 1e-3 and (rep["worst"][6:] <= pr.BAR).all()
+
+
+def test_served_session_fed_from_many_streams():
+    """HIP multiplexes streams onto a few hardware queues; a feeder stream that shared the env kernel's queue would
+    sit behind the persistent kernel and dead-lock the session.  The env kernel's stream is the only
+    high-priority stream: sessions fed from 24 different default-priority streams all complete."""
+    import torch
+    n, K = 4096, 12
+    served, plain = _twin("lander3d", n, "float32", autoreset_mode="next_step")
+    acts = torch.rand((K, n, 4), device=served.device) * 2 - 1
+    streams = [torch.cuda.Stream(device=served.device) for _ in range(24)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(served.device))
+        with torch.cuda.stream(st):
+            served.serve_begin(K, ring=2, timeout=0.5)
+            for s in range(K):
+                served.serve_submit(s, acts[s])
+                served.serve_collect(s)
+            assert served.serve_end() == K
+        torch.cuda.current_stream(served.device).wait_stream(st)
+        for s in range(K):
+            plain.step(acts[s])
+    _assert_same_state(served, plain)
+    served.close()
+    plain.close()
