@@ -198,11 +198,38 @@ __device__ __forceinline__ bool free_flight(int fs, const double (&x)[12]) {
          fabs(x[10]) < 0.785;
 }
 
+// Will free_flight() hold at EVERY call of the next T seconds?  A sufficient test on the state before them
+// (all bounds hold for the forward-Euler iterates as well as for the flow: each increment is dt times an
+// expression bounded here):
+//   contact   z can rise by at most T (|dz| + T A), A = |bz| + |G| >= |netz|  (NED: the ground is z = 0, flying z < 0)
+//   rates     S = max |rate| obeys S' <= C S^2 + g S + a (state derivative, :275-289): if S0 + T (C Sb^2 + g Sb + a)
+//             <= Sb for the trial bound Sb = 2 (S0 + T a), then S <= Sb throughout (continuation)
+//   angles    each moves by at most T Sb
+// A lane that fails (close to the ground, spinning fast, NaN anywhere) sends its wavefront to the per-call test.
+template <bool GYRO>
+__device__ __forceinline__ bool flight_assured(const Coef& q, const Wrench& w, int fs, const double (&x)[12], double T) {
+  const double A = fabs(w.bz) + fabs(q.G);
+  const bool no_contact = fma(T, fma(T, A, fabs(x[5])), x[4]) < 0.0;
+  const double S0 = fmax(fmax(fabs(x[7]), fabs(x[9])), fabs(x[11]));
+  const double a = fmax(fmax(fabs(w.aphi), fabs(w.athe)), fabs(w.apsi));
+  const double C = fmax(fmax(fabs(q.c_dphi), fabs(q.c_dthe)), fabs(q.c_dpsi));
+  const double Sb = 2.0 * fma(T, a, S0);
+  double grow = fma(C * Sb, Sb, a);
+  if constexpr (GYRO) grow = fma((fabs(q.g_phi) + fabs(q.g_the)) * fabs(w.om), Sb, grow);
+  const bool rates_ok = fma(T, grow, S0) <= Sb;
+  const double ang = fmax(fmax(fabs(x[6]), fabs(x[8])), fabs(x[10]));
+  const bool angles_ok = fma(T, Sb, ang) < 0.785;
+  const bool finite = (x[6] == x[6]) && (x[8] == x[8]) && (x[10] == x[10]) && (S0 == S0) && (x[7] == x[7]) &&
+                      (x[9] == x[9]) && (x[11] == x[11]);
+  return fs == CS_STATUS_AIRBORNE && no_contact && rates_ok && angles_ok && finite;
+}
+
 // `nsub` x Dynamics.setMotors with one wrench.  The pending perturbation can only enter the FIRST
 // call: a call that freezes on ground contact keeps it, but the status it leaves (CRASHED / LEVELING)
 // makes the next call drop it.  So the first call is the general one (perturbation, status machine) and
 // the calls after it run without a perturbation -- as the free-flight form whenever the whole wavefront
-// qualifies (the usual case of an integration-bound workload: BASELINE configs[4] flies near hover).
+// qualifies (the usual case of an integration-bound workload: BASELINE configs[4] flies near hover): with no
+// test at all when flight_assured() vouches for all of them, else tested call by call.
 // Returns the calls that ticked (Dynamics._ticks, :197: every call but a ground-contact freeze).
 template <bool FULL, bool GYRO, bool ONE_CALL, bool IN_LOOP = false>
 __device__ __forceinline__ uint32_t physics_substeps(const DevConst& c, const Coef& q, const Wrench& w,
@@ -222,6 +249,12 @@ __device__ __forceinline__ uint32_t physics_substeps(const DevConst& c, const Co
   // would pay for the register shuffling of the merge.  A wavefront that leaves free flight (a lane touches
   // down, an angle leaves the reduction-free range) finishes the step in the general form.
   int sub = 1;
+  // every lane provably in free flight for all the remaining calls: no per-call test at all
+  if (sub < c.nsub && __all(flight_assured<GYRO>(q, w, fs, x, (double)(c.nsub - 1) * c.dt))) {
+#pragma clang loop unroll(disable)
+    for (; sub < c.nsub; ++sub) physics_flight<FULL, GYRO>(c, q, w, x);
+    return ticked + (uint32_t)(c.nsub - 1);
+  }
   if (sub < c.nsub && __all(free_flight(fs, x))) {
 #pragma clang loop unroll(disable)
     do {
