@@ -94,6 +94,8 @@ def parse(argv=None):
                    help="also time cs_rollout_pid / cs_rollout_random with this many steps per launch (0 = skip)")
     p.add_argument("--served", type=int, default=500,
                    help="also time served stepping (cs_serve_*) with this many steps per session (0 = skip)")
+    p.add_argument("--served-graph", type=int, default=-1, help="diagnostic: feeders of the served legs from a hipGraph (1) "
+                   "or eagerly (0); default: as the headline")
     p.add_argument("--many", type=int, default=100,
                    help="also time cs_step_many with this many steps per launch (0 = skip)")
     p.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
@@ -257,12 +259,7 @@ class ServedSession:
     def __init__(self, torch, env, K, body, ring, use_graph=True):
         self.torch, self.env, self.K, self.body, self.ring = torch, env, K, body, ring
         self.graph = None
-        dev = env.device
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            self.session()                    # the first session allocates the rings
-        torch.cuda.current_stream(dev).wait_stream(side)
+        self.session()                        # the first session allocates the rings
         torch.cuda.synchronize()
         self.check()
         if use_graph:
@@ -567,6 +564,10 @@ def main(argv=None):
                            substeps=a.substeps, env_id_base=rank * n)
     actions = make_actions(torch, a.actions, a.ring, n, device, 1234 + rank)
     env.reset()
+    # streams for the served legs, created BEFORE any hipGraph is captured: on MI355X / ROCm 7 a stream created once
+    # graphs have been instantiated is served several times more slowly by the hardware scheduler (DESIGN.md section 8;
+    # the env kernel's own stream is created with the context for the same reason)
+    served_side = [torch.cuda.Stream(device=device) for _ in (0, 1)] if a.served > 0 else None
     use_graph = not a.no_graph
     chunk = graph_chunk_for(a.steps, a.graph_chunk)
     stepper = Stepper(torch, env, actions, use_graph, chunk, prefetch=bool(a.prefetch), produce=a.produce_actions)
@@ -663,7 +664,7 @@ def main(argv=None):
         k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 136.0 / k,
                    "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
                    "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)")
-    if a.served > 0:
+    def served_legs():
         # served stepping (cs_serve_*): ONE persistent env kernel per K-step session, the env state in
         # registers throughout; action rows in and result rows out as tagged 16-byte granules through device
         # memory.  Reported beside the headline with their own byte models (what crosses memory per env-step).
@@ -677,7 +678,7 @@ def main(argv=None):
                     prepare()
                 env.reset()
                 print("bench.py: served leg %s: building" % name, file=sys.stderr, flush=True)
-                ses = ServedSession(torch, env, k, body, ring, use_graph)
+                ses = ServedSession(torch, env, k, body, ring, use_graph if a.served_graph < 0 else bool(a.served_graph))
                 ses.run(2 * k)                     # two sessions back to back, checked before anything is timed
                 torch.cuda.synchronize()
                 ses.check()
@@ -712,7 +713,7 @@ def main(argv=None):
                    "plain tensors in and out: cs_serve_submit + cs_serve_collect per step (two small launches on one "
                    "stream) against the persistent env kernel; bit-identical to cs_step "
                    "(tests/test_gpu_round3.py::test_served_steps_are_bit_identical_to_cs_step)")
-        side = [torch.cuda.Stream(device=device) for _ in (0, 1)]
+        side = served_side
 
         def submit_two_streams(s):
             # no launch dependency between consecutive producers: even / odd steps on two streams
@@ -727,6 +728,8 @@ def main(argv=None):
                    "producers that run ahead of the env (open-loop rows submitted from two alternating streams, only ring "
                    "back-pressure; outputs left in the output ring for a device-side consumer): what the persistent env "
                    "kernel sustains when it never waits for a policy")
+    if a.served > 0:
+        served_legs()
     env.close()
     del stepper, env, actions
     torch.cuda.empty_cache()

@@ -247,6 +247,9 @@ int check_ctx(const cs_ctx* ctx) {
 #ifdef CS_SPAN
 extern "C" int cs_debug_reset_spans(cs_ctx* ctx);
 #endif
+namespace {
+int serve_make_stream(cs_ctx* ctx);
+}
 
 extern "C" {
 
@@ -368,6 +371,10 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
     if (s.tiles) (void)hipFree(s.tiles);
     delete ctx;
     return fail(CS_ERR_MEMORY, "cs_create: device allocation failed");
+  }
+  if (serve_make_stream(ctx) != CS_OK) {  // best effort here; cs_serve_begin tries again and reports
+    (void)hipGetLastError();
+    ctx->serve_stream = nullptr;
   }
 #ifdef CS_SPAN
   (void)hipMalloc((void**)&s.span, (size_t)cs::kSpanSlots * 2 * sizeof(unsigned long long));
@@ -781,6 +788,25 @@ int serve_read_ctrl(cs_ctx* ctx, uint32_t (&w)[CS_SERVE_CTRL_WORDS]) {
 
 }  // namespace
 
+namespace {
+// The env kernel's stream.  It must never share a hardware queue with a stream that feeds it: HIP multiplexes
+// streams onto a few hardware queues, and a feeder queued behind the persistent kernel would wait for it while it
+// waits for the feeder.  Two measures: (1) queues are per priority level -- this is the context's only
+// high-priority stream, the feeders' streams are the caller's (default priority); (2) it is created WITH the
+// context, i.e. normally before the process captures hipGraphs or opens many streams: a stream created late, once
+// graphs have been instantiated, was measured to be served 4-5x more slowly by the hardware scheduler on MI355X /
+// ROCm 7.
+int serve_make_stream(cs_ctx* ctx) {
+  if (ctx->serve_stream != nullptr) return CS_OK;
+  int least = 0, greatest = 0;
+  CS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  CS_HIP(hipStreamCreateWithPriority(&ctx->serve_stream, hipStreamNonBlocking, greatest));
+  CS_HIP(hipEventCreateWithFlags(&ctx->serve_fork, hipEventDisableTiming));
+  CS_HIP(hipEventCreateWithFlags(&ctx->serve_join, hipEventDisableTiming));
+  return CS_OK;
+}
+}  // namespace
+
 int cs_serve_max_envs(const cs_ctx* cctx, int64_t* out) {
   cs_ctx* ctx = const_cast<cs_ctx*>(cctx);
   if (check_ctx(ctx) || out == nullptr) return fail(CS_ERR_ARG, "cs_serve_max_envs: null argument");
@@ -829,17 +855,7 @@ int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_
     return fail(CS_ERR_ARG, "cs_serve_begin: `stream` is being captured; open and close sessions eagerly and capture "
                             "only the feeder launches between cs_serve_begin and cs_serve_end");
   if (ctx->serve_stream == nullptr || ctx->serve_bytes < total) {
-    if (ctx->serve_stream == nullptr) {
-      // The env kernel must never share a hardware queue with a stream that feeds it: HIP multiplexes streams
-      // onto a few hardware queues, and a feeder queued behind the persistent kernel would wait for it while it
-      // waits for the feeder.  Queues are per priority level: the env kernel's stream is the context's only
-      // high-priority stream, the feeders' streams are the caller's (default priority).
-      int least = 0, greatest = 0;
-      CS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      CS_HIP(hipStreamCreateWithPriority(&ctx->serve_stream, hipStreamNonBlocking, greatest));
-      CS_HIP(hipEventCreateWithFlags(&ctx->serve_fork, hipEventDisableTiming));
-      CS_HIP(hipEventCreateWithFlags(&ctx->serve_join, hipEventDisableTiming));
-    }
+    if (int rc = serve_make_stream(ctx)) return rc;
     if (ctx->serve_bytes < total) {
       CS_HIP(hipStreamSynchronize(ctx->serve_stream));
       if (ctx->serve_mem) (void)hipFree(ctx->serve_mem);
@@ -916,7 +932,8 @@ int cs_serve_policy_pid(cs_ctx* ctx, int32_t step, void* stream) {
 
 int cs_serve_status(cs_ctx* ctx, int32_t* steps_done_min, int32_t* steps_done_max, int32_t* timeouts) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
-  if (ctx->serve_stream == nullptr) return fail(CS_ERR_ARG, "cs_serve_status: no session was ever opened");
+  if (ctx->serve_stream == nullptr || ctx->serve.num_steps == 0)
+    return fail(CS_ERR_ARG, "cs_serve_status: no session was ever opened");
   DeviceGuard guard(ctx->cfg.device);
   CS_HIP(hipStreamSynchronize(ctx->serve_stream));
   uint32_t w[CS_SERVE_CTRL_WORDS];

@@ -66,3 +66,72 @@ for name, body in (("submit+collect", lambda s: (env.serve_submit(s, acts[s % 8]
     torch.cuda.current_stream(env.device).synchronize()
     print("%-34s %8.3f us/step  status %r" % (name + " 20 sessions", (time.perf_counter() - t0) / (20 * K) * 1e6,
                                               env.serve_status()), flush=True)
+
+# ---- what in bench.py's flow makes graph-replayed feeders slow?  one experiment per line ----------------------
+body = lambda s: env.serve_policy_pid(s)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    for s in range(K):
+        body(s)
+
+
+def sessions(label, count=10, timeout=0.2, events=False, sync_each=False):
+    env.reset()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    if events:
+        e0.record()
+    for _ in range(count):
+        env.serve_begin(K, ring=ring, timeout=timeout)
+        g.replay()
+        env.serve_end(wait=False)
+        if sync_each:
+            torch.cuda.current_stream(env.device).synchronize()
+    if events:
+        e1.record()
+    torch.cuda.current_stream(env.device).synchronize()
+    print("%-44s %8.3f us/step  status %r" % (label, (time.perf_counter() - t0) / (count * K) * 1e6, env.serve_status()),
+          flush=True)
+
+
+sessions("A plain")
+sessions("B timing events around")
+sessions("B timing events around", events=True)
+sessions("C timeout 1.0", timeout=1.0)
+other = torch.zeros(65536, device=env.device)
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2):
+    for _ in range(100):
+        other.add_(1.0)
+for _ in range(50):
+    g2.replay()
+torch.cuda.synchronize()
+sessions("D after another torch graph was replayed")
+side = torch.cuda.Stream(device=env.device)
+with torch.cuda.stream(side):
+    sessions("E on a side stream")
+sessions("F again plain")
+
+# G: as bench.py does it: the SAME env first stepped from a captured hipGraph of cs_step launches
+acts64 = torch.rand((64, n, 4), device=env.device) * 2 - 1
+s2 = torch.cuda.Stream(device=env.device)
+s2.wait_stream(torch.cuda.current_stream(env.device))
+with torch.cuda.stream(s2):
+    for j in range(3):
+        env.step(acts64[j])
+torch.cuda.current_stream(env.device).wait_stream(s2)
+g3 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g3):
+    for j in range(100):
+        env.step(acts64[j % 64])
+for _ in range(30):
+    g3.replay()
+torch.cuda.synchronize()
+sessions("G after a cs_step graph on the same env")
+g4 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g4, capture_error_mode="thread_local"):
+    for s in range(K):
+        body(s)
+g = g4
+sessions("H feeders re-captured after that")
