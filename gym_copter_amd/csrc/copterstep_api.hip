@@ -248,8 +248,24 @@ int check_ctx(const cs_ctx* ctx) {
 extern "C" int cs_debug_reset_spans(cs_ctx* ctx);
 #endif
 namespace {
-int serve_make_stream(cs_ctx* ctx);
+// The env kernel's stream.  It must never share a hardware queue with a stream that feeds it: HIP multiplexes
+// streams onto a few hardware queues, and a feeder queued behind the persistent kernel would wait for it while it
+// waits for the feeder.  Two measures: (1) queues are per priority level -- this is the context's only
+// high-priority stream, the feeders' streams are the caller's (default priority); (2) it is created WITH the
+// context, i.e. normally before the process captures hipGraphs or opens many streams: a stream created late, once
+// graphs have been instantiated, was measured to be served 4-5x more slowly by the hardware scheduler on MI355X /
+// ROCm 7 (DESIGN.md section 8).
+int serve_make_stream(cs_ctx* ctx) {
+  if (ctx->serve_stream != nullptr) return CS_OK;
+  int least = 0, greatest = 0;
+  CS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  CS_HIP(hipStreamCreateWithPriority(&ctx->serve_stream, hipStreamNonBlocking, greatest));
+  CS_HIP(hipEventCreateWithFlags(&ctx->serve_fork, hipEventDisableTiming));
+  CS_HIP(hipEventCreateWithFlags(&ctx->serve_join, hipEventDisableTiming));
+  return CS_OK;
 }
+}  // namespace
+
 
 extern "C" {
 
@@ -786,25 +802,6 @@ int serve_read_ctrl(cs_ctx* ctx, uint32_t (&w)[CS_SERVE_CTRL_WORDS]) {
   return CS_OK;
 }
 
-}  // namespace
-
-namespace {
-// The env kernel's stream.  It must never share a hardware queue with a stream that feeds it: HIP multiplexes
-// streams onto a few hardware queues, and a feeder queued behind the persistent kernel would wait for it while it
-// waits for the feeder.  Two measures: (1) queues are per priority level -- this is the context's only
-// high-priority stream, the feeders' streams are the caller's (default priority); (2) it is created WITH the
-// context, i.e. normally before the process captures hipGraphs or opens many streams: a stream created late, once
-// graphs have been instantiated, was measured to be served 4-5x more slowly by the hardware scheduler on MI355X /
-// ROCm 7 (DESIGN.md section 8).
-int serve_make_stream(cs_ctx* ctx) {
-  if (ctx->serve_stream != nullptr) return CS_OK;
-  int least = 0, greatest = 0;
-  CS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-  CS_HIP(hipStreamCreateWithPriority(&ctx->serve_stream, hipStreamNonBlocking, greatest));
-  CS_HIP(hipEventCreateWithFlags(&ctx->serve_fork, hipEventDisableTiming));
-  CS_HIP(hipEventCreateWithFlags(&ctx->serve_join, hipEventDisableTiming));
-  return CS_OK;
-}
 }  // namespace
 
 int cs_serve_max_envs(const cs_ctx* cctx, int64_t* out) {
