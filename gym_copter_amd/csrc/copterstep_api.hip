@@ -393,7 +393,7 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
     ctx->serve_stream = nullptr;
   }
 #ifdef CS_SPAN
-  (void)hipMalloc((void**)&s.span, (size_t)cs::kSpanSlots * 2 * sizeof(unsigned long long));
+  (void)hipMalloc((void**)&s.span, (size_t)cs::kSpanLaunches * s.ntiles * 2 * sizeof(unsigned long long));
   (void)cs_debug_reset_spans(ctx);
 #endif
 #ifdef CS_STAMPS
@@ -405,20 +405,15 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
 }
 
 #ifdef CS_SPAN
-// diagnostic build only (make span): {earliest wavefront start, latest wavefront end} per launch slot, 100 MHz ticks
-extern "C" int cs_debug_read_spans(cs_ctx* ctx, unsigned long long* host, uint32_t slots, void* stream) {
+// diagnostic build only (make span): {start, end} of every wavefront of the last `launches` launches, 100 MHz ticks
+extern "C" int cs_debug_read_spans(cs_ctx* ctx, unsigned long long* host, uint32_t launches, void* stream) {
   (void)hipStreamSynchronize((hipStream_t)stream);
-  return hipMemcpy(host, ctx->st.span, (size_t)slots * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) ==
-                 hipSuccess ? 0 : -4;
+  return hipMemcpy(host, ctx->st.span, (size_t)launches * ctx->st.ntiles * 2 * sizeof(unsigned long long),
+                   hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }
 extern "C" int cs_debug_reset_spans(cs_ctx* ctx) {
-  std::vector<unsigned long long> init((size_t)cs::kSpanSlots * 2);
-  for (size_t k = 0; k < init.size(); k += 2) {
-    init[k] = ~0ull;
-    init[k + 1] = 0ull;
-  }
   ctx->st.span_slot = 0;
-  return hipMemcpy(ctx->st.span, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) ==
+  return hipMemset(ctx->st.span, 0, (size_t)cs::kSpanLaunches * ctx->st.ntiles * 2 * sizeof(unsigned long long)) ==
                  hipSuccess ? 0 : -4;
 }
 #endif
@@ -518,7 +513,7 @@ int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream) {
   hipError_t e = cs::launch_step(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, *io, ctx->tune,
                                  (hipStream_t)stream);
 #ifdef CS_SPAN
-  ctx->st.span_slot = (ctx->st.span_slot + 1u) % cs::kSpanSlots;  // one slot per (eager) launch
+  ctx->st.span_slot = (ctx->st.span_slot + 1u) % cs::kSpanLaunches;  // one slot per (eager) launch
 #endif
   if (e != hipSuccess) return hip_fail(e, "cs_step: kernel launch");
   return CS_OK;

@@ -168,7 +168,7 @@ constexpr int kPidRows = 4 * kPidControllers;
 // per-env vehicle / world coefficient columns (cs_set_vehicle_params): rows of DevState::veh
 constexpr int kCoefRows = 11;  // k_thrust, k_roll, k_pitch, k_yaw, G, c_dphi, c_dthe, c_dpsi, two_inv_M, g_phi, g_the
 
-constexpr uint32_t kSpanSlots = 1u << 16;
+constexpr uint32_t kSpanLaunches = 256;
 struct DevState {
   char* tiles;      // ntiles * tile_bytes
   uint32_t n;       // envs
@@ -180,10 +180,11 @@ struct DevState {
   unsigned long long* stamps;  // diagnostic build: [ntiles][8] shader-clock stamps
 #endif
 #ifdef CS_SPAN
-  // diagnostic build (make span): per LAUNCH, the earliest wavefront start and the latest wavefront end on the
-  // chip-wide 100 MHz clock (s_memrealtime), gathered with two atomics per wavefront -- the phases of the
-  // kernel are NOT serialised, so the span is the kernel's own duration without the launch gap around it
-  unsigned long long* span;    // [kSpanSlots][2]: {min start, max end}
+  // diagnostic build (make span): every wavefront of every launch notes the chip-wide 100 MHz clock
+  // (s_memrealtime) when it starts and when its stores have been acknowledged, into ITS OWN slot (two plain
+  // 8-byte stores; no atomics: 1 024 atomics on one address serialise to ~12 us).  The phases of the kernel are
+  // NOT serialised; the host takes min(start) / max(end) per launch: the kernel's own duration on the chip.
+  unsigned long long* span;    // [kSpanLaunches][ntiles][2]: {start, end}
   uint32_t span_slot;          // this launch's slot (set by the host per eager launch)
 #endif
 };

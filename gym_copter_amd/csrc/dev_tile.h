@@ -23,14 +23,15 @@ namespace {
 #endif
 
 #ifdef CS_SPAN
-#define CS_SPAN_BEGIN()                                                                                       \
-  do {                                                                                                        \
-    if (lane == 0 && s.span) atomicMin(s.span + 2 * (size_t)s.span_slot, __builtin_amdgcn_s_memrealtime());   \
-  } while (0)
+#define CS_SPAN_BEGIN() const unsigned long long span_t0_ = __builtin_amdgcn_s_memrealtime()
 #define CS_SPAN_END()                                                                                         \
   do {                                                                                                        \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the wavefront's stores have been acknowledged */      \
-    if (lane == 0 && s.span) atomicMax(s.span + 2 * (size_t)s.span_slot + 1, __builtin_amdgcn_s_memrealtime()); \
+    if (lane == 0 && s.span) {                                                                                \
+      unsigned long long* sp_ = s.span + ((size_t)s.span_slot * s.ntiles + tile_index) * 2;                   \
+      sp_[0] = span_t0_;                                                                                      \
+      sp_[1] = __builtin_amdgcn_s_memrealtime();                                                              \
+    }                                                                                                         \
   } while (0)
 #else
 #define CS_SPAN_BEGIN() ((void)0)

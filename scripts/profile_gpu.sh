@@ -55,5 +55,14 @@ if [ -f $R/gym_copter_amd/csrc/build/libcopterstep_span.so ]; then
   python3 $R/tools/kernel_span.py lander3d 65536 near_hover 10 > $OUT/span_lander3d_65536_substeps10.json 2>> $OUT/span.err
   python3 $R/tools/kernel_span.py lander3d 4194304 uniform 1 > $OUT/span_lander3d_4194304.json 2>> $OUT/span.err
 fi
+# 5. what RCCL itself logs for the forced 1-rank collectives (RCCL turns a 1-rank all-gather into a device copy:
+#    no kernel appears in a trace, so its own call log is the evidence that the collective path ran)
+NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=COLL $LIGHT --gather --steps 20 --warmup 5 --no-graph --regions 1 --min-region-ms 1 > $OUT/rccl_debug.json 2> $OUT/rccl_debug.err
+grep -c "AllGather" $OUT/rccl_debug.err > $OUT/rccl_allgather_calls.txt
+grep "AllGather" $OUT/rccl_debug.err | head -6 | cut -c1-260 >> $OUT/rccl_allgather_calls.txt
 python3 $R/scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# gpurun copies back at most 64 MiB: keep the stats, the summaries and the logs, drop the per-dispatch CSVs
+find $OUT -name "*kernel_trace.csv" -delete -o -name "*counter_collection.csv" -delete -o -name "*.db" -delete
+rm -f $OUT/rccl_debug.err
+du -sh $OUT | cut -f1

@@ -79,6 +79,16 @@ for sub, label in (("trace", "bench default command (65 536 envs + sweep + confi
             print("   rccl echo: %s" % m.group(1))
     print()
 
+f = os.path.join(out, "rccl_allgather_calls.txt")
+if os.path.exists(f):
+    lines = open(f).read().strip().splitlines()
+    print("== RCCL's own call log of the forced 1-rank collectives (NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=COLL) ==")
+    print("AllGather calls logged: %s" % (lines[0] if lines else "?"))
+    for ln in lines[1:]:
+        print("   " + ln)
+    res["rccl_allgather_calls_logged"] = int(lines[0]) if lines and lines[0].isdigit() else None
+    print()
+
 # ---- 2. the kernel's own duration, un-profiled (span build) -------------------------------------------------
 spans = sorted(glob.glob(os.path.join(out, "span_*.json")))
 if spans:
