@@ -330,6 +330,11 @@ def test_long_soak_mixed_actions_vs_oracle():
         for k in range(chunk):
             got, want, _ = step_both(env, orc, a[k])
             assert_step_close(got, want, 2e-6, r_abs=2e-3, r_rel=2e-6, ctx="t=%d" % (t0 + k))
+            # the near-hover third does not diverge: its rewards get the tight bound of the golden-trace tests
+            # (the 2e-3 above is for full-throttle trajectories), leaving out the steps around an episode's end
+            calm = ~(want[2][1::3] | got[2][1::3].astype(bool))
+            dr = np.abs(got[1][1::3].astype(np.float64) - want[1][1::3])[calm]
+            assert dr.size == 0 or dr.max() <= 5e-5, ("near-hover reward", t0 + k, float(dr.max()))
             ends += want[2]
             bonus += int((want[1][2::3] > 50).sum())
             seen |= set(np.unique(orc.status).tolist())
