@@ -84,9 +84,8 @@ def parse(argv=None):
     p.add_argument("--min-region-ms", type=float, default=50.0, help="GPU work per timed region")
     p.add_argument("--regions", type=int, default=5, help="timed regions (the median is reported)")
     p.add_argument("--gather", action="store_true",
-                   help="also time with the RCCL all-gathers of the concatenated return (default when --gpus > 1; on "
-                        "one GPU it runs them in a 1-rank RCCL group)")
-    p.add_argument("--no-gather", action="store_true", help="--gpus > 1 without the collective legs")
+                   help="also time with the RCCL all-gathers of the concatenated return (on one GPU it runs them in a "
+                        "1-rank RCCL group with the collectives forced)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-sweep", action="store_true", help="skip the batch-size / task sweep and config 5")
@@ -526,8 +525,6 @@ def main(argv=None):
     import torch
     dist = None
     launched = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # by torch.distributed.run
-    if world > 1 and not a.no_gather:
-        a.gather = True            # N > 1: the collective legs are part of the default report
     if launched or a.gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -728,7 +725,7 @@ def main(argv=None):
                    "producers that run ahead of the env (open-loop rows submitted from two alternating streams, only ring "
                    "back-pressure; outputs left in the output ring for a device-side consumer): what the persistent env "
                    "kernel sustains when it never waits for a policy")
-    if a.served > 0:
+    if a.served > 0 and world == 1:
         served_legs()
     env.close()
     del stepper, env, actions

@@ -656,13 +656,14 @@ class CopterVecEnv:
         dt = 1.0 / (float(self.config.frames_per_second) * int(self.config.substeps))
         return self.state_tensors()["ticks"].double() * dt
 
-    def get_state(self):
+    def get_state(self, only=None):
         """Whole-batch state as NumPy (synchronises): dict with x[12,N] f64, status, steps,
         prev_shaping (NaN = None), force[3,N] newtons (this episode's reset perturbation: an installed one, or
         the Philox draw of (seed, global env id, episode - 1)), flags (bit 0 perturbation pending, bit 1 reset
         pending, bit 2 the perturbation was installed explicitly), episode, (episode_return), (ticks).
         set_state(**get_state()) is a faithful restore: a `force` that comes with `flags` is installed only
-        where bit 2 says it was explicit; the other envs stay on their Philox draw."""
+        where bit 2 says it was explicit; the other envs stay on their Philox draw.  only=("x", ...) fetches
+        just those arrays."""
         self._check_open()
         n = self.num_envs
         out = {"x": np.empty((12, n)), "status": np.empty(n, np.uint8), "steps": np.empty(n, np.int32),
@@ -670,10 +671,15 @@ class CopterVecEnv:
                "episode": np.empty(n, np.uint32)}
         er = np.empty(n) if self.episode_stats else None
         tk = np.empty(n, np.int32) if self.track_time else None
+        if only is not None:             # only these arrays cross PCIe (the others are not even staged)
+            out = {k: v for k, v in out.items() if k in only}
+            er = er if "episode_return" in only else None
+            tk = tk if "ticks" in only else None
         p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-        _lib.check(self._lib.cs_get_state(self._ctx, p(out["x"]), p(out["status"]), p(out["steps"]),
-                                          p(out["prev_shaping"]), p(out["force"]), p(out["flags"]),
-                                          p(er), p(out["episode"]), p(tk), self._stream()))
+        g = out.get
+        _lib.check(self._lib.cs_get_state(self._ctx, p(g("x")), p(g("status")), p(g("steps")),
+                                          p(g("prev_shaping")), p(g("force")), p(g("flags")),
+                                          p(er), p(g("episode")), p(tk), self._stream()))
         if er is not None:
             out["episode_return"] = er
         if tk is not None:

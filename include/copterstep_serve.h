@@ -81,6 +81,9 @@ struct Spin {
       *stopped = true;
       return true;
     }
+    // a session in which somebody has already given up is lost: everybody still waiting gives up at once, so that a
+    // broken session costs one timeout, not one per launch queued behind it
+    if (__hip_atomic_load(v.ctrl + CS_SERVE_CTRL_TIMEOUTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
     return __builtin_amdgcn_s_memrealtime() - t0 > v.spin_limit;
   }
 };

@@ -108,7 +108,7 @@ class DeviceBackend:
         self.env.set_motors(torch.from_numpy(np.ascontiguousarray(motors, np.float32)).to(self.env.device))
 
     def state(self):
-        return self.env.get_state()["x"]
+        return self.env.get_state(only=("x",))["x"]
 
     def close(self):
         self.env.close()
