@@ -533,3 +533,36 @@ def test_served_session_fed_from_many_streams():
     _assert_same_state(served, plain)
     served.close()
     plain.close()
+
+
+def test_served_session_argument_errors():
+    """What cs_serve_* refuses, as error codes with messages: a batch whose wavefronts could not all stay resident,
+    a ring that is not a power of two, a second session, feeders before any session, the PID policy on a task it
+    does not fly."""
+    import torch
+    import gym_copter_amd
+    from gym_copter_amd._lib import CopterStepError
+    big = gym_copter_amd.CopterVecEnv("lander3d", 1 << 20)
+    assert big.serve_max_envs() < (1 << 20)
+    with pytest.raises(CopterStepError, match="resident"):
+        big.serve_begin(4)
+    big.close()
+    env = gym_copter_amd.CopterVecEnv("lander1d", 4096)
+    env.reset()
+    a = torch.zeros((4096, 1), device=env.device)
+    with pytest.raises(CopterStepError, match="no session"):
+        env.serve_submit(0, a)
+    with pytest.raises(CopterStepError, match="power of two"):
+        env.serve_begin(4, ring=3)
+    env.serve_begin(4, ring=2, timeout=1.0)
+    with pytest.raises(CopterStepError, match="already open"):
+        env.serve_begin(4)
+    with pytest.raises(CopterStepError, match="step must be"):
+        env.serve_submit(4, a)
+    with pytest.raises(CopterStepError):
+        env._lib.cs_pid_configure  # (the heuristic needs the 3D observation: configure_pid itself refuses)
+        env.serve_policy_pid(0)
+    for s in range(4):
+        env.serve_submit(s, a)
+    assert env.serve_end() == 4
+    env.close()
