@@ -559,10 +559,9 @@ def test_served_session_argument_errors():
         env.serve_begin(4)
     with pytest.raises(CopterStepError, match="step must be"):
         env.serve_submit(4, a)
-    with pytest.raises(CopterStepError):
-        env._lib.cs_pid_configure  # (the heuristic needs the 3D observation: configure_pid itself refuses)
-        env.serve_policy_pid(0)
     for s in range(4):
         env.serve_submit(s, a)
     assert env.serve_end() == 4
+    with pytest.raises(CopterStepError, match="3D"):      # (after the session: configuring allocates and synchronises)
+        env.serve_policy_pid(0)
     env.close()
