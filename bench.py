@@ -861,7 +861,15 @@ def main(argv=None):
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.close(real_stdout)
     if dist is not None:
-        dist.destroy_process_group()
+        torch.cuda.synchronize()
+        if launched:
+            dist.destroy_process_group()
+        else:
+            # the 1-rank group this process opened for --gather: leave without tearing RCCL down (its watchdog thread
+            # has been seen to abort the process during interpreter shutdown once hipGraphs that captured collectives
+            # are being freed); the line is out, nothing is left to flush
+            sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":
