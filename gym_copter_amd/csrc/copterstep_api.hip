@@ -242,6 +242,15 @@ int check_ctx(const cs_ctx* ctx) {
   return CS_OK;
 }
 
+// While a served session is open the env state lives in the registers of its persistent kernel (which writes the
+// tiles back when it exits): everything else that reads or writes the tiles has to wait for cs_serve_end.
+int check_idle(const cs_ctx* ctx, const char* who) {
+  if (ctx == nullptr) return fail(CS_ERR_ARG, "null context");
+  if (ctx->serve_active)
+    return fail(CS_ERR_ARG, std::string(who) + ": a served session is open on this context (cs_serve_end first)");
+  return CS_OK;
+}
+
 }  // namespace
 
 #ifdef CS_SPAN
@@ -478,7 +487,7 @@ int cs_set_altitude(cs_ctx* ctx, double altitude) {
 
 int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, float* obs_dev,
              void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_reset")) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
                                   force_xyz_dev, obs_dev, ctx->pid_state, ctx->pid_stride, nullptr, 1,
@@ -489,7 +498,7 @@ int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, f
 
 int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, int32_t perturb,
                   const float* force_xyz_dev, float* obs_dev, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_reset_pose")) return rc_;
   if (pose_dev == nullptr) return fail(CS_ERR_ARG, "cs_reset_pose: pose_dev is required");
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
@@ -500,7 +509,7 @@ int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, i
 }
 
 int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_step_ex")) return rc_;
   if (io == nullptr || io->actions_dev == nullptr)
     return fail(CS_ERR_ARG, "cs_step: actions_dev is required");
   if (io->done_return_dev != nullptr && !ctx->cfg.episode_stats)
@@ -547,7 +556,7 @@ int cs_step_prefetch(cs_ctx* ctx, const float* actions_dev, const float* next_ac
 
 int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float* obs_dev,
                  float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_step_many")) return rc_;
   if (actions_dev == nullptr) return fail(CS_ERR_ARG, "cs_step_many: actions_dev is required");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_step_many: num_steps must be >= 1");
   const cs::DevConst& c = constants(ctx);
@@ -560,7 +569,7 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
 }
 
 int cs_set_vehicle_params(cs_ctx* ctx, const double* params_host) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_set_vehicle_params")) return rc_;
   if (ctx->cfg.action_arith == CS_ARITH_F32 && params_host != nullptr)
     return fail(CS_ERR_ARG, "cs_set_vehicle_params: per-env vehicles are not available with the float32 motor model");
   DeviceGuard guard(ctx->cfg.device);
@@ -621,7 +630,7 @@ int cs_pid_gains_init(cs_pid_gains* g) {
 }
 
 int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* g) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_pid_configure")) return rc_;
   if (g == nullptr || g->struct_size != sizeof(cs_pid_gains))
     return fail(CS_ERR_ARG, "cs_pid_configure: gains missing or struct_size mismatch");
   if (g->heuristic != CS_PID_LANDER && g->heuristic != CS_PID_HOVER)
@@ -670,7 +679,7 @@ int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* g) {
 }
 
 int cs_pid_get_state(cs_ctx* ctx, double* state_host, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_pid_get_state")) return rc_;
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_pid_get_state: call cs_pid_configure first");
   if (state_host == nullptr) return fail(CS_ERR_ARG, "cs_pid_get_state: null buffer");
   const size_t n = (size_t)ctx->cfg.num_envs;
@@ -682,7 +691,7 @@ int cs_pid_get_state(cs_ctx* ctx, double* state_host, void* stream) {
 }
 
 int cs_pid_set_state(cs_ctx* ctx, const double* state_host, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_pid_set_state")) return rc_;
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_pid_set_state: call cs_pid_configure first");
   if (state_host == nullptr) return fail(CS_ERR_ARG, "cs_pid_set_state: null buffer");
   const size_t n = (size_t)ctx->cfg.num_envs;
@@ -696,7 +705,7 @@ int cs_pid_set_state(cs_ctx* ctx, const double* state_host, void* stream) {
 int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
                    float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
                    void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_rollout_pid")) return rc_;
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_rollout_pid: call cs_pid_configure first");
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_rollout_pid: the heuristic flies the 3D tasks only");
@@ -713,7 +722,7 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
 int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
                       float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
                       void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_rollout_random")) return rc_;
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_random: num_steps must be >= 1");
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
@@ -725,7 +734,7 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
 }
 
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_set_motors")) return rc_;
   if (motors_dev == nullptr) return fail(CS_ERR_ARG, "cs_set_motors: motors_dev is required");
   const cs::DevConst& c = constants(ctx);
   hipError_t e =
@@ -736,7 +745,7 @@ int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
 
 int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, int32_t* ticks_dev,
                     void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_export_state")) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_export_state(ctx->cfg.state_mode, c, ctx->st, x_dev, status_dev, steps_dev, ticks_dev,
                                          (hipStream_t)stream);
@@ -745,7 +754,7 @@ int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* ste
 }
 
 int cs_set_perturbation(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_set_perturbation")) return rc_;
   if (force_xyz_dev == nullptr) return fail(CS_ERR_ARG, "cs_set_perturbation: force_xyz_dev is required");
   hipError_t e = cs::launch_set_perturbation(ctx->cfg.state_mode, ctx->st, mask_dev, force_xyz_dev,
                                              (hipStream_t)stream);
@@ -754,7 +763,7 @@ int cs_set_perturbation(cs_ctx* ctx, const uint8_t* mask_dev, const float* force
 }
 
 int cs_episode_stats(cs_ctx* ctx, double* stats_dev, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_episode_stats")) return rc_;
   if (stats_dev == nullptr) return fail(CS_ERR_ARG, "cs_episode_stats: stats_dev is required");
   CS_HIP(hipMemsetAsync(stats_dev, 0, CS_EPISODE_STATS * sizeof(double), (hipStream_t)stream));
   hipError_t e = cs::launch_episode_stats(ctx->cfg.state_mode, ctx->st, stats_dev, (hipStream_t)stream);
@@ -1060,7 +1069,7 @@ int cs_allgather(cs_comm* comm, const void* send_dev, void* recv_dev, int64_t by
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
                  double* episode_return_host, uint32_t* episode_host, int32_t* ticks_host, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_get_state")) return rc_;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_get_state: episode_stats is disabled");
   DeviceGuard guard_dev(ctx->cfg.device);
@@ -1092,7 +1101,7 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
                  const double* force_xyz_host, const uint8_t* flags_host,
                  const double* episode_return_host, const uint32_t* episode_host,
                  const int32_t* ticks_host, void* stream) {
-  if (check_ctx(ctx)) return CS_ERR_ARG;
+  if (int rc_ = check_idle(ctx, "cs_set_state")) return rc_;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_set_state: episode_stats is disabled");
   if (ticks_host && !ctx->cfg.track_time)

@@ -346,6 +346,9 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out); /* the values in effect */
  * queue with the streams that feed it (HIP multiplexes streams onto a few hardware queues per priority level; a
  * feeder queued behind the persistent kernel would wait for it while it waits for the feeder): feed a session
  * from default-priority streams.
+ * While a session is open the env state lives in its kernel's registers: every other entry point that reads or
+ * writes the env state (cs_step*, cs_reset*, cs_rollout_*, cs_get_state, cs_set_state, ...) returns CS_ERR_ARG
+ * until cs_serve_end.
  * While a session is open its kernel is RUNNING: a device-wide synchronisation (hipDeviceSynchronize,
  * torch.cuda.synchronize) waits for the session to end or time out; synchronise streams or events instead.
  * All env wavefronts must be resident at once: num_envs <= cs_serve_max_envs().  cs_serve_begin and

@@ -559,6 +559,9 @@ def test_served_session_argument_errors():
         env.serve_begin(4)
     with pytest.raises(CopterStepError, match="step must be"):
         env.serve_submit(4, a)
+    for call in (lambda: env.step(a), env.reset, env.get_state, lambda: env.rollout_random(2)):
+        with pytest.raises(CopterStepError, match="served session is open"):     # the state is in the kernel's registers
+            call()
     for s in range(4):
         env.serve_submit(s, a)
     assert env.serve_end() == 4
