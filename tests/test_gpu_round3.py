@@ -568,3 +568,42 @@ def test_served_session_argument_errors():
     with pytest.raises(CopterStepError, match="3D"):      # (after the session: configuring allocates and synchronises)
         env.serve_policy_pid(0)
     env.close()
+
+
+def test_served_session_under_uneven_load():
+    """The hand-offs under load: while another stream streams 2 GB through the memory system again and again (every
+    CU busy with loads and stores, the L2s churning), a served session at 65 536 envs still delivers every word of
+    every step bit-identically to cs_step -- a stale or torn granule would show up as a different number."""
+    import torch
+    n, K = 65536, 300
+    served, plain = _twin("hover3d", n, "float32", autoreset_mode="next_step")
+    g = torch.Generator(device=served.device)
+    g.manual_seed(3)
+    acts = torch.rand((8, n, 4), generator=g, device=served.device) * 2 - 1
+    big = torch.empty(1 << 28, dtype=torch.float32, device=served.device)      # 1 GiB
+    other = torch.empty_like(big)
+    noise = torch.cuda.Stream(device=served.device)
+    feed = torch.cuda.Stream(device=served.device)
+    stop_at = 40
+    with torch.cuda.stream(noise):
+        for _ in range(stop_at):
+            other.copy_(big)                  # ~0.35 ms each at ~6 TB/s: keeps the memory system saturated
+            big.add_(1.0)
+    bad = torch.zeros((), dtype=torch.int64, device=served.device)
+    feed.wait_stream(torch.cuda.current_stream(served.device))
+    with torch.cuda.stream(feed):
+        served.serve_begin(K, ring=4, timeout=10.0)
+        for s in range(K):
+            a = acts[s % 8]
+            served.serve_submit(s, a)
+            got = served.serve_collect(s)
+            want = plain.step(a)[:4]
+            for x, y in zip(got, want):
+                bad += (x != y).sum()
+        assert served.serve_end() == K
+    noise.synchronize()
+    torch.cuda.current_stream(served.device).wait_stream(feed)
+    assert int(bad) == 0
+    _assert_same_state(served, plain)
+    served.close()
+    plain.close()
