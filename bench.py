@@ -704,6 +704,11 @@ def main(argv=None):
                        "(tests/test_gpu_round3.py::test_served_closed_loop_policy_kernel_equals_rollout_pid); compare "
                        "with a policy kernel + cs_step per step (config.actions_produced_by_a_preceding_kernel)",
                        prepare=lambda: env.configure_pid())
+            served_leg("served_closed_loop_persistent_policy",
+                       lambda s: env.serve_policy_pid(0, num_steps=k) if s == 0 else None, 4, wire,
+                       "the same closed loop with the POLICY persistent as well (cs_serve_policy_pid_many: one policy "
+                       "kernel per session, controllers in registers): no launch left in the loop -- two hand-offs "
+                       "through device memory and the two kernels' arithmetic per step")
         served_leg("served_submit_collect",
                    lambda s: (env.serve_submit(s, actions[s % actions.shape[0]]), env.serve_collect(s)), 4,
                    wire + 4 * env.action_dim + 4 * od + 6,
@@ -852,7 +857,8 @@ def main(argv=None):
               "k_step_us": {k: round(extra[k]["us_per_step"], 3) for k in ("step_many", "rollout_pid", "rollout_random")
                             if "us_per_step" in extra.get(k, {})},
               "served_us": {k: round(extra[k]["us_per_step"], 3)
-                            for k in ("served_closed_loop", "served_submit_collect", "served_producers_ahead")
+                            for k in ("served_closed_loop", "served_closed_loop_persistent_policy",
+                                      "served_submit_collect", "served_producers_ahead")
                             if "us_per_step" in extra.get(k, {})},
               "rccl": rccl}
     out["roofline"]["digest"] = digest

@@ -130,6 +130,7 @@ SYMBOLS = {
     "cs_serve_submit": (C.c_int, [_P, C.c_int32, _P, _P]),
     "cs_serve_collect": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "cs_serve_policy_pid": (C.c_int, [_P, C.c_int32, _P]),
+    "cs_serve_policy_pid_many": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "cs_serve_end": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     "cs_serve_status": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cs_get_state": (C.c_int, [_P] + [_P] * 9 + [_P]),

@@ -917,18 +917,22 @@ int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_de
   return CS_OK;
 }
 
-int cs_serve_policy_pid(cs_ctx* ctx, int32_t step, void* stream) {
+int cs_serve_policy_pid_many(cs_ctx* ctx, int32_t first_step, int32_t num_steps, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_policy_pid: no session has been opened yet");
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_serve_policy_pid: call cs_pid_configure first");
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_serve_policy_pid: the heuristic flies the 3D tasks only");
-  if (step < 0 || (uint32_t)step >= ctx->serve.num_steps)
-    return fail(CS_ERR_ARG, "cs_serve_policy_pid: step must be in [0, num_steps)");
-  hipError_t e = cs::launch_serve_pid(ctx->serve, (uint32_t)step, ctx->pid, ctx->pid_state, ctx->pid_stride,
-                                      (hipStream_t)stream);
+  if (first_step < 0 || num_steps < 1 || (int64_t)first_step + num_steps > (int64_t)ctx->serve.num_steps)
+    return fail(CS_ERR_ARG, "cs_serve_policy_pid: steps must lie in [0, num_steps)");
+  hipError_t e = cs::launch_serve_pid(ctx->serve, (uint32_t)first_step, (uint32_t)num_steps, ctx->pid, ctx->pid_state,
+                                      ctx->pid_stride, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_serve_policy_pid: kernel launch");
   return CS_OK;
+}
+
+int cs_serve_policy_pid(cs_ctx* ctx, int32_t step, void* stream) {
+  return cs_serve_policy_pid_many(ctx, step, 1, stream);
 }
 
 int cs_serve_status(cs_ctx* ctx, int32_t* steps_done_min, int32_t* steps_done_max, int32_t* timeouts) {

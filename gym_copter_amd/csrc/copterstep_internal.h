@@ -232,8 +232,8 @@ hipError_t serve_occupancy(int task, int mode, const DevConst& c, const DevState
 hipError_t launch_serve_submit(const cs_serve_view& v, uint32_t step, const float* actions, hipStream_t stream);
 hipError_t launch_serve_collect(const cs_serve_view& v, int step, float* obs, float* reward, uint8_t* term,
                                 uint8_t* trunc, hipStream_t stream);
-hipError_t launch_serve_pid(const cs_serve_view& v, uint32_t step, const PidConst& pc, double* pid_state,
-                            uint32_t pid_stride, hipStream_t stream);
+hipError_t launch_serve_pid(const cs_serve_view& v, uint32_t first_step, uint32_t num_steps, const PidConst& pc,
+                            double* pid_state, uint32_t pid_stride, hipStream_t stream);
 hipError_t launch_serve_stop(uint32_t* ctrl, hipStream_t stream);
 
 // cs_get_state / cs_set_state: plain struct-of-arrays staging buffers on the DEVICE (any may be nullptr):

@@ -13,7 +13,8 @@
 //   serve_submit_kernel   plain action rows [N,A] -> action granules        (a "trivial producer", one launch / step)
 //   serve_collect_kernel  output granules -> plain obs / reward / flag rows (one launch / step)
 //   serve_pid_kernel      a tile-matched closed-loop POLICY kernel: outputs of step s-1 -> PID heuristic ->
-//                         actions of step s; the worked example of a caller's own policy kernel
+//                         actions of step s, for one step per launch or for a stretch of steps in one launch (a
+//                         persistent policy next to the persistent env); the worked example of a caller's own kernel
 //   serve_stop_kernel     raises the stop word
 #include <type_traits>
 
@@ -240,14 +241,14 @@ __global__ __launch_bounds__(kBlock) void serve_collect_kernel(const cs_serve_vi
 // returned (s = 0: the initial rows).  Controller state: the context's [24][stride] float64 rows, as
 // cs_rollout_pid keeps them (zeroed where the env started a new episode).
 template <int OBS, bool HOVER>
-__global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v, const uint32_t step,
-                                                           const PidConst pc, double* __restrict__ pid_state,
-                                                           const uint32_t pid_stride) {
+__global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v, const uint32_t first_step,
+                                                           const uint32_t num_steps, const PidConst pc_arg,
+                                                           double* __restrict__ pid_state, const uint32_t pid_stride) {
   constexpr int OP = (OBS + 2) / 2;
   constexpr int NCTL = HOVER ? kPidControllers : 4;
   const uint32_t tile = blockIdx.x, lane = threadIdx.x, i = tile * kBlock + lane;
-  uint32_t w[2 * OP];
-  if (!cs_serve::take_outputs<OP>(v, (int)step - 1, tile, lane, w)) return;
+  PidConst pc = pc_arg;
+  if (num_steps > 1) park_gains(pc);  // the policy of a whole stretch of steps as ONE kernel: gains out of the SGPRs' way
   PidCtl ctl[NCTL];
 #pragma unroll
   for (int j = 0; j < NCTL; ++j) {
@@ -256,14 +257,20 @@ __global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v
     ctl[j].d1 = pid_state[(size_t)(4 * j + 2) * pid_stride + i];
     ctl[j].d2 = pid_state[(size_t)(4 * j + 3) * pid_stride + i];
   }
-  if (w[OBS + 1] & 4u) {  // a new episode flies with fresh controllers
+  for (uint32_t step = first_step; step < first_step + num_steps; ++step) {
+    uint32_t w[2 * OP];
+    if (!cs_serve::take_outputs<OP>(v, (int)step - 1, tile, lane, w)) break;
+    if (w[OBS + 1] & 4u) {  // a new episode flies with fresh controllers
 #pragma unroll
-    for (int j = 0; j < NCTL; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
+      for (int j = 0; j < NCTL; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
+    }
+    float seen[OBS];
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) seen[k] = __uint_as_float(w[k]);
+    const float4 act = pid_policy<OBS, HOVER, NCTL>(pc, ctl, seen);
+    const float a[4] = {act.x, act.y, act.z, act.w};
+    if (!cs_serve::put_actions<2>(v, step, tile, lane, a)) break;
   }
-  float seen[OBS];
-#pragma unroll
-  for (int k = 0; k < OBS; ++k) seen[k] = __uint_as_float(w[k]);
-  const float4 act = pid_policy<OBS, HOVER, NCTL>(pc, ctl, seen);
 #pragma unroll
   for (int j = 0; j < NCTL; ++j) {
     pid_state[(size_t)(4 * j + 0) * pid_stride + i] = ctl[j].err_i;
@@ -271,8 +278,6 @@ __global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v
     pid_state[(size_t)(4 * j + 2) * pid_stride + i] = ctl[j].d1;
     pid_state[(size_t)(4 * j + 3) * pid_stride + i] = ctl[j].d2;
   }
-  const float a[4] = {act.x, act.y, act.z, act.w};
-  cs_serve::put_actions<2>(v, step, tile, lane, a);
 }
 
 __global__ void serve_stop_kernel(uint32_t* ctrl) {
@@ -348,20 +353,24 @@ hipError_t launch_serve_collect(const cs_serve_view& v, int step, float* obs, fl
   return hipGetLastError();
 }
 
-hipError_t launch_serve_pid(const cs_serve_view& v, uint32_t step, const PidConst& pc, double* pid_state,
-                            uint32_t pid_stride, hipStream_t stream) {
+hipError_t launch_serve_pid(const cs_serve_view& v, uint32_t first_step, uint32_t num_steps, const PidConst& pc,
+                            double* pid_state, uint32_t pid_stride, hipStream_t stream) {
   const dim3 grid(v.tiles), block(kBlock);
   if (v.act_dim != 4) return hipErrorInvalidValue;
+#define CS_PID(OBS, HOVER)                                                                                      \
+  hipLaunchKernelGGL((serve_pid_kernel<OBS, HOVER>), grid, block, 0, stream, v, first_step, num_steps, pc, pid_state, \
+                     pid_stride)
   if (pc.hover != 0) {
     if (v.obs_dim != 12) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((serve_pid_kernel<12, true>), grid, block, 0, stream, v, step, pc, pid_state, pid_stride);
+    CS_PID(12, true);
   } else if (v.obs_dim == 12) {
-    hipLaunchKernelGGL((serve_pid_kernel<12, false>), grid, block, 0, stream, v, step, pc, pid_state, pid_stride);
+    CS_PID(12, false);
   } else if (v.obs_dim == 10) {
-    hipLaunchKernelGGL((serve_pid_kernel<10, false>), grid, block, 0, stream, v, step, pc, pid_state, pid_stride);
+    CS_PID(10, false);
   } else {
     return hipErrorInvalidValue;
   }
+#undef CS_PID
   return hipGetLastError();
 }
 

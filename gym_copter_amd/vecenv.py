@@ -545,13 +545,15 @@ class CopterVecEnv:
                                                   self._stream()))
         return obs, rew, term.view(torch.bool), trunc.view(torch.bool)
 
-    def serve_policy_pid(self, step):
+    def serve_policy_pid(self, step, num_steps=1):
         """One closed-loop policy step as its own kernel: the PID heuristic of configure_pid() on the
-        outputs of step - 1 -> the actions of `step`."""
+        outputs of step - 1 -> the actions of `step`.  num_steps > 1: the policy of the steps [step, step +
+        num_steps) as ONE persistent kernel next to the env kernel (controllers in registers, no launch in
+        the loop)."""
         if not getattr(self, "_pid", False):
             self.configure_pid()
         with _torch().cuda.device(self.device):
-            _lib.check(self._lib.cs_serve_policy_pid(self._ctx, int(step), self._stream()))
+            _lib.check(self._lib.cs_serve_policy_pid_many(self._ctx, int(step), int(num_steps), self._stream()))
 
     def serve_end(self, wait=True):
         """Close the session: order the current stream behind the env kernel's exit.  wait=True also waits for

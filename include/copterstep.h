@@ -387,6 +387,11 @@ int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_de
  * `step` - 1 -> the actions of `step` (controller state in the context, as cs_rollout_pid keeps it).  K of
  * these against a served session are bit-identical to cs_rollout_pid(K). */
 int cs_serve_policy_pid(cs_ctx* ctx, int32_t step, void* stream);
+/* The same policy for the steps [first_step, first_step + num_steps) as ONE kernel: a persistent policy kernel
+ * next to the persistent env kernel -- the controllers stay in registers, and no launch is left in the loop at
+ * all (what remains per step is two hand-offs and the two kernels' arithmetic).  Bit-identical to num_steps
+ * launches of cs_serve_policy_pid. */
+int cs_serve_policy_pid_many(cs_ctx* ctx, int32_t first_step, int32_t num_steps, void* stream);
 /* Ask the env kernel to stop at the first step whose actions are not there, and order `stream` behind its
  * exit.  With steps_done != NULL it then synchronises `stream` and reports: CS_OK, or CS_ERR_TIMEOUT if a
  * wavefront gave up; *steps_done = steps completed by every tile.  With steps_done == NULL it only enqueues

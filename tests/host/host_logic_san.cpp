@@ -28,7 +28,7 @@ hipError_t launch_serve(int, int, const DevConst&, const DevState&, const cs_ser
 hipError_t serve_occupancy(int, int, const DevConst&, const DevState&, int*) { return hipErrorUnknown; }
 hipError_t launch_serve_submit(const cs_serve_view&, uint32_t, const float*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_serve_collect(const cs_serve_view&, int, float*, float*, uint8_t*, uint8_t*, hipStream_t) { return hipErrorUnknown; }
-hipError_t launch_serve_pid(const cs_serve_view&, uint32_t, const PidConst&, double*, uint32_t, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_serve_pid(const cs_serve_view&, uint32_t, uint32_t, const PidConst&, double*, uint32_t, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_serve_stop(uint32_t*, hipStream_t) { return hipErrorUnknown; }
 }  // namespace cs
 

@@ -278,6 +278,35 @@ def test_served_closed_loop_policy_kernel_equals_rollout_pid(task, heuristic):
     b.close()
 
 
+def test_served_persistent_policy_kernel_equals_rollout_pid():
+    """The policy of a whole session as ONE kernel next to the env kernel (cs_serve_policy_pid_many: controllers in
+    registers, no launch in the loop): 60 closed-loop steps, every output read back from a 64-deep ring afterwards,
+    against cs_rollout_pid(60)."""
+    import torch
+    n, K = 6000, 60
+    a, b = _twin("lander3d", n, "float32", autoreset_mode="next_step")
+    for e in (a, b):
+        e.configure_pid()
+        e.reset()
+    want = [t.clone() for t in b.rollout_pid(K)]
+    a.serve_begin(K, ring=64, timeout=5.0)
+    a.serve_policy_pid(0, num_steps=K)
+    assert a.serve_end() == K
+    outs = [torch.empty_like(t) for t in want]
+    for s in range(K):                         # the ring still holds every step of the (closed) session
+        a.serve_collect(s, out=(outs[0][s], outs[1][s], outs[2][s].view(torch.uint8), outs[3][s].view(torch.uint8)))
+    torch.cuda.current_stream(a.device).synchronize()
+    for k, (x, y) in enumerate(zip(outs, want)):
+        assert torch.equal(x, y), k
+    _assert_same_state(a, b)
+    pa, pb = a.pid_get_state(), b.pid_get_state()
+    reset_last = to_np(outs[2][K - 2] | outs[3][K - 2])
+    pa[:, reset_last] = 0
+    assert (pb[:, reset_last] == 0).all() and np.array_equal(pa, pb)
+    a.close()
+    b.close()
+
+
 def test_served_session_gives_up_after_its_timeout_and_says_so():
     """A step whose actions never arrive: every wavefront's wait is bounded, the session ends with
     CS_ERR_TIMEOUT, the steps that were served are kept, and the env is usable afterwards."""
