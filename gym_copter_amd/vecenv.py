@@ -274,6 +274,16 @@ class CopterVecEnv:
                 _lib.check(self._lib.cs_reset_pose(self._ctx, mask_p, C.c_void_p(pose_t.data_ptr()), int(perturb),
                                                    force_p, C.c_void_p(self._obs.data_ptr()), self._stream()))
         self._keep = (mask_t, force_t, pose_t)      # alive until the stream has consumed them
+        if (forces is not None and perturb and self.config.state_mode == _lib.STATE_F64
+                and not isinstance(forces, torch.Tensor)):
+            # float64 state words: the device entry point takes float32 force rows; install the float64 values
+            # the caller gave (upstream's force / M is float64) through the host path where they differ
+            f64 = np.ascontiguousarray(np.asarray(forces, dtype=np.float64))
+            if not np.array_equal(f64, f64.astype(np.float32).astype(np.float64)):
+                st = self.get_state(only=("force", "flags"))
+                m = np.ones(self.num_envs, bool) if mask is None else (np.asarray(to_numpy_mask(mask)) != 0)
+                st["force"][:, m] = f64[:, m]
+                self.set_state(force=st["force"], flags=(st["flags"] | np.where(m, 5, 0)).astype(np.uint8))
         return self._obs, {}
 
     def step(self, actions):
@@ -766,6 +776,10 @@ class CopterVecEnv:
         _lib.check(self._lib.cs_get_tuning(self._ctx, C.byref(t)))
         return {"nt_action_max_envs": t.nt_action_max_envs, "nt_state_min_envs": t.nt_state_min_envs,
                 "direct_rows_max_envs": t.direct_rows_max_envs}
+
+
+def to_numpy_mask(mask):
+    return mask.detach().cpu().numpy() if hasattr(mask, "detach") else mask
 
 
 def _to_numpy(v):

@@ -636,3 +636,26 @@ def test_served_session_under_uneven_load():
     _assert_same_state(served, plain)
     served.close()
     plain.close()
+
+
+def test_float64_mode_keeps_float64_forces():
+    """with float64 state words an installed force (reset options / Dynamics.perturb) stays
+    float64 -- upstream's force / M is -- instead of passing through the float32 device rows."""
+    n = 200
+    env, orc = make_pair("lander3d", n, "float64")
+    rng = np.random.default_rng(8)
+    f = rng.uniform(-30, 30, (3, n)) + 1.0 / 3.0                      # not float32-representable
+    env.reset(options={"forces": f})
+    orc.reset(forces=f)
+    assert np.array_equal(env.get_state()["force"], f)
+    got, want, _ = step_both(env, orc, np.full((n, 4), HOVER, np.float32))
+    assert_step_close(got, want, MODE_TOL["float64"])
+    assert_state_close(env, orc, MODE_TOL["float64"])
+    f2 = rng.uniform(-5, 5, (3, n)) + 1.0 / 7.0
+    env.set_perturbation(f2)
+    assert np.array_equal(env.get_state()["force"], f2) and (env.get_state()["flags"] & 5 == 5).all()
+    m = np.arange(n) % 2 == 0
+    env.reset(options={"forces": f, "mask": m})
+    st = env.get_state()
+    assert np.array_equal(st["force"][:, m], f[:, m]) and np.array_equal(st["force"][:, ~m], f2[:, ~m])
+    env.close()
