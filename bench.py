@@ -868,7 +868,8 @@ def main(argv=None):
     os.close(real_stdout)
     if dist is not None:
         torch.cuda.synchronize()
-        if launched:
+        profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+        if launched or profiled:       # (a profiler writes its files from exit handlers: leave normally)
             dist.destroy_process_group()
         else:
             # the 1-rank group this process opened for --gather: leave without tearing RCCL down (its watchdog thread
