@@ -10,25 +10,27 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# every step is bounded on its own: one stuck profiler run must not eat the GPU budget of the others
+T="timeout 400"
 BENCH="python3 $R/bench.py --steps 1000 --warmup 200 --no-cpu-baseline"
 LIGHT="$BENCH --no-sweep --pid 0 --many 0 --served 0"
 # 0. the un-profiled bench line of the same build (what the profiled figures are compared with)
-$BENCH > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+$T $BENCH > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 # 1. per-kernel time of the bench default command (65 536 envs, hipGraph replay, with the sweep, config 5 and
 #    the K-step extras).  The summary groups kernel_trace.csv by (kernel name, grid size): the 262 144-env and
 #    1 M-env sweep points run the same instantiation and are told apart by their grids.
-rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- $BENCH --served 0 > $OUT/trace.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- $BENCH --served 0 > $OUT/trace.log 2>&1
 # 1b. the headline kernel alone at 4 194 304 envs, where the per-dispatch cost of tracing is negligible
-rocprofv3 --kernel-trace --stats -d $OUT/trace_4m --output-format csv -- $LIGHT --envs 4194304 --steps 200 --warmup 50 --ring 4 > $OUT/trace_4m.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT/trace_4m --output-format csv -- $LIGHT --envs 4194304 --steps 200 --warmup 50 --ring 4 > $OUT/trace_4m.log 2>&1
 # 1c. a 1-rank RCCL group whose all-gathers are really issued (bench.py --gather on one GPU): the kernel names
 #     RCCL launched are the evidence that the collective path ran, eagerly and from hipGraphs
-rocprofv3 --kernel-trace --stats -d $OUT/trace_rccl --output-format csv -- $LIGHT --gather --steps 200 --warmup 50 > $OUT/trace_rccl.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $OUT/trace_rccl --output-format csv -- $LIGHT --gather --steps 200 --warmup 50 > $OUT/trace_rccl.log 2>&1
 # 2. HBM traffic (FETCH_SIZE and WRITE_SIZE in their own passes: TCC slots), eager launches so that every
 #    dispatch is attributed: headline, 4 M envs, BASELINE configs[2] (Hover3D 262 144), configs[4] (10 substeps)
 pmc_pair() {  # <name> <bench args...>
   local name=$1; shift
-  rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/fetch_$name.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE -d $OUT/write_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/write_$name.log 2>&1
+  $T rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/fetch_$name.log 2>&1
+  $T rocprofv3 --pmc WRITE_SIZE -d $OUT/write_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/write_$name.log 2>&1
 }
 pmc_pair lander3d_65536 --envs 65536
 pmc_pair lander3d_4194304 --envs 4194304
@@ -39,25 +41,25 @@ pmc_pair lander3d_65536_substeps10 --envs 65536 --substeps 10 --actions near_hov
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES"
 SQ2="SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"
 SQB="$BENCH --no-sweep --served 0 --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1"
-rocprofv3 --pmc $SQ1 -d $OUT/sq1 --output-format csv -- $SQB > $OUT/sq1.log 2>&1
-rocprofv3 --pmc $SQ2 -d $OUT/sq2 --output-format csv -- $SQB > $OUT/sq2.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/l2 --output-format csv -- $SQB > $OUT/l2.log 2>&1
+$T rocprofv3 --pmc $SQ1 -d $OUT/sq1 --output-format csv -- $SQB > $OUT/sq1.log 2>&1
+$T rocprofv3 --pmc $SQ2 -d $OUT/sq2 --output-format csv -- $SQB > $OUT/sq2.log 2>&1
+$T rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/l2 --output-format csv -- $SQB > $OUT/l2.log 2>&1
 for cfgname in "c5 --envs 65536 --substeps 10 --actions near_hover" "c3 --task hover3d --envs 262144"; do
   set -- $cfgname; name=$1; shift
-  rocprofv3 --pmc $SQ1 -d $OUT/sq1_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/sq1_$name.log 2>&1
-  rocprofv3 --pmc $SQ2 -d $OUT/sq2_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/sq2_$name.log 2>&1
+  $T rocprofv3 --pmc $SQ1 -d $OUT/sq1_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/sq1_$name.log 2>&1
+  $T rocprofv3 --pmc $SQ2 -d $OUT/sq2_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/sq2_$name.log 2>&1
 done
 # 4. the kernel's own duration per launch, un-profiled: first wavefront start -> last wavefront end on the
 #    100 MHz clock in the span build (tools/kernel_span.py; phases not serialised)
 if [ -f $R/gym_copter_amd/csrc/build/libcopterstep_span.so ]; then
-  python3 $R/tools/kernel_span.py lander3d 65536 uniform 1 > $OUT/span_lander3d_65536.json 2> $OUT/span.err
-  python3 $R/tools/kernel_span.py hover3d 262144 uniform 1 > $OUT/span_hover3d_262144.json 2>> $OUT/span.err
-  python3 $R/tools/kernel_span.py lander3d 65536 near_hover 10 > $OUT/span_lander3d_65536_substeps10.json 2>> $OUT/span.err
-  python3 $R/tools/kernel_span.py lander3d 4194304 uniform 1 > $OUT/span_lander3d_4194304.json 2>> $OUT/span.err
+  $T python3 $R/tools/kernel_span.py lander3d 65536 uniform 1 > $OUT/span_lander3d_65536.json 2> $OUT/span.err
+  $T python3 $R/tools/kernel_span.py hover3d 262144 uniform 1 > $OUT/span_hover3d_262144.json 2>> $OUT/span.err
+  $T python3 $R/tools/kernel_span.py lander3d 65536 near_hover 10 > $OUT/span_lander3d_65536_substeps10.json 2>> $OUT/span.err
+  $T python3 $R/tools/kernel_span.py lander3d 4194304 uniform 1 > $OUT/span_lander3d_4194304.json 2>> $OUT/span.err
 fi
 # 5. what RCCL itself logs for the forced 1-rank collectives (RCCL turns a 1-rank all-gather into a device copy:
 #    no kernel appears in a trace, so its own call log is the evidence that the collective path ran)
-NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=COLL $LIGHT --gather --steps 20 --warmup 5 --no-graph --regions 1 --min-region-ms 1 > $OUT/rccl_debug.json 2> $OUT/rccl_debug.err
+NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=COLL $T $LIGHT --gather --steps 20 --warmup 5 --no-graph --regions 1 --min-region-ms 1 > $OUT/rccl_debug.json 2> $OUT/rccl_debug.err
 grep -c "AllGather" $OUT/rccl_debug.err > $OUT/rccl_allgather_calls.txt
 grep "AllGather" $OUT/rccl_debug.err | head -6 | cut -c1-260 >> $OUT/rccl_allgather_calls.txt
 python3 $R/scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
