@@ -11,20 +11,28 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # every step is bounded on its own: one stuck profiler run must not eat the GPU budget of the others
-T="timeout 400"
+T="timeout ${STEP_TIMEOUT:-400}"
+step() {  # <label>: note how long the previous step took (progress.txt travels back even if a later step is killed)
+  echo "$(date +%s) $1" >> $OUT/progress.txt
+}
 BENCH="python3 $R/bench.py --steps 1000 --warmup 200 --no-cpu-baseline"
 LIGHT="$BENCH --no-sweep --pid 0 --many 0 --served 0"
+step bench_unprofiled
 # 0. the un-profiled bench line of the same build (what the profiled figures are compared with)
 $T $BENCH > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+step trace
 # 1. per-kernel time of the bench default command (65 536 envs, hipGraph replay, with the sweep, config 5 and
 #    the K-step extras).  The summary groups kernel_trace.csv by (kernel name, grid size): the 262 144-env and
 #    1 M-env sweep points run the same instantiation and are told apart by their grids.
 $T rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- $BENCH --served 0 > $OUT/trace.log 2>&1
+step trace_4m
 # 1b. the headline kernel alone at 4 194 304 envs, where the per-dispatch cost of tracing is negligible
 $T rocprofv3 --kernel-trace --stats -d $OUT/trace_4m --output-format csv -- $LIGHT --envs 4194304 --steps 200 --warmup 50 --ring 4 > $OUT/trace_4m.log 2>&1
+step trace_rccl
 # 1c. a 1-rank RCCL group whose all-gathers are really issued (bench.py --gather on one GPU): the kernel names
 #     RCCL launched are the evidence that the collective path ran, eagerly and from hipGraphs
 $T rocprofv3 --kernel-trace --stats -d $OUT/trace_rccl --output-format csv -- $LIGHT --gather --steps 200 --warmup 50 > $OUT/trace_rccl.log 2>&1
+step pmc_traffic
 # 2. HBM traffic (FETCH_SIZE and WRITE_SIZE in their own passes: TCC slots), eager launches so that every
 #    dispatch is attributed: headline, 4 M envs, BASELINE configs[2] (Hover3D 262 144), configs[4] (10 substeps)
 pmc_pair() {  # <name> <bench args...>
@@ -36,6 +44,7 @@ pmc_pair lander3d_65536 --envs 65536
 pmc_pair lander3d_4194304 --envs 4194304
 pmc_pair hover3d_262144 --task hover3d --envs 262144
 pmc_pair lander3d_65536_substeps10 --envs 65536 --substeps 10 --actions near_hover
+step pmc_sq
 # 3. instruction mix / wave cycles (SQ counters, 8 per pass): the headline with the K-step kernels of the extras,
 #    then configs[4] and configs[2] on their own
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES"
@@ -49,6 +58,7 @@ for cfgname in "c5 --envs 65536 --substeps 10 --actions near_hover" "c3 --task h
   $T rocprofv3 --pmc $SQ1 -d $OUT/sq1_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/sq1_$name.log 2>&1
   $T rocprofv3 --pmc $SQ2 -d $OUT/sq2_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/sq2_$name.log 2>&1
 done
+step spans
 # 4. the kernel's own duration per launch, un-profiled: first wavefront start -> last wavefront end on the
 #    100 MHz clock in the span build (tools/kernel_span.py; phases not serialised)
 if [ -f $R/gym_copter_amd/csrc/build/libcopterstep_span.so ]; then
@@ -57,14 +67,18 @@ if [ -f $R/gym_copter_amd/csrc/build/libcopterstep_span.so ]; then
   $T python3 $R/tools/kernel_span.py lander3d 65536 near_hover 10 > $OUT/span_lander3d_65536_substeps10.json 2>> $OUT/span.err
   $T python3 $R/tools/kernel_span.py lander3d 4194304 uniform 1 > $OUT/span_lander3d_4194304.json 2>> $OUT/span.err
 fi
+step rccl_log
 # 5. what RCCL itself logs for the forced 1-rank collectives (RCCL turns a 1-rank all-gather into a device copy:
 #    no kernel appears in a trace, so its own call log is the evidence that the collective path ran)
 NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=COLL $T $LIGHT --gather --steps 20 --warmup 5 --no-graph --regions 1 --min-region-ms 1 > $OUT/rccl_debug.json 2> $OUT/rccl_debug.err
 grep -c "AllGather" $OUT/rccl_debug.err > $OUT/rccl_allgather_calls.txt
 grep "AllGather" $OUT/rccl_debug.err | head -6 | cut -c1-260 >> $OUT/rccl_allgather_calls.txt
+step summarize
 python3 $R/scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # gpurun copies back at most 64 MiB: keep the stats, the summaries and the logs, drop the per-dispatch CSVs
 find $OUT -name "*kernel_trace.csv" -delete -o -name "*counter_collection.csv" -delete -o -name "*.db" -delete
 rm -f $OUT/rccl_debug.err
+step done
+awk 'NR>1{print prev_label, $1-prev_t " s"} {prev_t=$1; prev_label=$2}' $OUT/progress.txt
 du -sh $OUT | cut -f1
