@@ -240,7 +240,9 @@ __global__ __launch_bounds__(kBlock) void serve_collect_kernel(const cs_serve_vi
 // A closed-loop policy as its own kernel per step: the PID heuristics of dev_pid.h on what step s-1
 // returned (s = 0: the initial rows).  Controller state: the context's [24][stride] float64 rows, as
 // cs_rollout_pid keeps them (zeroed where the env started a new episode).
-template <int OBS, bool HOVER>
+// MANY = false: ONE step per launch (the launch itself is part of the loop: wait for the env first, touch the
+// controller state only then).  MANY = true: a stretch of steps in one launch, controllers in registers.
+template <int OBS, bool HOVER, bool MANY>
 __global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v, const uint32_t first_step,
                                                            const uint32_t num_steps, const PidConst pc_arg,
                                                            double* __restrict__ pid_state, const uint32_t pid_stride) {
@@ -248,7 +250,11 @@ __global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v
   constexpr int NCTL = HOVER ? kPidControllers : 4;
   const uint32_t tile = blockIdx.x, lane = threadIdx.x, i = tile * kBlock + lane;
   PidConst pc = pc_arg;
-  if (num_steps > 1) park_gains(pc);  // the policy of a whole stretch of steps as ONE kernel: gains out of the SGPRs' way
+  if constexpr (MANY) park_gains(pc);  // (a loop body: gains out of the scalar registers' way, as in the K-step kernels)
+  uint32_t w[2 * OP];
+  if constexpr (!MANY) {
+    if (!cs_serve::take_outputs<OP>(v, (int)first_step - 1, tile, lane, w)) return;
+  }
   PidCtl ctl[NCTL];
 #pragma unroll
   for (int j = 0; j < NCTL; ++j) {
@@ -257,9 +263,10 @@ __global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v
     ctl[j].d1 = pid_state[(size_t)(4 * j + 2) * pid_stride + i];
     ctl[j].d2 = pid_state[(size_t)(4 * j + 3) * pid_stride + i];
   }
-  for (uint32_t step = first_step; step < first_step + num_steps; ++step) {
-    uint32_t w[2 * OP];
-    if (!cs_serve::take_outputs<OP>(v, (int)step - 1, tile, lane, w)) break;
+  for (uint32_t step = first_step; step < first_step + (MANY ? num_steps : 1u); ++step) {
+    if constexpr (MANY) {
+      if (!cs_serve::take_outputs<OP>(v, (int)step - 1, tile, lane, w)) break;
+    }
     if (w[OBS + 1] & 4u) {  // a new episode flies with fresh controllers
 #pragma unroll
       for (int j = 0; j < NCTL; ++j) ctl[j] = PidCtl{0.0, 0.0, 0.0, 0.0};
@@ -357,9 +364,15 @@ hipError_t launch_serve_pid(const cs_serve_view& v, uint32_t first_step, uint32_
                             double* pid_state, uint32_t pid_stride, hipStream_t stream) {
   const dim3 grid(v.tiles), block(kBlock);
   if (v.act_dim != 4) return hipErrorInvalidValue;
-#define CS_PID(OBS, HOVER)                                                                                      \
-  hipLaunchKernelGGL((serve_pid_kernel<OBS, HOVER>), grid, block, 0, stream, v, first_step, num_steps, pc, pid_state, \
-                     pid_stride)
+#define CS_PID(OBS, HOVER)                                                                                         \
+  do {                                                                                                             \
+    if (num_steps > 1)                                                                                             \
+      hipLaunchKernelGGL((serve_pid_kernel<OBS, HOVER, true>), grid, block, 0, stream, v, first_step, num_steps, pc, \
+                         pid_state, pid_stride);                                                                   \
+    else                                                                                                           \
+      hipLaunchKernelGGL((serve_pid_kernel<OBS, HOVER, false>), grid, block, 0, stream, v, first_step, num_steps, pc, \
+                         pid_state, pid_stride);                                                                   \
+  } while (0)
   if (pc.hover != 0) {
     if (v.obs_dim != 12) return hipErrorInvalidValue;
     CS_PID(12, true);
