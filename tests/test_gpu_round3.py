@@ -708,3 +708,15 @@ def test_served_long_soak_closed_loop_and_graph_fed():
     _assert_same_state(a, b)
     a.close()
     b.close()
+
+
+def test_caller_side_policy_kernel_on_the_public_device_header():
+    """tests/host/serve_policy_host.hip: a third party's HIP policy kernel built only on include/copterstep.h +
+    include/copterstep_serve.h, one launch per closed-loop step against a served session, checked against a twin
+    stepped with cs_step on the actions the policy recorded."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "serve_policy_host")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert "serve_policy_host: OK" in p.stdout
