@@ -179,7 +179,10 @@ class Stepper:
                     self._one(j)
             torch.cuda.current_stream(env.device).wait_stream(s)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread-local capture mode: with a process group alive, RCCL's watchdog thread queries the events of
+            # earlier collectives while this thread captures -- under the default (global) mode that query is an
+            # error inside ProcessGroupNCCL and aborts the process (seen once in three runs with forced collectives)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 for j in range(chunk):
                     self._one(j)
 
@@ -223,7 +226,7 @@ class PipeStepper:
                 self.chunk(3)
             cur.wait_stream(s)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):      # (see Stepper)
                 self.chunk(chunk)
 
     def chunk(self, count, start=0):
@@ -302,7 +305,7 @@ class LaunchFloor:
             probe.add_(1.0)
         torch.cuda.current_stream(device).wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             for _ in range(100):
                 probe.add_(1.0)
 

@@ -450,7 +450,7 @@ for gather in ("obs", "all"):
     graph = torch.cuda.CUDAGraph()
     captured = "graph"
     try:
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # (RCCL's watchdog thread queries events meanwhile)
             out = env.step(acts[1])
     except Exception as e:
         captured = "refused: " + type(e).__name__
