@@ -158,6 +158,19 @@ def make_actions(torch, law, ring, n, device, seed):
     return torch.full((ring, n, 4), 1.625e-2, device=device, dtype=torch.float32)
 
 
+def quiesce_collectives(torch):
+    """Before a capture in a process with a process group: let the eager collectives finish and give
+    ProcessGroupNCCL's watchdog (polling period 100 ms) time to retire them, so that it has nothing to query while
+    the capture is open."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            torch.cuda.synchronize()
+            time.sleep(0.3)
+    except Exception:
+        pass
+
+
 class Stepper:
     """Runs `count` consecutive env steps, as hipGraph replays of `chunk` captured
     launches plus eager launches for the remainder."""
@@ -182,6 +195,7 @@ class Stepper:
             # thread-local capture mode: with a process group alive, RCCL's watchdog thread queries the events of
             # earlier collectives while this thread captures -- under the default (global) mode that query is an
             # error inside ProcessGroupNCCL and aborts the process (seen once in three runs with forced collectives)
+            quiesce_collectives(torch)
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 for j in range(chunk):
                     self._one(j)
@@ -226,6 +240,7 @@ class PipeStepper:
                 self.chunk(3)
             cur.wait_stream(s)
             self.graph = torch.cuda.CUDAGraph()
+            quiesce_collectives(torch)
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):      # (see Stepper)
                 self.chunk(chunk)
 

@@ -449,6 +449,7 @@ for gather in ("obs", "all"):
     torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     captured = "graph"
+    import time; time.sleep(0.3)        # (the watchdog retires the eager collectives before the capture opens)
     try:
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # (RCCL's watchdog thread queries events meanwhile)
             out = env.step(acts[1])
