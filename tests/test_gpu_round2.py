@@ -466,7 +466,8 @@ def test_sharded_env_in_a_spawned_nccl_process_group(tmp_path):
     script.write_text(_CHILD % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    from gpu_util import run_with_rccl
+    p = run_with_rccl([sys.executable, str(script)], env, 600)
     assert p.returncode == 0 and "SHARDED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
@@ -480,7 +481,8 @@ def test_bench_as_a_torchrun_rank_with_gather_legs(tmp_path):
            "--warmup", "5", "--gather", "--no-sweep", "--no-cpu-baseline", "--pid", "0", "--many", "0",
            "--min-region-ms", "5", "--regions", "3"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    from gpu_util import run_with_rccl
+    p = run_with_rccl(cmd, env, 900, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]

@@ -479,7 +479,8 @@ def test_a_real_rccl_all_gather_runs_on_one_gpu(tmp_path):
     script.write_text(_RCCL_CHILD % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    from gpu_util import run_with_rccl
+    p = run_with_rccl([sys.executable, str(script)], env, 600)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
     legs = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("RCCL_LEG")]
     assert [l[1] for l in legs] == ["obs", "all"]
@@ -497,7 +498,8 @@ def test_bench_gather_on_one_gpu_reports_what_rccl_saw(tmp_path):
            "--regions", "3"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("COPTERSTEP_FORCE_COLLECTIVE", None)
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    from gpu_util import run_with_rccl
+    p = run_with_rccl(cmd, env, 900, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
