@@ -240,14 +240,6 @@ __device__ __forceinline__ uint32_t physics_substeps(const DevConst& c, const Co
     pend = pend && what == kCallFroze;
     return what == kCallFroze ? 0u : 1u;
   }
-  // no perturbation pending anywhere in the wavefront and free flight assured for ALL nsub calls: the whole step
-  // is the unchecked free-flight loop (an episode's first step, a wavefront near the ground, ... take the general
-  // route below)
-  if (__all(!pend) && __all(flight_assured<GYRO>(q, w, fs, x, (double)c.nsub * c.dt))) {
-#pragma clang loop unroll(disable)
-    for (int sub = 0; sub < c.nsub; ++sub) physics_flight<FULL, GYRO>(c, q, w, x);
-    return (uint32_t)c.nsub;
-  }
   const int first = physics_call<FULL, GYRO, true>(c, q, w, x, fs, px, py, pz);
   uint32_t ticked = first == kCallFroze ? 0u : 1u;
   // a call that froze keeps the perturbation (upstream's early return); the next call, which cannot
