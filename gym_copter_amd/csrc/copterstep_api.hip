@@ -37,6 +37,7 @@ struct cs_ctx {
   size_t serve_bytes = 0;
   cs_serve_view serve{};
   bool serve_active = false;
+  bool serve_joined = false;  // serve_join has been recorded (a closed session's exit)
   int64_t serve_cap[4] = {0, 0, 0, 0};  // cs_serve_max_envs by kernel variant (queried once: begin may be captured)
 };
 
@@ -885,6 +886,8 @@ int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_
   v.num_steps = (uint32_t)num_steps;
   // every polled word (tags, control) is zeroed per session: tags are session-relative, so a hipGraph of the
   // feeders of one session can be replayed against every later session
+  if (ctx->serve_joined)  // a session closed without waiting may still be running: the rings are its until it exits
+    CS_HIP(hipStreamWaitEvent(stream, ctx->serve_join, 0));
   CS_HIP(hipMemsetAsync(ctx->serve_mem, 0, total, stream));
   CS_HIP(hipEventRecord(ctx->serve_fork, stream));
   CS_HIP(hipStreamWaitEvent(ctx->serve_stream, ctx->serve_fork, 0));
@@ -964,6 +967,7 @@ int cs_serve_end(cs_ctx* ctx, void* stream_, int32_t* steps_done) {
   if (e != hipSuccess) return hip_fail(e, "cs_serve_end: kernel launch");
   CS_HIP(hipEventRecord(ctx->serve_join, ctx->serve_stream));
   CS_HIP(hipStreamWaitEvent(stream, ctx->serve_join, 0));
+  ctx->serve_joined = true;
   ctx->serve_active = false;
   if (steps_done == nullptr) return CS_OK;  // enqueue only: cs_serve_status reports later
   CS_HIP(hipStreamSynchronize(stream));
