@@ -144,10 +144,18 @@ class CopterVecEnv:
         assert (od.value, ad.value) == (self.obs_dim, self.action_dim), "library / binding disagree on shapes"
         n = self.num_envs
         with torch.cuda.device(self.device):
-            self._obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=self.device)
-            self._reward = torch.empty(n, dtype=torch.float32, device=self.device)
-            self._term = torch.empty(n, dtype=torch.uint8, device=self.device)
-            self._trunc = torch.empty(n, dtype=torch.uint8, device=self.device)
+            # the default outputs are sections of ONE byte buffer [obs f32 | reward f32 | terminated u8 | truncated
+            # u8] (each 16-byte aligned): the NumPy convenience path ships them to the host as one copy
+            up = lambda b: (b + 15) // 16 * 16
+            o_r = up(n * self.obs_dim * 4)
+            o_t = o_r + up(n * 4)
+            o_u = o_t + up(n)
+            self._packbuf = torch.empty(o_u + up(n), dtype=torch.uint8, device=self.device)
+            self._pack_off = (o_r, o_t, o_u)
+            self._obs = self._packbuf[:n * self.obs_dim * 4].view(torch.float32).view(n, self.obs_dim)
+            self._reward = self._packbuf[o_r:o_r + n * 4].view(torch.float32)
+            self._term = self._packbuf[o_t:o_t + n]
+            self._trunc = self._packbuf[o_u:o_u + n]
             self._final_obs = None
             self._done = None
         self._cache_outputs()
@@ -206,7 +214,22 @@ class CopterVecEnv:
         torch = _torch()
         was_numpy = not isinstance(a, torch.Tensor)
         if was_numpy:
-            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+            arr = np.asarray(a, dtype=np.float32)
+            if name == "actions" and arr.shape == tuple(shape):
+                # NumPy actions every step: stage them in pinned memory (an H2D from pageable memory is a
+                # synchronous double copy) and keep a resident destination
+                st = getattr(self, "_act_stage", None)
+                if st is None:
+                    st = self._act_stage = (torch.empty(shape, dtype=torch.float32).pin_memory(),
+                                            torch.empty(shape, dtype=torch.float32, device=self.device),
+                                            torch.cuda.Event())
+                else:
+                    st[2].synchronize()            # the previous upload has left the pinned buffer
+                st[0].numpy()[...] = arr
+                st[1].copy_(st[0], non_blocking=True)
+                st[2].record(torch.cuda.current_stream(self.device))
+                return st[1], True
+            t = torch.from_numpy(np.ascontiguousarray(arr))
         else:
             t = a
         if tuple(t.shape) != tuple(shape):
@@ -349,25 +372,27 @@ class CopterVecEnv:
         return self._obs, self._reward, term, trunc, infos
 
     def _outputs_to_numpy(self):
-        """The NumPy convenience path: obs, reward and both flags cross PCIe as ONE device-to-host copy of a
-        packed byte buffer (one device-side gather into it, one blocking copy) instead of four."""
+        """The NumPy convenience path: obs, reward and both flags cross PCIe as ONE device-to-host copy into a
+        pinned buffer, and the arrays returned are views of it -- two buffers alternate, so what a step returned
+        stays valid until the step after the next one (copy what you keep longer)."""
         torch = _torch()
         n, od = self.num_envs, self.obs_dim
-        pk = getattr(self, "_pack", None)
-        if pk is None:
-            o_r, o_t = n * od * 4, n * od * 4 + n * 4
-            dev = torch.empty(o_t + 2 * n, dtype=torch.uint8, device=self.device)
-            host = torch.empty(o_t + 2 * n, dtype=torch.uint8).pin_memory()
-            pk = self._pack = (dev, host, o_r, o_t)
-        dev, host, o_r, o_t = pk
-        dev[:o_r].view(torch.float32).view(n, od).copy_(self._obs)
-        dev[o_r:o_t].view(torch.float32).copy_(self._reward)
-        dev[o_t:o_t + n].copy_(self._term)
-        dev[o_t + n:].copy_(self._trunc)
-        host.copy_(dev)                                   # the one blocking D2H
+        o_r, o_t, o_u = self._pack_off
+        if self._obs.data_ptr() != self._packbuf.data_ptr():       # outputs re-bound by the caller: gather them first
+            self._packbuf[:n * od * 4].view(torch.float32).view(n, od).copy_(self._obs)
+            self._packbuf[o_r:o_r + n * 4].view(torch.float32).copy_(self._reward)
+            self._packbuf[o_t:o_t + n].copy_(self._term)
+            self._packbuf[o_u:o_u + n].copy_(self._trunc)
+        hosts = getattr(self, "_pack_host", None)
+        if hosts is None:
+            hosts = self._pack_host = [torch.empty(self._packbuf.numel(), dtype=torch.uint8).pin_memory() for _ in (0, 1)]
+            self._pack_turn = 0
+        host = hosts[self._pack_turn]
+        self._pack_turn ^= 1
+        host.copy_(self._packbuf)                          # the one blocking D2H
         h = host.numpy()
-        return (h[:o_r].view(np.float32).reshape(n, od).copy(), h[o_r:o_t].view(np.float32).copy(),
-                h[o_t:o_t + n].astype(bool), h[o_t + n:].astype(bool))
+        return (h[:n * od * 4].view(np.float32).reshape(n, od), h[o_r:o_r + n * 4].view(np.float32),
+                h[o_t:o_t + n].view(np.bool_), h[o_u:o_u + n].view(np.bool_))
 
     def step_prefetch(self, actions, next_actions):
         """step(actions) for open-loop callers that already hold the NEXT action batch as a device
