@@ -15,6 +15,40 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that hangs must fail by itself, not take the whole run with it: every gpu test gets a 700 s
+    limit when pytest-timeout is there (the slowest, the RCCL children with one retry, stay under 11 minutes
+    even on a cold box; a normal test takes well under a second)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(700))
+
+
+def pytest_runtest_logstart(nodeid, location):
+    """The test now running, for a run that never comes back (gpurun merges gpurun_out/ also after a timeout)."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "current_test.txt"), "w") as f:
+            f.write(nodeid + "\n")
+    except OSError:
+        pass
+
+
+def pytest_runtest_logreport(report):
+    """Any gpu test that takes more than 10 s leaves a line (and what it printed) in gpurun_out/slow_tests.txt:
+    a run that was slow or was cut off can be explained afterwards."""
+    if report.when != "call" or report.duration < 10.0 or "gpu" not in report.keywords:
+        return
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "slow_tests.txt"), "a") as f:
+            f.write("%8.1f s  %s  %s\n%s\n" % (report.duration, report.outcome, report.nodeid, report.capstdout[-8000:]))
+    except OSError:
+        pass
+
+
 def pytest_sessionstart(session):
     """A fresh checkout has no built artefacts (they are git-ignored): build the library and the C++
     host programs once, exactly as __graft_entry__.build() does, when hipcc is available.  (hipcc

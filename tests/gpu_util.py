@@ -94,14 +94,35 @@ MODE_TOL = {"float64": 1e-11, "float32": 2e-8, "float32_rn": 5e-6}
 
 
 def run_with_rccl(cmd, env, timeout, cwd=None):
-    """subprocess.run for a child that opens an RCCL process group.  One retry for ONE known third-party failure:
-    ProcessGroupNCCL's watchdog thread aborting the process (SIGABRT, 'ProcessGroupNCCL' + 'Watchdog' in the
-    child's stderr) when its event query races a stream capture or the teardown -- seen about once in fifteen
-    cold starts on the GPU box, in PyTorch's code, not in this repository's.  Anything else fails at once."""
+    """subprocess.run for a child that opens an RCCL process group.  One retry for TWO known third-party failures,
+    both in ProcessGroupNCCL's watchdog thread (PyTorch's code, not this repository's), seen about once in fifteen
+    cold starts on the GPU box: the watchdog aborting the process (SIGABRT, 'ProcessGroupNCCL' + 'Watchdog' in the
+    child's stderr) when its event query races a stream capture or the teardown, and -- rarer -- the child not
+    coming back at all.  A child that overruns `timeout` is sent SIGABRT (PYTHONFAULTHANDLER=1: its Python stacks
+    land in stderr and are printed here), then retried once.  Anything else fails at once."""
+    import signal
     import subprocess
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=cwd)
-    if p.returncode != 0 and "ProcessGroupNCCL" in p.stderr and "Watchdog" in p.stderr:
-        print("note: ProcessGroupNCCL watchdog abort in the child (rc %d); retrying once" % p.returncode)
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=cwd)
-    return p
+    env = dict(env, PYTHONFAULTHANDLER="1")
 
+    def once():
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=cwd)
+        try:
+            out, err = child.communicate(timeout=timeout)
+            return subprocess.CompletedProcess(cmd, child.returncode, out, err), False
+        except subprocess.TimeoutExpired:
+            child.send_signal(signal.SIGABRT)
+            try:
+                out, err = child.communicate(timeout=30)
+            except subprocess.TimeoutExpired:
+                child.kill()
+                out, err = child.communicate()
+            return subprocess.CompletedProcess(cmd, -signal.SIGABRT, out, "TIMEOUT after %d s\n%s" % (timeout, err)), True
+
+    p, hung = once()
+    if hung:
+        print("note: RCCL child did not return in %d s; its stacks:\n%s\nretrying once" % (timeout, p.stderr[-6000:]))
+        p, _ = once()
+    elif p.returncode != 0 and "ProcessGroupNCCL" in p.stderr and "Watchdog" in p.stderr:
+        print("note: ProcessGroupNCCL watchdog abort in the child (rc %d); retrying once" % p.returncode)
+        p, _ = once()
+    return p

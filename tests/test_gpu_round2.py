@@ -467,7 +467,7 @@ def test_sharded_env_in_a_spawned_nccl_process_group(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     from gpu_util import run_with_rccl
-    p = run_with_rccl([sys.executable, str(script)], env, 600)
+    p = run_with_rccl([sys.executable, str(script)], env, 240)
     assert p.returncode == 0 and "SHARDED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
@@ -482,7 +482,7 @@ def test_bench_as_a_torchrun_rank_with_gather_legs(tmp_path):
            "--min-region-ms", "5", "--regions", "3"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     from gpu_util import run_with_rccl
-    p = run_with_rccl(cmd, env, 900, cwd=str(tmp_path))
+    p = run_with_rccl(cmd, env, 300, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]

@@ -480,7 +480,7 @@ def test_a_real_rccl_all_gather_runs_on_one_gpu(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     from gpu_util import run_with_rccl
-    p = run_with_rccl([sys.executable, str(script)], env, 600)
+    p = run_with_rccl([sys.executable, str(script)], env, 240)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
     legs = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("RCCL_LEG")]
     assert [l[1] for l in legs] == ["obs", "all"]
@@ -499,7 +499,7 @@ def test_bench_gather_on_one_gpu_reports_what_rccl_saw(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("COPTERSTEP_FORCE_COLLECTIVE", None)
     from gpu_util import run_with_rccl
-    p = run_with_rccl(cmd, env, 900, cwd=str(tmp_path))
+    p = run_with_rccl(cmd, env, 300, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
