@@ -440,13 +440,25 @@ extern "C" int cs_debug_read_stamps(cs_ctx* ctx, unsigned long long* host, void*
 int cs_destroy(cs_ctx* ctx) {
   if (ctx == nullptr) return CS_OK;
   DeviceGuard guard(ctx->cfg.device);
-  if (ctx->st.tiles) (void)hipFree(ctx->st.tiles);
-  if (ctx->pid_state) (void)hipFree(ctx->pid_state);
-  if (ctx->veh) (void)hipFree(ctx->veh);
   if (ctx->serve_stream) {
+    // the env kernel of a session stores its tiles when it exits: it has to be gone before they are freed.  A
+    // session that is still open is told to stop (from a stream of its own: the caller's may hold feeders that
+    // are waiting for it), so that destroying a context costs a poll interval, not the session's timeout.
+    if (ctx->serve_active) {
+      hipStream_t side = nullptr;
+      if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess) {
+        (void)cs::launch_serve_stop(ctx->serve.ctrl, side);
+        (void)hipStreamSynchronize(side);
+        (void)hipStreamDestroy(side);
+      }
+      (void)hipGetLastError();
+    }
     (void)hipStreamSynchronize(ctx->serve_stream);
     (void)hipStreamDestroy(ctx->serve_stream);
   }
+  if (ctx->st.tiles) (void)hipFree(ctx->st.tiles);
+  if (ctx->pid_state) (void)hipFree(ctx->pid_state);
+  if (ctx->veh) (void)hipFree(ctx->veh);
   if (ctx->serve_fork) (void)hipEventDestroy(ctx->serve_fork);
   if (ctx->serve_join) (void)hipEventDestroy(ctx->serve_join);
   if (ctx->serve_mem) (void)hipFree(ctx->serve_mem);

@@ -357,6 +357,30 @@ def test_served_session_stops_early_on_request():
     plain.close()
 
 
+def test_closing_a_context_with_an_open_session_stops_it_first():
+    """cs_destroy with a session still open: the env kernel is told to stop and waited for BEFORE its tiles are
+    freed (it stores them when it exits), and that costs a poll interval, not the session's 30 s timeout."""
+    import time
+    import torch
+    n = 4096
+    import gym_copter_amd
+    env = gym_copter_amd.CopterVecEnv(task="lander3d", num_envs=n, seed=2, autoreset_mode="next_step")
+    env.reset()
+    acts = torch.rand((n, 4), device=env.device)
+    env.serve_begin(1000, timeout=30.0)
+    for s in range(3):
+        env.serve_submit(s, acts)
+    torch.cuda.current_stream().synchronize()
+    t0 = time.time()
+    env.close()
+    assert time.time() - t0 < 5.0
+    other = gym_copter_amd.CopterVecEnv(task="lander3d", num_envs=n, seed=3)     # the device is fine afterwards
+    other.reset()
+    other.step(acts)
+    torch.cuda.synchronize()
+    other.close()
+
+
 def test_served_feeders_captured_in_a_hipgraph_replay_against_every_session():
     """The K x (submit, collect) launches of one session captured ONCE and replayed against later sessions:
     tags are session-relative and cs_serve_begin zeroes the rings.  begin / end themselves refuse a capturing
