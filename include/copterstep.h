@@ -189,7 +189,7 @@ const char* cs_last_error(void);
 
 int cs_config_init(cs_config* cfg, int task);
 int cs_create(const cs_config* cfg, cs_ctx** out);
-int cs_destroy(cs_ctx* ctx);
+int cs_destroy(cs_ctx* ctx);   /* waits for the context's queued work; a served session still open is stopped first */
 
 int cs_num_envs(const cs_ctx* ctx, int64_t* out);
 int cs_obs_dim(const cs_ctx* ctx, int32_t* out);
