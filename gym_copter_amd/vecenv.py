@@ -70,7 +70,7 @@ class CopterVecEnv:
                  time_limit_truncates=False, episode_stats=False, env_id_base=0,
                  max_steps=1000, vehicle_params=None, frames_per_second=None,
                  action_arith="float64", thrust_model="B", rotor_gyro=False, world_params=None,
-                 track_time=False, **task_kwargs):
+                 track_time=False, copy=True, **task_kwargs):
         lib = _lib.load()
         torch = _torch()
         if task not in _TASKS:
@@ -126,6 +126,7 @@ class CopterVecEnv:
         self.autoreset_mode = autoreset_mode
         self.episode_stats = bool(episode_stats)
         self.track_time = bool(track_time)
+        self.copy = bool(copy)              # as gymnasium.vector.SyncVectorEnv(copy=True): NumPy returns are the caller's
         self.device = torch.device("cuda", int(device))
         first, self.obs_dim, self.action_dim = _TASK_SHAPES[self.task]
         self.STATE_NAMES = STATE_NAMES_12[first:first + self.obs_dim]   # lander.py:30-31
@@ -372,9 +373,11 @@ class CopterVecEnv:
         return self._obs, self._reward, term, trunc, infos
 
     def _outputs_to_numpy(self):
-        """The NumPy convenience path: obs, reward and both flags cross PCIe as ONE device-to-host copy into a
-        pinned buffer, and the arrays returned are views of it -- two buffers alternate, so what a step returned
-        stays valid until the step after the next one (copy what you keep longer)."""
+        """The NumPy convenience path: obs, reward and both flags cross PCIe as ONE device-to-host copy and the
+        arrays returned are views of that host buffer.  copy=True (the default, as gymnasium.vector.SyncVectorEnv):
+        a fresh buffer every step -- the arrays are the caller's to keep.  copy=False: two PINNED buffers
+        alternate (no staging copy, no allocation), so what a step returned stays valid only until the step
+        after the next one."""
         torch = _torch()
         n, od = self.num_envs, self.obs_dim
         o_r, o_t, o_u = self._pack_off
@@ -383,14 +386,18 @@ class CopterVecEnv:
             self._packbuf[o_r:o_r + n * 4].view(torch.float32).copy_(self._reward)
             self._packbuf[o_t:o_t + n].copy_(self._term)
             self._packbuf[o_u:o_u + n].copy_(self._trunc)
-        hosts = getattr(self, "_pack_host", None)
-        if hosts is None:
-            hosts = self._pack_host = [torch.empty(self._packbuf.numel(), dtype=torch.uint8).pin_memory() for _ in (0, 1)]
-            self._pack_turn = 0
-        host = hosts[self._pack_turn]
-        self._pack_turn ^= 1
+        if self.copy:
+            host = torch.empty(self._packbuf.numel(), dtype=torch.uint8)
+        else:
+            hosts = getattr(self, "_pack_host", None)
+            if hosts is None:
+                hosts = self._pack_host = [torch.empty(self._packbuf.numel(), dtype=torch.uint8).pin_memory()
+                                           for _ in (0, 1)]
+                self._pack_turn = 0
+            host = hosts[self._pack_turn]
+            self._pack_turn ^= 1
         host.copy_(self._packbuf)                          # the one blocking D2H
-        h = host.numpy()
+        h = host.numpy()                                   # (shares the tensor's memory and keeps it alive)
         return (h[:n * od * 4].view(np.float32).reshape(n, od), h[o_r:o_r + n * 4].view(np.float32),
                 h[o_t:o_t + n].view(np.bool_), h[o_u:o_u + n].view(np.bool_))
 

@@ -747,3 +747,30 @@ def test_caller_side_policy_kernel_on_the_public_device_header():
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
     assert "serve_policy_host: OK" in p.stdout
+
+
+def test_numpy_returns_are_the_callers_to_keep_unless_copy_is_off():
+    """gymnasium.vector.SyncVectorEnv(copy=True) semantics on the NumPy convenience path: by default what step()
+    returned is not touched by later steps; copy=False hands out views of two alternating pinned buffers."""
+    import gym_copter_amd
+    n = 1000
+    rng = np.random.default_rng(5)
+    acts = [rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(4)]
+    for copy in (True, False):
+        env = gym_copter_amd.CopterVecEnv(task="lander3d", num_envs=n, seed=9, copy=copy)
+        twin = gym_copter_amd.CopterVecEnv(task="lander3d", num_envs=n, seed=9)
+        env.reset()
+        twin.reset()
+        kept, want = [], []
+        for a in acts:
+            kept.append(env.step(a)[:4])
+            want.append(tuple(np.array(v) for v in twin.step(a)[:4]))
+        assert all(isinstance(v, np.ndarray) for v in kept[0])
+        for j in range(len(acts)):
+            same = all(np.array_equal(k, w) for k, w in zip(kept[j], want[j]))
+            if copy or j >= len(acts) - 2:
+                assert same, (copy, j)             # copy=False: the last two steps' views are still intact
+        if not copy:
+            assert np.shares_memory(kept[0][0], kept[2][0]) and not np.shares_memory(kept[0][0], kept[1][0])
+        env.close()
+        twin.close()

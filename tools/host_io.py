@@ -12,19 +12,20 @@ import torch  # noqa: E402
 import gym_copter_amd  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-env = gym_copter_amd.make("Lander-v0", num_envs=n, seed=1, autoreset_mode="next_step")
-env.reset()
 rng = np.random.default_rng(0)
 acts = [rng.uniform(-1, 1, (n, 4)).astype(np.float32) for _ in range(8)]
-for j in range(20):
-    env.step(acts[j % 8])
 K = 300
-t0 = time.perf_counter()
-for j in range(K):
-    obs, r, term, trunc, _ = env.step(acts[j % 8])      # NumPy in -> NumPy out (synchronous)
-dt = (time.perf_counter() - t0) / K
-assert isinstance(obs, np.ndarray)
-print("NumPy in/out (PCIe-inclusive): %d envs  %.1f us/step  %.3f G env-steps/s" % (n, dt * 1e6, n / dt / 1e9))
+for copy in (True, False):
+    env = gym_copter_amd.make("Lander-v0", num_envs=n, seed=1, autoreset_mode="next_step", copy=copy)
+    env.reset()
+    for j in range(20):
+        env.step(acts[j % 8])
+    t0 = time.perf_counter()
+    for j in range(K):
+        obs, r, term, trunc, _ = env.step(acts[j % 8])      # NumPy in -> NumPy out (synchronous)
+    dt = (time.perf_counter() - t0) / K
+    assert isinstance(obs, np.ndarray)
+    print("NumPy in/out (PCIe-inclusive), copy=%s: %d envs  %.1f us/step  %.3f G env-steps/s" % (copy, n, dt * 1e6, n / dt / 1e9))
 dev = [torch.from_numpy(a).to(env.device) for a in acts]
 torch.cuda.synchronize()
 t0 = time.perf_counter()
