@@ -103,6 +103,10 @@ def run_with_rccl(cmd, env, timeout, cwd=None):
     import signal
     import subprocess
     env = dict(env, PYTHONFAULTHANDLER="1")
+    # a world of one on this host: keep RCCL's bootstrap off whatever other interfaces the box has (probing an
+    # unreachable one costs minutes), as tests/test_gpu_parity.py::test_c_host_rccl_allgather does for the C host
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    env.setdefault("NCCL_IB_DISABLE", "1")
 
     def once():
         child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=cwd)
