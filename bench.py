@@ -562,6 +562,11 @@ def main(argv=None):
     rccl = None
     with stdout_to_stderr():
         if dist is not None:
+            if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+                # one node (the contract): RCCL's bootstrap sockets belong on the loopback interface -- probing
+                # whatever else the box has can cost minutes; the data path is xGMI either way
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+                os.environ.setdefault("NCCL_IB_DISABLE", "1")
             dist.init_process_group("nccl", device_id=device)
         timer.barrier()      # (N > 1: the communicator is set up here, outside every timed region)
         if dist is not None:
