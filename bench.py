@@ -42,7 +42,6 @@ all-gather over RCCL (--gather) is timed separately and reported as value_with_a
 import argparse
 import json
 import os
-import statistics
 import subprocess
 import sys
 import time

@@ -17,7 +17,6 @@ gym_copter/envs/task.py:161 builds one Dynamics per env), so the batch shards tr
 """
 import os
 
-import numpy as np
 
 
 def _force_collective(flag):

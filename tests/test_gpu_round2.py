@@ -4,7 +4,6 @@ air density, rotor-inertia term), the device-side Dynamics.perturb / batch stati
 the 64-bit tile addressing at the context size limit, odd batch sizes in the K-step kernels, and the
 sharded env under RCCL in a spawned process group."""
 import os
-import subprocess
 import sys
 
 import numpy as np

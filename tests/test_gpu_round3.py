@@ -7,8 +7,8 @@ import numpy as np
 import pytest
 
 from conftest import load_cases
-from gpu_util import (MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu, make_pair,
-                      scaled_err, step_both, to_np)
+from gpu_util import (MODE_TOL, assert_state_close, assert_step_close, have_gpu, make_pair,
+                      step_both, to_np)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 

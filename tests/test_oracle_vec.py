@@ -6,7 +6,7 @@ import pytest
 
 from conftest import load_cases
 from oracle import refvec
-from oracle.refcpu import AIRBORNE, DJI_PHANTOM, LANDED, TaskOracle, TaskParams
+from oracle.refcpu import AIRBORNE, TaskOracle, TaskParams
 from oracle.refvec import VecOracle, draw_forces, philox2x32_10
 
 DYN = load_cases("dynamics_traces.npz")

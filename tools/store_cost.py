@@ -5,7 +5,6 @@ output pointers withheld (cs_step accepts NULL for each), hipGraph replay of 100
 import ctypes as C
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
