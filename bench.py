@@ -754,6 +754,36 @@ def main(argv=None):
                    "kernel sustains when it never waits for a policy")
     if a.served > 0 and world == 1:
         served_legs()
+
+    def fused_policy_leg():
+        # the caller's OWN policy fused into the K-step kernel (include/copterstep_rollout.h): such a kernel lives in
+        # the caller's translation unit, so the figure comes from the third-party-style test program, run as a child
+        # (same GPU, this process idle meanwhile); it checks itself against cs_step_many / cs_step before it times
+        exe = os.path.join(ROOT, "tests", "host", "rollout_policy_host")
+        if not os.path.exists(exe):
+            return
+        try:
+            p = subprocess.run([exe, "time"], capture_output=True, text=True, timeout=120)
+            import re
+            m = re.search(r"(\d+) envs, (\d+) steps per launch.*?cs_rollout_random ([\d.]+)\s+cs_step_many ([\d.]+)\s+"
+                          r"custom replay policy ([\d.]+)\s+custom closed-loop policy with state ([\d.]+)\s+"
+                          r"custom linear policy \(44 weights\) ([\d.]+)", p.stdout)
+            if p.returncode != 0 or m is None or "rollout_policy_host: OK" not in p.stdout:
+                extra["rollout_custom"] = {"error": "rc %d: %s" % (p.returncode, (p.stdout + p.stderr)[-300:])}
+                return
+            extra["rollout_custom"] = {
+                "envs": int(m.group(1)), "steps_per_launch": int(m.group(2)), "unit": "us per env step",
+                "same_run": {"cs_rollout_random": float(m.group(3)), "cs_step_many": float(m.group(4))},
+                "replay_policy": float(m.group(5)), "closed_loop_law_with_state": float(m.group(6)),
+                "linear_policy_44_weights": float(m.group(7)),
+                "note": "tests/host/rollout_policy_host.hip: caller-side device functors instantiated into the K-step "
+                        "kernel in the caller's translation unit; eager launches timed with HIP events; verified "
+                        "bit-identical to cs_step_many / a twin stepped with cs_step in the same run"}
+        except Exception as e:              # an extra never costs the headline
+            extra["rollout_custom"] = {"error": repr(e)}
+    if a.pid > 0 and world == 1 and not any(k.startswith("ROCPROF") for k in os.environ) \
+            and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
+        fused_policy_leg()
     env.close()
     del stepper, env, actions
     torch.cuda.empty_cache()
@@ -882,6 +912,9 @@ def main(argv=None):
                             for k in ("served_closed_loop", "served_closed_loop_persistent_policy",
                                       "served_submit_collect", "served_producers_ahead")
                             if "us_per_step" in extra.get(k, {})},
+              "fused_caller_policy_us": {k: extra["rollout_custom"][k] for k in
+                                         ("closed_loop_law_with_state", "linear_policy_44_weights", "replay_policy")
+                                         if k in extra.get("rollout_custom", {})},
               "rccl": rccl}
     out["roofline"]["digest"] = digest
     out["summary"] = digest

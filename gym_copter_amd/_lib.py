@@ -87,7 +87,15 @@ class ServeView(C.Structure):
                 ("act_dim", C.c_uint32), ("num_envs", C.c_uint32), ("num_steps", C.c_uint32)]
 
 
-ERR_TIMEOUT = -6
+class LaunchView(C.Structure):
+    """cs_launch_view (include/copterstep.h): what a kernel of include/copterstep_rollout.h is launched on."""
+    _fields_ = [("struct_size", C.c_uint32), ("abi_version", C.c_uint32), ("consts_size", C.c_uint32),
+                ("state_size", C.c_uint32), ("task", C.c_int32), ("state_mode", C.c_int32), ("lean", C.c_int32),
+                ("one_call", C.c_int32), ("direct_rows", C.c_int32), ("grid", C.c_uint32), ("block", C.c_uint32),
+                ("reserved_", C.c_uint32), ("num_envs", C.c_int64), ("consts", C.c_void_p), ("state", C.c_void_p)]
+
+
+ERR_ARG, ERR_TIMEOUT = -1, -6
 PID_LANDER, PID_HOVER = 0, 1
 PID_ROWS = 24          # 6 controllers x {errorI, lastError, deltaError1, deltaError2}
 
@@ -125,6 +133,7 @@ SYMBOLS = {
     "cs_pid_set_state": (C.c_int, [_P, _P, _P]),
     "cs_rollout_pid": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cs_rollout_random": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "cs_get_launch_view": (C.c_int, [_P, _P]),   # for include/copterstep_rollout.h (HIP callers); LaunchView below
     "cs_serve_max_envs": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "cs_serve_begin": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_double, _P, C.POINTER(ServeView)]),
     "cs_serve_submit": (C.c_int, [_P, C.c_int32, _P, _P]),

@@ -581,6 +581,30 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
   return CS_OK;
 }
 
+int cs_get_launch_view(cs_ctx* ctx, cs_launch_view* view) {
+  if (int rc_ = check_idle(ctx, "cs_get_launch_view")) return rc_;
+  if (view == nullptr) return fail(CS_ERR_ARG, "cs_get_launch_view: null view");
+  const cs::DevConst& c = constants(ctx);
+  const uint32_t direct_max =
+      ctx->tune.direct_rows_max_envs ? ctx->tune.direct_rows_max_envs : cs::default_tuning().direct_rows_max_envs;
+  std::memset(view, 0, sizeof *view);
+  view->struct_size = (uint32_t)sizeof *view;
+  view->abi_version = CS_ABI_VERSION;
+  view->consts_size = (uint32_t)sizeof(cs::DevConst);
+  view->state_size = (uint32_t)sizeof(cs::DevState);
+  view->task = ctx->cfg.task;
+  view->state_mode = ctx->cfg.state_mode;
+  view->lean = cs::launch_is_lean(c, ctx->st) ? 1 : 0;
+  view->one_call = c.nsub == 1 ? 1 : 0;
+  view->direct_rows = ctx->st.n <= direct_max ? 1 : 0;
+  view->grid = (ctx->st.n + 63u) / 64u;  // one 64-thread workgroup per tile of 64 envs (dev_tile.h: kBlock)
+  view->block = 64u;
+  view->num_envs = ctx->cfg.num_envs;
+  view->consts = &c;
+  view->state = &ctx->st;
+  return CS_OK;
+}
+
 int cs_set_vehicle_params(cs_ctx* ctx, const double* params_host) {
   if (int rc_ = check_idle(ctx, "cs_set_vehicle_params")) return rc_;
   if (ctx->cfg.action_arith == CS_ARITH_F32 && params_host != nullptr)

@@ -197,6 +197,8 @@ struct Tuning {
 };
 
 Tuning default_tuning();
+// the launchers' own choice between the lean and the full-featured instantiations (dev_launch.h: lean_config)
+bool launch_is_lean(const DevConst& c, const DevState& s);
 
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                        const cs_step_io& io, const Tuning& tune, hipStream_t stream);

@@ -773,6 +773,7 @@ hipError_t reset_t(const DevConst& c, const DevState& s, const uint8_t* mask, co
 }  // namespace
 
 Tuning default_tuning() { return Tuning{kNtActionMaxEnvs, kNtStateMinEnvs, kDirectRowsMaxEnvs}; }
+bool launch_is_lean(const DevConst& c, const DevState& s) { return lean_config(c, s); }
 
 hipError_t launch_step(int task, int mode, const DevConst& c, const DevState& s,
                        const cs_step_io& io, const Tuning& tune, hipStream_t stream) {

@@ -33,6 +33,7 @@
  *                                                               attic/mars/lander3d.py:32-36,64-87
  *   cs_rollout_random        the `--random` action loop         lander.py:40-65 (action = MOTORVAL*randn / action_space.sample())
  *   cs_serve_*               the caller's policy <-> step loop  lander.py:40-65, attic/drl/3dtest.py:44-59 (persistent env kernel)
+ *   cs_get_launch_view       the same loop with the caller's policy FUSED into the K-step kernel (copterstep_rollout.h)
  *
  * Conventions
  *   - Every function returns CS_OK (0) or a negative cs_status; cs_last_error() then
@@ -282,6 +283,29 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
 int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
                       float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
                       void* stream);
+
+/* The caller's OWN policy fused into the K-step kernel (include/copterstep_rollout.h: a HIP source-level
+ * extension point -- the policy <-> env.step() loop of lander.py:40-65 / attic/drl/3dtest.py:44-59 for any
+ * policy written as a device functor).  cs_get_launch_view hands that header what a kernel instantiated in the
+ * caller's translation unit is launched on: the context's folded constants and state view (opaque here; the
+ * header checks their sizes against its own build of the device headers), the instantiation the library
+ * itself would pick (lean / one physics call per step / per-lane row stores) and the launch shape.  The
+ * pointers are into the context: valid until its configuration changes (cs_seed, cs_set_altitude,
+ * cs_set_vehicle_params, cs_set_tuning) or it is destroyed.  Refused while a served session is open. */
+typedef struct cs_launch_view {
+  uint32_t struct_size;   /* in: sizeof(cs_launch_view) */
+  uint32_t abi_version;   /* out: CS_ABI_VERSION of the library */
+  uint32_t consts_size;   /* sizeof(cs::DevConst) / sizeof(cs::DevState) of the library's build */
+  uint32_t state_size;
+  int32_t task, state_mode;
+  int32_t lean, one_call, direct_rows;
+  uint32_t grid, block;   /* workgroups (= tiles of 64 envs), threads per workgroup (64) */
+  uint32_t reserved_;
+  int64_t num_envs;
+  const void* consts;
+  const void* state;
+} cs_launch_view;
+int cs_get_launch_view(cs_ctx* ctx, cs_launch_view* view);
 
 /* Per-env vehicles and worlds (domain randomisation).  params_host: [CS_VEHICLE_ROWS, N] float64,
  * rows B, D, M, L, Ix, Iy, Iz, Jr, maxrpm -- the keys of the `vehicle_params` dict that

@@ -1,0 +1,202 @@
+/*
+ * copterstep_rollout.h -- the caller's OWN policy fused into the stepping kernel: K closed-loop steps per launch
+ * with the env in registers between the steps, for any policy that can be written as a HIP device functor.
+ *
+ * What it replaces upstream: the policy <-> env.step() loop of a caller (lander.py:40-65,
+ * attic/drl/3dtest.py:44-59, attic/neat/3dtest.py:21-22).  cs_rollout_pid / cs_rollout_random (copterstep.h) are
+ * this loop for the two policies the reference ships; this header is the same kernel with the policy left open.
+ * It is what removes BOTH the per-step launch and the hand-off through memory for a caller-supplied policy
+ * (a launch boundary costs 1.4-1.8 us per step, a hand-off to a persistent kernel ~2 us;
+ * a fused policy costs its own arithmetic).
+ *
+ * A SOURCE-LEVEL extension point, HIP only (gfx950): the kernel is instantiated in the caller's translation
+ * unit from the library's device headers, and launched on the launch view of a context (cs_get_launch_view,
+ * copterstep.h), whose layout is checked against this build's before anything is launched.
+ *
+ *   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I gym_copter_amd/csrc my_rollout.hip -L gym_copter_amd -lcopterstep
+ *
+ * The policy is a trivially copyable functor, passed by value to every thread (one thread = one env):
+ *
+ *   struct MyPolicy {
+ *     // per-env policy state lives in members (registers across the K steps of a launch) and, between
+ *     // launches, wherever load() / store() keep it.  `env` < the padded batch (whole tiles of 64): size
+ *     // per-env arrays with cs_rollout_padded_envs(); `valid` is false for the padding lanes.
+ *     __device__ void load(uint32_t env, bool valid);
+ *     __device__ void store(uint32_t env, bool valid);
+ *     // obs    what the previous step returned (k = 0: the stored state), float32, the task's observation
+ *     // k      step of this launch;  fresh: the env started a new episode in the previous step (obs is then
+ *     //        the reset observation, as with auto-reset in cs_step) -- forget per-episode state
+ *     // action the task's action row (4 / 2 / 1 values), unclipped (the env clips: task.py:91)
+ *     __device__ void operator()(const float (&obs)[OBS], uint32_t env, int k, bool fresh, float (&action)[ACT]);
+ *   };
+ *
+ *   cs_rollout_custom<CS_TASK_LANDER3D, CS_STATE_F32G>(ctx, K, MyPolicy{...}, actions_out, obs, reward, term, trunc, stream);
+ *
+ * Outputs are those of cs_step_many ([K,N,...] row blocks; any may be NULL); actions_out ([K,N,ACT], may be
+ * NULL) records what the policy chose.  Every step is the same advance() that cs_step runs (same rounding: the
+ * device headers forbid floating-point contraction), so a policy that replays recorded actions gives
+ * bit-identical results to cs_step_many -- tests/host/rollout_policy_host.hip checks that and a closed loop.
+ */
+#ifndef COPTERSTEP_ROLLOUT_H
+#define COPTERSTEP_ROLLOUT_H
+
+#include "copterstep.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "copterstep_internal.h"
+
+#pragma clang fp contract(off) /* as in the library's own kernels: the step must round identically everywhere */
+
+#include "dev_tile.h"
+#include "dev_codec.h"
+#include "dev_math.h"
+#include "dev_physics.h"
+#include "dev_task.h"
+#include "dev_pid.h"
+
+namespace cs {
+namespace {
+
+template <int TASK, int MODE, bool LEAN, bool ONE_CALL, bool DIRECT_ROWS, class POLICY>
+__global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
+    char* const tiles, const uint32_t n_envs, float* const actions_dev, float* const obs_dev, float* const reward_dev,
+    uint8_t* const terminated_dev, uint8_t* const truncated_dev, const int num_steps, const DevConst c_arg,
+    const DevState s_rest, POLICY policy) {
+  using T = typename ModeOf<MODE>::T;
+  constexpr int OBS = task_obs_dim(TASK), FIRST = task_obs_first(TASK), ACT = task_act_dim(TASK);
+  DevConst c = c_arg;
+  park_constants<MODE == CS_STATE_F64>(c);   // loop body: the deep constants out of the scalar registers' way
+  DevState s = s_rest;
+  s.tiles = tiles;
+  s.n = n_envs;
+  __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
+  const uint32_t n = s.n;
+  const uint32_t tile_index = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t i = tile_index * kBlock + lane;
+  const uint32_t env0 = i - lane;
+  const bool valid = i < n;
+  using TILE = TileIO<MODE>;
+  const TILE tile(s, tile_index, lane);
+
+  Env<MODE> e;
+  {
+    const typename TILE::Group t2 = tile.load_group(1);
+    const typename TILE::Group r1 = tile.load_group(2);
+    const typename TILE::Group r2 = tile.load_group(3);
+    const typename TILE::Group t1 = tile.load_group(0);
+    unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
+  }
+  e.prev_sh = 0.0;
+  if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
+  StepOpts o;
+  o.stats = !LEAN && c.stats;
+  o.ticks = !LEAN && c.ticks;
+  o.trunc = !LEAN && c.tl_trunc;
+  o.done_list = false;
+  o.same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
+  o.gyro = !LEAN && c.gyro;
+  o.act_f32 = !LEAN && c.act_f32;
+  e.ep_ret = o.stats ? tile.load_ret() : 0.f;
+  e.ticks = o.ticks ? tile.load_ticks() : 0u;
+  cs_step_io io;  /* no optional outputs in the K-step forms */
+  io.actions_dev = io.next_actions_dev = nullptr;
+  io.obs_dev = io.reward_dev = io.final_obs_dev = io.done_return_dev = nullptr;
+  io.terminated_dev = io.truncated_dev = nullptr;
+  io.done_count_dev = io.done_ids_dev = io.done_length_dev = nullptr;
+  Coef q = uniform_coef(c);
+  if constexpr (!LEAN) {
+    if (s.veh != nullptr) q = load_coef(s.veh, s.veh_stride, i);
+  }
+  const uint32_t ia = valid ? i : 0u;
+
+  policy.load(i, valid);
+  float seen[OBS];
+#pragma unroll
+  for (int j = 0; j < OBS; ++j) seen[j] = (float)e.x[FIRST + j];
+  bool fresh = false;
+  for (int k = 0; k < num_steps; ++k) {
+    const size_t row = (size_t)k * n;  /* 64-bit uniform offsets: K * N can exceed 32 bits */
+    float a[ACT];
+    policy(seen, i, k, fresh, a);
+    float4 act;
+    if constexpr (ACT == 4) {  /* the task's motor fan-out (_get_motors of the 2D / 1D variants), as load_action() */
+      act = make_float4(a[0], a[1], a[2], a[3]);
+      if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
+    } else if constexpr (ACT == 2) {
+      act = make_float4(a[0], a[1], a[1], a[0]);
+      if (actions_dev != nullptr && valid) *at32<float2>(actions_dev + row * 2, ia << 3) = make_float2(a[0], a[1]);
+    } else {
+      act = make_float4(a[0], a[0], a[0], a[0]);
+      if (actions_dev != nullptr && valid) *at32<float>(actions_dev + row, ia << 2) = a[0];
+    }
+    StepOut<OBS> out;
+    advance<TASK, MODE, OBS, LEAN, ONE_CALL, true>(c, q, o, e, act, io, i, lane, valid, tile, out);
+#pragma unroll
+    for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
+    fresh = out.did_reset;
+    if (valid) {
+      if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
+      if (terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(terminated_dev + row, i));
+      if (truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(truncated_dev + row, i));
+    }
+    if constexpr (DIRECT_ROWS) {  /* one wavefront per SIMD: three row stores per lane cost fewer instructions */
+      if (obs_dev != nullptr && valid) {
+        float* dst = obs_dev + (row + i) * OBS;
+#pragma unroll
+        for (int j = 0; j < OBS; ++j) dst[j] = out.row[j];
+      }
+    } else {
+      write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
+    }
+  }
+  policy.store(i, valid);
+
+  store_env<MODE, TILE>(tile, e);
+  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
+  if (o.stats) tile.store_ret(e.ep_ret);
+  if (o.ticks) tile.store_ticks(e.ticks);
+}
+
+}  // namespace
+}  // namespace cs
+
+/* Envs of the batch rounded up to whole tiles of 64: the range of `env` a policy's load() / store() see. */
+static inline uint32_t cs_rollout_padded_envs(int64_t num_envs) { return (uint32_t)((num_envs + 63) / 64 * 64); }
+
+/* K closed-loop steps of every env under `policy`, one launch.  TASK / MODE must be the context's (checked).
+ * Returns CS_OK or a negative cs_status (cs_last_error() for the library's own refusals). */
+template <int TASK, int MODE, class POLICY>
+int cs_rollout_custom(cs_ctx* ctx, int num_steps, POLICY policy, float* actions_out, float* obs_dev, float* reward_dev,
+                      uint8_t* terminated_dev, uint8_t* truncated_dev, hipStream_t stream) {
+  static_assert(std::is_trivially_copyable<POLICY>::value, "the policy is passed to the kernel by value");
+  cs_launch_view v;
+  if (int rc = cs_get_launch_view(ctx, &v)) return rc;
+  if (v.consts_size != sizeof(cs::DevConst) || v.state_size != sizeof(cs::DevState) || v.block != (uint32_t)cs::kBlock)
+    return CS_ERR_ABI;  /* these device headers are not the ones libcopterstep.so was built from */
+  if (v.task != TASK || v.state_mode != MODE || num_steps < 1) return CS_ERR_ARG;
+  const cs::DevConst& c = *static_cast<const cs::DevConst*>(v.consts);
+  const cs::DevState& s = *static_cast<const cs::DevState*>(v.state);
+  const dim3 grid(v.grid), block(v.block);
+#define CS_ROLLOUT_LAUNCH(LEAN, ONE, DIRECT)                                                                        \
+  hipLaunchKernelGGL((cs::rollout_custom_kernel<TASK, MODE, LEAN, ONE, DIRECT, POLICY>), grid, block, 0, stream,    \
+                     s.tiles, s.n, actions_out, obs_dev, reward_dev, terminated_dev, truncated_dev, num_steps, c, s, \
+                     policy)
+  if (v.lean && v.one_call && v.direct_rows)
+    CS_ROLLOUT_LAUNCH(true, true, true);
+  else if (v.lean && v.one_call)
+    CS_ROLLOUT_LAUNCH(true, true, false);
+  else if (v.lean)
+    CS_ROLLOUT_LAUNCH(true, false, false);
+  else
+    CS_ROLLOUT_LAUNCH(false, false, false);
+#undef CS_ROLLOUT_LAUNCH
+  return hipGetLastError() == hipSuccess ? CS_OK : CS_ERR_HIP;
+}
+
+#endif /* __HIPCC__ */
+#endif /* COPTERSTEP_ROLLOUT_H */

@@ -56,7 +56,7 @@ def pytest_sessionstart(session):
     import shutil
     import subprocess
     lib = os.path.join(ROOT, "gym_copter_amd", "libcopterstep.so")
-    host = os.path.join(ROOT, "tests", "host", "serve_policy_host")      # the last target of `make all`
+    host = os.path.join(ROOT, "tests", "host", "rollout_policy_host")    # the last target of `make all`
     hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
     if (not os.path.exists(lib) or not os.path.exists(host)) and hipcc:
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "gym_copter_amd", "csrc"), "all",

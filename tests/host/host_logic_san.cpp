@@ -13,6 +13,7 @@
 
 namespace cs {
 Tuning default_tuning() { return Tuning{98304u, 3670016u, 65536u}; }
+bool launch_is_lean(const DevConst&, const DevState&) { return true; }
 hipError_t launch_step(int, int, const DevConst&, const DevState&, const cs_step_io&, const Tuning&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_step_many(int, int, const DevConst&, const DevState&, int, float*, float*, float*, uint8_t*, uint8_t*, int,
                             const PidConst*, double*, uint32_t, const Tuning&, hipStream_t) { return hipErrorUnknown; }

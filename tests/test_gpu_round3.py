@@ -749,6 +749,39 @@ def test_caller_side_policy_kernel_on_the_public_device_header():
     assert "serve_policy_host: OK" in p.stdout
 
 
+def test_caller_side_policy_fused_into_the_k_step_kernel():
+    """tests/host/rollout_policy_host.hip: the caller's OWN policy as a device functor, instantiated into the K-step
+    kernel in the caller's translation unit (include/copterstep_rollout.h on cs_get_launch_view): a replay policy is
+    bit-identical to cs_step_many, a closed-loop policy with per-env state is bit-identical to a twin stepped with
+    cs_step on the recorded actions (and the host re-evaluates the law from what the twin returned), on the lean and
+    on the full-featured instantiation; the wrong task is refused.  Prints us per env step at 65 536 envs."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "rollout_policy_host")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    p = subprocess.run([exe, "time"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert "rollout_policy_host: OK" in p.stdout
+    print(p.stdout)
+
+
+def test_launch_view_describes_the_context():
+    import ctypes as C
+    import gym_copter_amd
+    from gym_copter_amd import _lib
+    for kw, lean in ((dict(), 1), (dict(episode_stats=True), 0), (dict(substeps=3), 1)):
+        env = gym_copter_amd.CopterVecEnv(task="hover3d", num_envs=1000, state_dtype="float64", **kw)
+        v = _lib.LaunchView()
+        _lib.check(env._lib.cs_get_launch_view(env._ctx, C.byref(v)))
+        assert (v.struct_size, v.abi_version) == (C.sizeof(_lib.LaunchView), _lib.ABI_VERSION)
+        assert (v.task, v.state_mode, v.num_envs, v.grid, v.block) == (_lib.TASK_HOVER3D, _lib.STATE_F64, 1000, 16, 64)
+        assert v.lean == lean and v.one_call == (0 if "substeps" in kw else 1) and v.direct_rows == 1
+        assert v.consts and v.state and v.consts_size > 256 and v.state_size >= 32
+        env.serve_begin(2, timeout=1.0)                      # refused while a served session is open
+        assert env._lib.cs_get_launch_view(env._ctx, C.byref(v)) == _lib.ERR_ARG
+        env.serve_end(wait=False)
+        env.close()
+
+
 def test_numpy_returns_are_the_callers_to_keep_unless_copy_is_off():
     """gymnasium.vector.SyncVectorEnv(copy=True) semantics on the NumPy convenience path: by default what step()
     returned is not touched by later steps; copy=False hands out views of two alternating pinned buffers."""
