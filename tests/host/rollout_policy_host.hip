@@ -79,12 +79,15 @@ struct Descent {  // closed loop with state: sink at 1 m/s, damp the body rates,
 
 struct Linear {  // INTEGRATION.md's example: action = W obs + b, weights in device memory
   const float* W;  // [4][10] then b[4]
-  __device__ void load(uint32_t, bool) {}
+  float w[44];     // ... fetched ONCE per launch: the K steps then run on registers
+  __device__ void load(uint32_t, bool) {
+    for (int j = 0; j < 44; ++j) w[j] = W[j];
+  }
   __device__ void store(uint32_t, bool) {}
   __device__ void operator()(const float (&obs)[10], uint32_t, int, bool, float (&a)[4]) const {
     for (int m = 0; m < 4; ++m) {
-      float s = W[40 + m];
-      for (int j = 0; j < 10; ++j) s += W[m * 10 + j] * obs[j];
+      float s = w[40 + m];
+      for (int j = 0; j < 10; ++j) s += w[m * 10 + j] * obs[j];
       a[m] = s;
     }
   }
@@ -273,7 +276,7 @@ int main(int argc, char** argv) {
       HIP(hipMemcpy(W, hW, sizeof hW, hipMemcpyHostToDevice));
       OK(cs_reset(ctx, nullptr, nullptr, obs0, stream));
       OK(cs_reset(twin, nullptr, nullptr, obs0, stream));
-      OK((cs_rollout_custom<TASK, MODE>(ctx, K, Linear{W}, alog, a.obs, a.rew, a.term, a.trunc, stream)));
+      OK((cs_rollout_custom<TASK, MODE>(ctx, K, Linear{W, {}}, alog, a.obs, a.rew, a.term, a.trunc, stream)));
       for (int k = 0; k < K; ++k)
         OK(cs_step(twin, alog + (size_t)k * n * 4, b.obs + (size_t)k * n * 10, b.rew + (size_t)k * n, b.term + (size_t)k * n,
                    b.trunc + (size_t)k * n, stream));
@@ -348,7 +351,7 @@ int main(int argc, char** argv) {
       HIP(hipMemcpy(W, hW, sizeof hW, hipMemcpyHostToDevice));
     }
     if (time_us(stream, 30, [&] {
-          return cs_rollout_custom<TASK, MODE>(ctx, K, Linear{W}, nullptr, a.obs, a.rew, a.term, a.trunc, stream);
+          return cs_rollout_custom<TASK, MODE>(ctx, K, Linear{W, {}}, nullptr, a.obs, a.rew, a.term, a.trunc, stream);
         }, &us_linear)) return 4;
     std::printf("65536 envs, %d steps per launch, us per env step: cs_rollout_random %.3f  cs_step_many %.3f  "
                 "custom replay policy %.3f  custom closed-loop policy with state %.3f  custom linear policy (44 weights) %.3f\n",
