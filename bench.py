@@ -768,6 +768,7 @@ def main(argv=None):
             m = re.search(r"(\d+) envs, (\d+) steps per launch.*?cs_rollout_random ([\d.]+)\s+cs_step_many ([\d.]+)\s+"
                           r"custom replay policy ([\d.]+)\s+custom closed-loop policy with state ([\d.]+)\s+"
                           r"custom linear policy \(44 weights\) ([\d.]+)", p.stdout)
+            mm = re.search(r"custom MLP actor .*? ([\d.]+) us per env step", p.stdout)
             if p.returncode != 0 or m is None or "rollout_policy_host: OK" not in p.stdout:
                 extra["rollout_custom"] = {"error": "rc %d: %s" % (p.returncode, (p.stdout + p.stderr)[-300:])}
                 return
@@ -776,6 +777,7 @@ def main(argv=None):
                 "same_run": {"cs_rollout_random": float(m.group(3)), "cs_step_many": float(m.group(4))},
                 "replay_policy": float(m.group(5)), "closed_loop_law_with_state": float(m.group(6)),
                 "linear_policy_44_weights": float(m.group(7)),
+                **({"mlp_10_32_32_4_per_lane_policy_bound": float(mm.group(1))} if mm else {}),
                 "note": "tests/host/rollout_policy_host.hip: caller-side device functors instantiated into the K-step "
                         "kernel in the caller's translation unit; eager launches timed with HIP events; verified "
                         "bit-identical to cs_step_many / a twin stepped with cs_step in the same run"}

@@ -93,6 +93,43 @@ struct Linear {  // INTEGRATION.md's example: action = W obs + b, weights in dev
   }
 };
 
+constexpr int kMlpWeights = 320 + 32 + 1024 + 32 + 128 + 4;
+struct Mlp {  // a small actor network, 10 -> 32 -> 32 -> 4 with softsign units (what attic/drl's callers evaluate per
+              // step in another framework), evaluated by every lane for its own env; the weights are uniform over the
+              // batch and come through the scalar cache.  1 472 multiply-adds and 68 divisions per env and step in ONE
+              // lane: this policy, not the env, sets the pace (staging the weights in LDS instead: 16.5 us per step;
+              // the form that would be fast is an MFMA over the 64 envs of the wavefront -- the caller's to write)
+  const float* W;  // W1[32][10] b1[32] W2[32][32] b2[32] W3[4][32] b3[4]
+  __device__ void load(uint32_t, bool) {}
+  __device__ void store(uint32_t, bool) {}
+  static __device__ __host__ float unit(float x) { return x / (1.0f + (x < 0.f ? -x : x)); }
+  __device__ void operator()(const float (&obs)[10], uint32_t, int, bool, float (&a)[4]) const {
+    const float *W1 = W, *b1 = W1 + 320, *W2 = b1 + 32, *b2 = W2 + 1024, *W3 = b2 + 32, *b3 = W3 + 128;
+    float h1[32], h2[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      float s = b1[m];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) s += W1[m * 10 + j] * obs[j];
+      h1[m] = unit(s);
+    }
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+      float s = b2[m];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) s += W2[m * 32 + j] * h1[j];
+      h2[m] = unit(s);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float s = b3[m];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) s += W3[m * 32 + j] * h2[j];
+      a[m] = 0.0165f + 0.003f * unit(s);
+    }
+  }
+};
+
 struct Outs {
   float *obs, *rew;
   uint8_t *term, *trunc;
@@ -353,6 +390,57 @@ int main(int argc, char** argv) {
     if (time_us(stream, 30, [&] {
           return cs_rollout_custom<TASK, MODE>(ctx, K, Linear{W, {}}, nullptr, a.obs, a.rew, a.term, a.trunc, stream);
         }, &us_linear)) return 4;
+    double us_mlp = 0;
+    float* Wm;
+    {
+      std::vector<float> hW(kMlpWeights);
+      unsigned r = 12345u;
+      for (float& w : hW) {
+        r = r * 1664525u + 1013904223u;
+        w = ((float)(r >> 8) / 8388608.0f - 1.0f) * 0.3f;
+      }
+      HIP(hipMalloc((void**)&Wm, hW.size() * sizeof(float)));
+      HIP(hipMemcpy(Wm, hW.data(), hW.size() * sizeof(float), hipMemcpyHostToDevice));
+      // the network on the device == the network on the host (plain float operations, no contraction), 2 steps x 64 envs
+      float* al;
+      HIP(hipMalloc((void**)&al, (size_t)2 * n * 4 * sizeof(float)));
+      OK(cs_reset(ctx, nullptr, nullptr, obs0, stream));
+      OK((cs_rollout_custom<TASK, MODE>(ctx, 2, Mlp{Wm}, al, a.obs, nullptr, nullptr, nullptr, stream)));
+      HIP(hipStreamSynchronize(stream));
+      std::vector<float> ho(64 * 10), ha(64 * 4);
+      HIP(hipMemcpy(ho.data(), a.obs, ho.size() * sizeof(float), hipMemcpyDeviceToHost));        // obs after step 0
+      HIP(hipMemcpy(ha.data(), al + (size_t)n * 4, ha.size() * sizeof(float), hipMemcpyDeviceToHost));  // actions of step 1
+      const float *W1 = hW.data(), *b1 = W1 + 320, *W2 = b1 + 32, *b2 = W2 + 1024, *W3 = b2 + 32, *b3 = W3 + 128;
+      for (int i = 0; i < 64; ++i) {
+        float h1[32], h2[32];
+        for (int m = 0; m < 32; ++m) {
+          volatile float s_ = b1[m];
+          for (int j = 0; j < 10; ++j) { volatile float p_ = W1[m * 10 + j] * ho[i * 10 + j]; s_ = s_ + p_; }
+          h1[m] = Mlp::unit(s_);
+        }
+        for (int m = 0; m < 32; ++m) {
+          volatile float s_ = b2[m];
+          for (int j = 0; j < 32; ++j) { volatile float p_ = W2[m * 32 + j] * h1[j]; s_ = s_ + p_; }
+          h2[m] = Mlp::unit(s_);
+        }
+        for (int m = 0; m < 4; ++m) {
+          volatile float s_ = b3[m];
+          for (int j = 0; j < 32; ++j) { volatile float p_ = W3[m * 32 + j] * h2[j]; s_ = s_ + p_; }
+          volatile float u_ = 0.003f * Mlp::unit(s_);
+          volatile float want = 0.0165f + u_;
+          if (ha[i * 4 + m] != want) {
+            std::fprintf(stderr, "MLP mismatch env %d motor %d: device %.9g host %.9g\n", i, m, ha[i * 4 + m], (float)want);
+            return 3;
+          }
+        }
+      }
+      HIP(hipFree(al));
+    }
+    if (time_us(stream, 30, [&] {
+          return cs_rollout_custom<TASK, MODE>(ctx, K, Mlp{Wm}, nullptr, a.obs, a.rew, a.term, a.trunc, stream);
+        }, &us_mlp)) return 4;
+    std::printf("65536 envs, %d steps per launch: custom MLP actor 10-32-32-4 (1 540 weights through the scalar cache; policy-bound) %.3f us per env step\n",
+                K, us_mlp / K);
     std::printf("65536 envs, %d steps per launch, us per env step: cs_rollout_random %.3f  cs_step_many %.3f  "
                 "custom replay policy %.3f  custom closed-loop policy with state %.3f  custom linear policy (44 weights) %.3f\n",
                 K, us_lib / K, us_many / K, us_replay / K, us_descent / K, us_linear / K);
