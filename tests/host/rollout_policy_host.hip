@@ -7,7 +7,8 @@
 //      to launch through load() / store() and is cleared when the env starts a new episode) against a twin that
 //      is stepped with cs_step on the actions the policy recorded: the loop really is closed (what the policy
 //      saw at step k is what the twin returned at step k - 1), outputs and final state bit-identical;
-//   3. INTEGRATION.md's linear policy (weights in device memory), the same check;
+//   3. INTEGRATION.md's linear policy (weights in device memory), the same check; Hover3D in float64 words and
+//      Lander2D (2-value action rows) against cs_step_many;
 //   4. what it costs: us per env step at 65 536 envs for both, beside cs_rollout_random of the library.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I gym_copter_amd/csrc -o rollout_policy_host \
 //         tests/host/rollout_policy_host.hip -L gym_copter_amd -lcopterstep
@@ -127,6 +128,18 @@ struct Mlp {  // a small actor network, 10 -> 32 -> 32 -> 4 with softsign units 
       for (int j = 0; j < 32; ++j) s += W3[m * 32 + j] * h2[j];
       a[m] = 0.0165f + 0.003f * unit(s);
     }
+  }
+};
+
+template <int OBS, int ACT>
+struct ReplayN {  // the replay policy for any task shape
+  const float* actions;
+  uint32_t n;
+  __device__ void load(uint32_t, bool) {}
+  __device__ void store(uint32_t, bool) {}
+  __device__ void operator()(const float (&)[OBS], uint32_t env, int k, bool, float (&a)[ACT]) const {
+    const float* row = actions + ((size_t)k * n + (env < n ? env : 0u)) * ACT;
+    for (int j = 0; j < ACT; ++j) a[j] = row[j];
   }
 };
 
@@ -331,6 +344,61 @@ int main(int argc, char** argv) {
     HIP(hipFree(alog));
     OK(cs_destroy(twin));
     OK(cs_destroy(ctx));
+  }
+
+  // ---- other tasks / storage modes: Hover3D in float64 words (12-value rows), Lander2D (2-value action rows with the
+  //      motor fan-out of _get_motors) -- a constant / replay policy against cs_step_many on a twin ------------------
+  {
+    const int64_t n = 1000;
+    const int K = 16;
+    for (int which = 0; which < 2; ++which) {
+      const int task = which == 0 ? CS_TASK_HOVER3D : CS_TASK_LANDER2D;
+      const int od = which == 0 ? 12 : 6, ad = which == 0 ? 4 : 2;
+      cs_config cfg;
+      OK(cs_config_init(&cfg, task));
+      cfg.num_envs = n;
+      cfg.state_mode = which == 0 ? CS_STATE_F64 : CS_STATE_F32G;
+      cfg.autoreset = CS_AUTORESET_NEXT_STEP;
+      cfg.seed = 11;
+      cs_ctx *ctx = nullptr, *twin = nullptr;
+      OK(cs_create(&cfg, &ctx));
+      OK(cs_create(&cfg, &twin));
+      float *o0, *acts, *oa_, *ob_, *ra_, *rb_;
+      HIP(hipMalloc((void**)&o0, n * od * sizeof(float)));
+      HIP(hipMalloc((void**)&acts, (size_t)K * n * ad * sizeof(float)));
+      HIP(hipMalloc((void**)&oa_, (size_t)K * n * od * sizeof(float)));
+      HIP(hipMalloc((void**)&ob_, (size_t)K * n * od * sizeof(float)));
+      HIP(hipMalloc((void**)&ra_, (size_t)K * n * sizeof(float)));
+      HIP(hipMalloc((void**)&rb_, (size_t)K * n * sizeof(float)));
+      std::vector<float> ha((size_t)K * n * ad);
+      unsigned r = 99u + which;
+      for (float& v : ha) {
+        r = r * 1664525u + 1013904223u;
+        v = 0.0166f + ((float)(r >> 8) / 16777216.0f - 0.5f) * 0.004f;
+      }
+      HIP(hipMemcpy(acts, ha.data(), ha.size() * sizeof(float), hipMemcpyHostToDevice));
+      OK(cs_reset(ctx, nullptr, nullptr, o0, stream));
+      OK(cs_reset(twin, nullptr, nullptr, o0, stream));
+      if (which == 0)
+        OK((cs_rollout_custom<CS_TASK_HOVER3D, CS_STATE_F64>(ctx, K, ReplayN<12, 4>{acts, (uint32_t)n}, nullptr, oa_, ra_, nullptr,
+                                                              nullptr, stream)));
+      else
+        OK((cs_rollout_custom<CS_TASK_LANDER2D, CS_STATE_F32G>(ctx, K, ReplayN<6, 2>{acts, (uint32_t)n}, nullptr, oa_, ra_, nullptr,
+                                                                nullptr, stream)));
+      OK(cs_step_many(twin, K, acts, ob_, rb_, nullptr, nullptr, stream));
+      HIP(hipStreamSynchronize(stream));
+      std::vector<float> x((size_t)K * n * od), y((size_t)K * n * od), p((size_t)K * n), q((size_t)K * n);
+      HIP(hipMemcpy(x.data(), oa_, x.size() * sizeof(float), hipMemcpyDeviceToHost));
+      HIP(hipMemcpy(y.data(), ob_, y.size() * sizeof(float), hipMemcpyDeviceToHost));
+      HIP(hipMemcpy(p.data(), ra_, p.size() * sizeof(float), hipMemcpyDeviceToHost));
+      HIP(hipMemcpy(q.data(), rb_, q.size() * sizeof(float), hipMemcpyDeviceToHost));
+      CHECK(std::memcmp(x.data(), y.data(), x.size() * sizeof(float)) == 0);
+      CHECK(std::memcmp(p.data(), q.data(), p.size() * sizeof(float)) == 0);
+      if (same_state(ctx, twin, n, stream)) return 3;
+      for (float* d : {o0, acts, oa_, ob_, ra_, rb_}) HIP(hipFree(d));
+      OK(cs_destroy(twin));
+      OK(cs_destroy(ctx));
+    }
   }
 
   // ---- refusals ------------------------------------------------------------------------------------------
