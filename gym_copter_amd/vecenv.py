@@ -525,6 +525,23 @@ class CopterVecEnv:
             self.configure_pid()
         return self._rollout(self._lib.cs_rollout_pid, num_steps, return_actions)
 
+    def rollout_policy(self, policy, num_steps, params=None, return_actions=False):
+        """K closed-loop steps in ONE kernel launch under the CALLER'S OWN policy: `policy` is a HIP device
+        functor compiled by gym_copter_amd.compile_policy(env, source) and fused into the K-step kernel
+        (include/copterstep_rollout.h); `params` is the float32 device tensor its first member points at (weights,
+        per-env policy state, ...; None for a policy without parameters).  Returns like rollout_pid."""
+        torch = _torch()
+        if (policy.task, policy.state_mode) != (self.task, int(self.config.state_mode)):
+            raise ValueError("this policy was compiled for task %r / storage mode %d" % (policy.task, policy.state_mode))
+        if params is not None:
+            if not isinstance(params, torch.Tensor):
+                params = torch.as_tensor(np.asarray(params, dtype=np.float32))
+            params = params.to(device=self.device, dtype=torch.float32).contiguous()
+        self._policy_keep = (policy, params)                 # alive until the stream has consumed them
+        pp = C.c_void_p(params.data_ptr()) if params is not None else None
+        entry = lambda ctx, K, a, o, r, t, u, stream: policy._entry(ctx, K, pp, a, o, r, t, u, stream)
+        return self._rollout(entry, num_steps, return_actions)
+
     def _rollout(self, entry, num_steps, return_actions):
         self._check_open()
         torch = _torch()

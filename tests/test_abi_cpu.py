@@ -172,3 +172,29 @@ def test_step_call_module_passes_its_arguments_through_unchanged():
         _cs_call.step(addr, 1, "x", 3, 4, 5, 6, 7)
     with pytest.raises(OverflowError):
         _cs_call.step(addr, 1, -2, 3, 4, 5, 6, 7)
+
+
+def test_policy_source_compiles_into_a_loadable_object(tmp_path):
+    """gym_copter_amd.compile_policy without a GPU: hipcc cross-compiles the caller's functor with
+    include/copterstep_rollout.h (the K-step kernel instantiated in THAT translation unit) into a shared object that
+    exports the entry point and binds to libcopterstep.so; identical source is served from the cache; a broken source
+    fails loudly.  (Launching it is a -m gpu test.)"""
+    import shutil
+    import types
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("needs hipcc")
+    from gym_copter_amd import compile_policy
+    env = types.SimpleNamespace(task="hover1d", obs_dim=2, action_dim=1, config=types.SimpleNamespace(state_mode=_lib.STATE_F32G))
+    src = """
+    struct Policy {
+      const float* params;
+      __device__ void load(uint32_t, bool) {}
+      __device__ void store(uint32_t, bool) {}
+      __device__ void operator()(const float (&obs)[OBS], uint32_t, int, bool, float (&a)[ACT]) const { a[0] = params[0] - obs[1]; }
+    };"""
+    p = compile_policy(env, src, cache_dir=str(tmp_path))
+    assert p.task == "hover1d" and os.path.exists(p.path) and hasattr(p._handle, "cs_user_rollout")
+    stamp = os.path.getmtime(p.path)
+    assert compile_policy(env, src, cache_dir=str(tmp_path)).path == p.path and os.path.getmtime(p.path) == stamp
+    with pytest.raises(RuntimeError, match="hipcc failed"):
+        compile_policy(env, "struct Policy { int x };;; garbage(", cache_dir=str(tmp_path))

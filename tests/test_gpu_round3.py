@@ -807,3 +807,69 @@ def test_numpy_returns_are_the_callers_to_keep_unless_copy_is_off():
             assert np.shares_memory(kept[0][0], kept[2][0]) and not np.shares_memory(kept[0][0], kept[1][0])
         env.close()
         twin.close()
+
+
+_LINEAR_POLICY = """
+struct Policy {
+  const float* params;                 // [ACT][OBS] weights, then ACT biases, then one thrust trim per env
+  float w[ACT * OBS + ACT];
+  float trim;
+  __device__ void load(uint32_t env, bool valid) {
+    for (int j = 0; j < ACT * OBS + ACT; ++j) w[j] = params[j];
+    trim = valid ? params[ACT * OBS + ACT + env] : 0.f;
+  }
+  __device__ void store(uint32_t, bool) {}
+  __device__ void operator()(const float (&obs)[OBS], uint32_t, int, bool, float (&a)[ACT]) const {
+    for (int m = 0; m < ACT; ++m) {
+      float s = w[ACT * OBS + m];
+      for (int j = 0; j < OBS; ++j) s += w[m * OBS + j] * obs[j];
+      a[m] = s + trim;
+    }
+  }
+};
+"""
+
+
+@pytest.mark.parametrize("task,mode", [("lander3d", "float32"), ("hover2d", "float64")])
+def test_python_callers_policy_source_is_compiled_and_fused(task, mode, tmp_path):
+    """gym_copter_amd.compile_policy + env.rollout_policy: a policy given as HIP source (a linear law with shared
+    weights and one parameter per env) is compiled with hipcc at run time, fused into the K-step kernel and flown
+    closed-loop for K steps in one launch.  Checked against a twin env stepped with step() on the actions the policy
+    recorded (bit-identical outputs and state: the loop is closed and the fused kernel IS the step), and the law
+    itself against NumPy on the observations returned."""
+    import torch
+    import gym_copter_amd
+    n, K = 1500, 40
+    mk = lambda: gym_copter_amd.CopterVecEnv(task=task, num_envs=n, state_dtype=mode, seed=5, autoreset_mode="next_step",
+                                             max_steps=25)
+    env, twin = mk(), mk()
+    od, ad = env.obs_dim, env.action_dim
+    rng = np.random.default_rng(3)
+    W = (rng.standard_normal((ad, od)) * 1e-3).astype(np.float32)
+    b = np.full(ad, HOVER, np.float32)
+    trim = (rng.standard_normal(n) * 2e-4).astype(np.float32)
+    params = torch.from_numpy(np.concatenate([W.ravel(), b, trim])).to(env.device)
+    policy = gym_copter_amd.compile_policy(env, _LINEAR_POLICY, cache_dir=str(tmp_path))
+    again = gym_copter_amd.compile_policy(env, _LINEAR_POLICY, cache_dir=str(tmp_path))     # served from the cache
+    assert again.path == policy.path and os.path.exists(policy.path)
+    obs0, _ = env.reset()
+    obs0 = to_np(obs0).copy()
+    twin.reset()
+    obs, rew, term, trunc, acts = (to_np(v).copy() for v in env.rollout_policy(policy, K, params, return_actions=True))
+    seen = obs0
+    for k in range(K):
+        want = (seen.astype(np.float64) @ W.T.astype(np.float64) + b + trim[:, None]).astype(np.float32)
+        assert np.allclose(acts[k], want, rtol=1e-5, atol=1e-7), k
+        o, r, t, u, _ = twin.step(torch.from_numpy(acts[k]).to(twin.device))
+        assert np.array_equal(to_np(o), obs[k]) and np.array_equal(to_np(r), rew[k]), k
+        assert np.array_equal(to_np(t), term[k]) and np.array_equal(to_np(u), trunc[k]), k
+        seen = obs[k]
+    assert term.any() or trunc.any()                     # episodes ended and restarted inside the launch
+    _assert_same_state(env, twin)
+    other = gym_copter_amd.CopterVecEnv(task="lander1d", num_envs=64)
+    with pytest.raises(ValueError):
+        other.rollout_policy(policy, 2, params)
+    with pytest.raises(RuntimeError, match="hipcc failed"):
+        gym_copter_amd.compile_policy(env, "struct Policy { this is not HIP };", cache_dir=str(tmp_path))
+    for e in (env, twin, other):
+        e.close()
