@@ -683,6 +683,39 @@ def main(argv=None):
         k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 136.0 / k,
                    "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
                    "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)")
+    if a.pid > 0:
+        # the CALLER'S OWN policy fused into the K-step kernel, the Python route: a linear law given as HIP source,
+        # compiled with hipcc here and now (gym_copter_amd.compile_policy), K closed-loop steps per launch
+        try:
+            from gym_copter_amd import compile_policy
+            src = """
+struct Policy {
+  const float* params;
+  float w[ACT * OBS + ACT];
+  __device__ void load(uint32_t, bool) { for (int j = 0; j < ACT * OBS + ACT; ++j) w[j] = params[j]; }
+  __device__ void store(uint32_t, bool) {}
+  __device__ void operator()(const float (&obs)[OBS], uint32_t, int, bool, float (&a)[ACT]) const {
+    for (int m = 0; m < ACT; ++m) { float s = w[ACT * OBS + m]; for (int j = 0; j < OBS; ++j) s += w[m * OBS + j] * obs[j]; a[m] = s; }
+  }
+};"""
+            t0 = time.perf_counter()
+            pol = compile_policy(env, src)
+            compile_s = time.perf_counter() - t0
+            ad = env.action_dim
+            W = torch.zeros(ad * od + ad, device=device)
+            W[ad * od:] = HOVER * 0.98                      # a slow descent; the sink rate and body rates fed back a little
+            for mtr in range(ad):
+                W[mtr * od + min(5, od - 1)] = 0.002
+            k = a.pid
+            env.reset()
+            k_step_leg("rollout_policy_linear", k, lambda: env.rollout_policy(pol, k, W), 4 * od + 4 + 2 + 136.0 / k,
+                       "env.rollout_policy: the caller's own policy (a linear law, %d weights, given as HIP source and "
+                       "compiled by hipcc in %.1f s%s) fused into the K-step kernel (include/copterstep_rollout.h; "
+                       "tests/test_gpu_round3.py::test_python_callers_policy_source_is_compiled_and_fused)"
+                       % (ad * od + ad, compile_s, "" if compile_s > 0.5 else ", cached"))
+        except Exception as e:              # an extra never costs the headline
+            extra["rollout_policy_linear"] = {"error": repr(e)}
+
     def served_legs():
         # served stepping (cs_serve_*): ONE persistent env kernel per K-step session, the env state in
         # registers throughout; action rows in and result rows out as tagged 16-byte granules through device
@@ -908,7 +941,7 @@ def main(argv=None):
                              for e in extra.get("sweep", []) if "frac" in e},
               "config5": [pick(b, "bound", "frac") for b in extra.get("config5", {}).get("bounds", [])],
               "config5_launch_us": extra.get("config5", {}).get("launch_us"),
-              "k_step_us": {k: round(extra[k]["us_per_step"], 3) for k in ("step_many", "rollout_pid", "rollout_random")
+              "k_step_us": {k: round(extra[k]["us_per_step"], 3) for k in ("step_many", "rollout_pid", "rollout_random", "rollout_policy_linear")
                             if "us_per_step" in extra.get(k, {})},
               "served_us": {k: round(extra[k]["us_per_step"], 3)
                             for k in ("served_closed_loop", "served_closed_loop_persistent_policy",
