@@ -683,7 +683,7 @@ def main(argv=None):
         k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 136.0 / k,
                    "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
                    "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)")
-    if a.pid > 0:
+    if a.pid > 0 and world == 1:     # (N = 1 only: a compile that failed on ONE rank would leave the others at a barrier)
         # the CALLER'S OWN policy fused into the K-step kernel, the Python route: a linear law given as HIP source,
         # compiled with hipcc here and now (gym_copter_amd.compile_policy), K closed-loop steps per launch
         try:
