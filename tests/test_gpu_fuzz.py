@@ -2,8 +2,9 @@
 whole configuration at random -- task x storage mode x auto-reset mode x substeps x frame rate x time-limit handling
 x episode statistics x tick counter x batch shape x shard offset x task constants -- and flies it for 90 steps
 against the CPU oracle (oracle/refvec.py, itself pinned bit-for-bit to the reference's golden traces), changing the
-STEPPING FORM every few steps: one launch per step (cs_step), K steps per launch (cs_step_many) and a served session
-(cs_serve_*).  Every step's observation, reward and flags, and the stored state, status, counters (and ticks) after
+STEPPING FORM every few steps: one launch per step (cs_step), K steps per launch (cs_step_many), a served session
+(cs_serve_*) and, in every fifth case (all six tasks), a caller-side replay policy fused into the K-step kernel (compile_policy +
+rollout_policy: the kernel of include/copterstep_rollout.h instantiated for that case's task and storage mode).  Every step's observation, reward and flags, and the stored state, status, counters (and ticks) after
 every stretch are compared; discrete outputs exactly, the state to the same-mode tolerance (MODE_TOL), the float32
 rows to one ulp.
 
@@ -70,8 +71,33 @@ def draw_actions(rng, law, n, adim):
     return a.astype(np.float32)
 
 
+# the caller's OWN policy fused into the K-step kernel (gym_copter_amd.compile_policy): a replay policy -- the K x N
+# action rows behind a one-float header holding N -- compiled once per (task, storage mode) of the cases that use it
+_REPLAY_POLICY = """
+struct Policy {
+  const float* params;
+  __device__ void load(uint32_t, bool) {}
+  __device__ void store(uint32_t, bool) {}
+  __device__ void operator()(const float (&)[OBS], uint32_t env, int k, bool, float (&a)[ACT]) const {
+    const uint32_t n = (uint32_t)params[0];
+    const float* row = params + 1 + ((size_t)k * n + (env < n ? env : 0u)) * ACT;
+    for (int j = 0; j < ACT; ++j) a[j] = row[j];
+  }
+};
+"""
+_policies = {}
+
+
+def replay_policy(env, cache_dir):
+    import gym_copter_amd
+    key = (env.task, int(env.config.state_mode))
+    if key not in _policies:
+        _policies[key] = gym_copter_amd.compile_policy(env, _REPLAY_POLICY, cache_dir=cache_dir)
+    return _policies[key]
+
+
 @pytest.mark.parametrize("seed", range(64))
-def test_random_configuration_and_stepping_forms_vs_oracle(seed):
+def test_random_configuration_and_stepping_forms_vs_oracle(seed, tmp_path_factory):
     import torch
     cfg, kw, law, rng = draw_case(seed)
     track = bool(rng.integers(0, 2))
@@ -87,7 +113,8 @@ def test_random_configuration_and_stepping_forms_vs_oracle(seed):
     served_ok = n <= env.serve_max_envs()
     t = 0
     while t < 90:
-        form = str(rng.choice(["step", "many", "served"] if served_ok else ["step", "many"]))
+        forms = ["step", "many"] + (["served"] if served_ok else []) + (["policy"] if seed % 5 == 0 else [])
+        form = str(rng.choice(forms))
         k = int(rng.integers(1, 9))
         acts = np.stack([draw_actions(rng, law, n, adim) for _ in range(k)])
         if form == "step":
@@ -98,6 +125,12 @@ def test_random_configuration_and_stepping_forms_vs_oracle(seed):
         elif form == "many":
             o, r, te, tr = env.step_many(torch.from_numpy(acts).to(env.device))
             o, r, te, tr = (to_np(v) for v in (o, r, te, tr))
+            outs = [(o[j], r[j], te[j], tr[j]) for j in range(k)]
+        elif form == "policy":
+            pol = replay_policy(env, str(tmp_path_factory.getbasetemp() / "policies"))
+            params = torch.from_numpy(np.concatenate([[np.float32(n)], acts.ravel()]).astype(np.float32)).to(env.device)
+            o, r, te, tr, rec = (to_np(v) for v in env.rollout_policy(pol, k, params, return_actions=True))
+            assert np.array_equal(rec, acts), ctx
             outs = [(o[j], r[j], te[j], tr[j]) for j in range(k)]
         else:
             env.serve_begin(k, ring=2, timeout=5.0)
