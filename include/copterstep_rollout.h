@@ -25,7 +25,9 @@
  *     __device__ void store(uint32_t env, bool valid);
  *     // obs    what the previous step returned (k = 0: the stored state), float32, the task's observation
  *     // k      step of this launch;  fresh: the env started a new episode in the previous step (obs is then
- *     //        the reset observation, as with auto-reset in cs_step) -- forget per-episode state
+ *     //        the reset observation, as with auto-reset in cs_step) -- forget per-episode state.  With
+ *     //        CS_AUTORESET_SAME_STEP that is the step that ended the episode; with CS_AUTORESET_NEXT_STEP the
+ *     //        step after it (the one whose action the env ignores, as Gymnasium's NEXT_STEP mode does)
  *     // action the task's action row (4 / 2 / 1 values), unclipped (the env clips: task.py:91)
  *     __device__ void operator()(const float (&obs)[OBS], uint32_t env, int k, bool fresh, float (&action)[ACT]);
  *   };
