@@ -699,7 +699,8 @@ struct Policy {
   }
 };"""
             t0 = time.perf_counter()
-            pol = compile_policy(env, src)
+            import tempfile
+            pol = compile_policy(env, src, cache_dir=os.path.join(tempfile.gettempdir(), "copterstep_bench_policies_%d" % os.getuid()))
             compile_s = time.perf_counter() - t0
             ad = env.action_dim
             W = torch.zeros(ad * od + ad, device=device)
