@@ -6,7 +6,7 @@ and the Gymnasium-style vector-env host class.  See DESIGN.md and INTEGRATION.md
 from ._lib import CopterStepError  # noqa: F401
 from .spaces import Box  # noqa: F401
 from .vecenv import CopterVecEnv  # noqa: F401
-from .policy_jit import compile_policy  # noqa: F401
+from .policy_jit import compile_policy, load_policy  # noqa: F401
 
 __version__ = "0.1.0"
 

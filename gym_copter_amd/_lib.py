@@ -95,13 +95,14 @@ class LaunchView(C.Structure):
                 ("reserved_", C.c_uint32), ("num_envs", C.c_int64), ("consts", C.c_void_p), ("state", C.c_void_p)]
 
 
-ERR_ARG, ERR_TIMEOUT = -1, -6
+ERR_ARG, ERR_ABI, ERR_TIMEOUT = -1, -5, -6
 PID_LANDER, PID_HOVER = 0, 1
 PID_ROWS = 24          # 6 controllers x {errorI, lastError, deltaError1, deltaError2}
 
 SYMBOLS = {
     "cs_version": (C.c_int, []),
     "cs_last_error": (C.c_char_p, []),
+    "cs_set_last_error": (None, [C.c_char_p]),
     "cs_config_init": (C.c_int, [C.POINTER(Config), C.c_int]),
     "cs_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "cs_destroy": (C.c_int, [_P]),

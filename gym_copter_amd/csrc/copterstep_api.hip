@@ -282,6 +282,7 @@ extern "C" {
 int cs_version(void) { return CS_ABI_VERSION; }
 
 const char* cs_last_error(void) { return g_err.c_str(); }
+void cs_set_last_error(const char* message) { g_err = message ? message : ""; }
 
 int cs_config_init(cs_config* cfg, int task) {
   if (cfg == nullptr) return fail(CS_ERR_ARG, "cs_config_init: null cfg");
@@ -584,6 +585,9 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
 int cs_get_launch_view(cs_ctx* ctx, cs_launch_view* view) {
   if (int rc_ = check_idle(ctx, "cs_get_launch_view")) return rc_;
   if (view == nullptr) return fail(CS_ERR_ARG, "cs_get_launch_view: null view");
+  if (view->struct_size != sizeof *view)  // (an in-parameter: a caller built against another layout is not written to)
+    return fail(CS_ERR_ABI, "cs_get_launch_view: view->struct_size " + std::to_string(view->struct_size) +
+                                " != sizeof(cs_launch_view) " + std::to_string(sizeof *view));
   const cs::DevConst& c = constants(ctx);
   const uint32_t direct_max =
       ctx->tune.direct_rows_max_envs ? ctx->tune.direct_rows_max_envs : cs::default_tuning().direct_rows_max_envs;

@@ -187,6 +187,10 @@ typedef struct cs_step_io {
 
 int cs_version(void);
 const char* cs_last_error(void);
+/* For code that refuses a call on the library's behalf before reaching it (include/copterstep_rollout.h: a
+ * caller-side template cannot reach the library's thread-local message otherwise): sets the calling thread's
+ * cs_last_error() text.  NULL clears it. */
+void cs_set_last_error(const char* message);
 
 int cs_config_init(cs_config* cfg, int task);
 int cs_create(const cs_config* cfg, cs_ctx** out);
@@ -293,7 +297,7 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
  * pointers are into the context: valid until its configuration changes (cs_seed, cs_set_altitude,
  * cs_set_vehicle_params, cs_set_tuning) or it is destroyed.  Refused while a served session is open. */
 typedef struct cs_launch_view {
-  uint32_t struct_size;   /* in: sizeof(cs_launch_view) */
+  uint32_t struct_size;   /* in: sizeof(cs_launch_view), set by the caller; anything else -> CS_ERR_ABI, nothing written */
   uint32_t abi_version;   /* out: CS_ABI_VERSION of the library */
   uint32_t consts_size;   /* sizeof(cs::DevConst) / sizeof(cs::DevState) of the library's build */
   uint32_t state_size;

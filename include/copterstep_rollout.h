@@ -177,10 +177,21 @@ int cs_rollout_custom(cs_ctx* ctx, int num_steps, POLICY policy, float* actions_
                       uint8_t* terminated_dev, uint8_t* truncated_dev, hipStream_t stream) {
   static_assert(std::is_trivially_copyable<POLICY>::value, "the policy is passed to the kernel by value");
   cs_launch_view v;
+  v.struct_size = (uint32_t)sizeof v;
   if (int rc = cs_get_launch_view(ctx, &v)) return rc;
-  if (v.consts_size != sizeof(cs::DevConst) || v.state_size != sizeof(cs::DevState) || v.block != (uint32_t)cs::kBlock)
-    return CS_ERR_ABI;  /* these device headers are not the ones libcopterstep.so was built from */
-  if (v.task != TASK || v.state_mode != MODE || num_steps < 1) return CS_ERR_ARG;
+  if (v.consts_size != sizeof(cs::DevConst) || v.state_size != sizeof(cs::DevState) || v.block != (uint32_t)cs::kBlock) {
+    cs_set_last_error("cs_rollout_custom: these device headers are not the ones libcopterstep.so was built from "
+                      "(sizeof DevConst / DevState or the workgroup size differ): rebuild the caller");
+    return CS_ERR_ABI;
+  }
+  if (v.task != TASK || v.state_mode != MODE) {
+    cs_set_last_error("cs_rollout_custom: instantiated for another task / storage mode than the context's");
+    return CS_ERR_ARG;
+  }
+  if (num_steps < 1) {
+    cs_set_last_error("cs_rollout_custom: num_steps < 1");
+    return CS_ERR_ARG;
+  }
   const cs::DevConst& c = *static_cast<const cs::DevConst*>(v.consts);
   const cs::DevState& s = *static_cast<const cs::DevState*>(v.state);
   const dim3 grid(v.grid), block(v.block);
@@ -197,7 +208,12 @@ int cs_rollout_custom(cs_ctx* ctx, int num_steps, POLICY policy, float* actions_
   else
     CS_ROLLOUT_LAUNCH(false, false, false);
 #undef CS_ROLLOUT_LAUNCH
-  return hipGetLastError() == hipSuccess ? CS_OK : CS_ERR_HIP;
+  const hipError_t launched = hipGetLastError();
+  if (launched != hipSuccess) {
+    cs_set_last_error(hipGetErrorString(launched));
+    return CS_ERR_HIP;
+  }
+  return CS_OK;
 }
 
 #endif /* __HIPCC__ */

@@ -222,6 +222,9 @@ int main(int argc, char** argv) {
     OK(cs_create(&cfg, &ctx));
     OK(cs_create(&cfg, &twin));
     cs_launch_view view;
+    view.struct_size = (uint32_t)sizeof view - 4;                              // another build's layout: refused
+    CHECK(cs_get_launch_view(ctx, &view) == CS_ERR_ABI);
+    view.struct_size = (uint32_t)sizeof view;
     OK(cs_get_launch_view(ctx, &view));
     CHECK(view.lean == !full && view.one_call == 1 && view.grid == (uint32_t)((n + 63) / 64) && view.block == 64);
     float *obs0, *acts, *alog;

@@ -198,3 +198,53 @@ def test_policy_source_compiles_into_a_loadable_object(tmp_path):
     assert compile_policy(env, src, cache_dir=str(tmp_path)).path == p.path and os.path.getmtime(p.path) == stamp
     with pytest.raises(RuntimeError, match="hipcc failed"):
         compile_policy(env, "struct Policy { int x };;; garbage(", cache_dir=str(tmp_path))
+
+    # a deployable form: the built object + its stamp, loaded back without a compiler
+    from gym_copter_amd import load_policy, policy_jit
+    ship = str(tmp_path / "shipped_policy.so")
+    assert compile_policy(env, src, cache_dir=str(tmp_path), save=ship).path == p.path
+    q = load_policy(ship, env)
+    assert (q.task, q.state_mode, q.stamp) == (p.task, p.state_mode, p.stamp) and hasattr(q._handle, "cs_user_rollout")
+    other = types.SimpleNamespace(task="hover2d", obs_dim=6, action_dim=2, config=env.config)
+    with pytest.raises(ValueError, match="compiled for task"):
+        load_policy(ship, other)
+    import json
+    meta = json.load(open(ship + ".json"))
+    json.dump(dict(meta, stamp="0" * 64), open(ship + ".json", "w"))      # built against other headers / library
+    with pytest.raises(ValueError, match="rebuild it"):
+        load_policy(ship)
+    json.dump(meta, open(ship + ".json", "w"))
+    with open(ship, "ab") as f:                                           # the object is not the one that was saved
+        f.write(b"x")
+    with pytest.raises(ValueError, match="hash"):
+        load_policy(ship)
+    # the stamp covers the library the object binds to, not only the headers
+    assert policy_jit._file_sha256(_lib.LIB_PATH) and len(p.stamp) == 64
+
+
+def test_policy_cache_directory_must_be_private(tmp_path, monkeypatch):
+    """Cached policy objects are dlopen()ed: the cache directory has to belong to the caller and be writable by
+    nobody else.  A world-writable directory, a symlink and a foreign-owned directory are refused
+    when the caller names them, and skipped -- down to a fresh mkdtemp -- when they are only defaults."""
+    from gym_copter_amd import policy_jit
+    good = tmp_path / "good"
+    assert policy_jit._private_cache_dir(str(good)) == str(good)
+    assert (os.stat(good).st_mode & 0o777) == 0o700
+    open_dir = tmp_path / "open"
+    open_dir.mkdir()
+    os.chmod(open_dir, 0o777)
+    with pytest.raises(PermissionError):
+        policy_jit._private_cache_dir(str(open_dir))
+    link = tmp_path / "link"
+    link.symlink_to(good)
+    with pytest.raises(PermissionError):
+        policy_jit._private_cache_dir(str(link))
+    monkeypatch.setattr(os, "getuid", lambda: 12345678)       # every existing directory is now somebody else's
+    assert not policy_jit._dir_is_private(str(good))
+    monkeypatch.setenv("COPTERSTEP_POLICY_CACHE", str(open_dir))
+    monkeypatch.setenv("HOME", str(open_dir))
+    import tempfile
+    monkeypatch.setattr(tempfile, "gettempdir", lambda: str(open_dir))
+    made = []
+    monkeypatch.setattr(tempfile, "mkdtemp", lambda prefix="": made.append(prefix) or str(tmp_path / "fresh"))
+    assert policy_jit._private_cache_dir(None) == str(tmp_path / "fresh") and made

@@ -771,6 +771,11 @@ def test_launch_view_describes_the_context():
     for kw, lean in ((dict(), 1), (dict(episode_stats=True), 0), (dict(substeps=3), 1)):
         env = gym_copter_amd.CopterVecEnv(task="hover3d", num_envs=1000, state_dtype="float64", **kw)
         v = _lib.LaunchView()
+        # struct_size is an in-parameter: a caller built against another layout is refused and not written to
+        v.struct_size, v.grid = C.sizeof(_lib.LaunchView) - 8, 777
+        assert env._lib.cs_get_launch_view(env._ctx, C.byref(v)) == _lib.ERR_ABI and v.grid == 777
+        assert "struct_size" in env._lib.cs_last_error().decode()
+        v.struct_size = C.sizeof(_lib.LaunchView)
         _lib.check(env._lib.cs_get_launch_view(env._ctx, C.byref(v)))
         assert (v.struct_size, v.abi_version) == (C.sizeof(_lib.LaunchView), _lib.ABI_VERSION)
         assert (v.task, v.state_mode, v.num_envs, v.grid, v.block) == (_lib.TASK_HOVER3D, _lib.STATE_F64, 1000, 16, 64)
@@ -778,6 +783,8 @@ def test_launch_view_describes_the_context():
         assert v.consts and v.state and v.consts_size > 256 and v.state_size >= 32
         env.serve_begin(2, timeout=1.0)                      # refused while a served session is open
         assert env._lib.cs_get_launch_view(env._ctx, C.byref(v)) == _lib.ERR_ARG
+        env._lib.cs_set_last_error(b"said by a caller-side header")     # (what copterstep_rollout.h's refusals use)
+        assert env._lib.cs_last_error() == b"said by a caller-side header"
         env.serve_end(wait=False)
         env.close()
 
