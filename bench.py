@@ -27,7 +27,8 @@ Rank 0 prints ONE JSON line (see the task contract) with, besides the contract k
                  launch duration measured with HIP events on the launch stream, vs 8 TB/s
   sweep        : the same kernel at the other single-GPU sizes / tasks (Lander3D and Hover3D at
                  262 144 = BASELINE configs[2], 1 M and 4 M envs), each with launch_us and frac
-  config5      : BASELINE configs[4] (dt = 1e-3, 10 substeps) with BOTH bounds, HBM and f64 vector ALU
+  config5      : BASELINE configs[4] (dt = 1e-3, 10 substeps) with its bounds: HBM, float64 vector ALU (flops
+                 executed, by PMC) and float64 instruction issue (vector instructions executed x 4 cycles)
   cpu_baseline : the scalar NumPy port of the reference (oracle/refcpu.py), timed here on
                  the host, 1 core, bounded sample (a reported baseline, not a target); beside
                  it the other action law, all host cores (one process and env each) and the
@@ -54,13 +55,15 @@ HBM_PEAK_GBPS = 8000.0                              # MI355X_MICROARCH.md: HBM3E
 # MI355X_MICROARCH.md: peak FP32 vector 157.3 TFLOP/s; float64 vector FMA issues at half that rate
 F64_VALU_PEAK_TFLOPS = 78.6
 HOVER = 0.016560178185018043                        # motor value with thrust == weight
-# float64 operations of one env step as the kernel evaluates it: per
-# Dynamics.setMotors call 3 sin/cos pairs (2 x 6 fused multiply-adds each + reduction), the body-Z
-# rotation, the state derivative and 12 Euler updates; once per step the motor model, the stored-word
-# rounding and the reward.  An FMA counts as 2.
-FLOPS_PER_SUBSTEP = 3 * 34 + 18 + 14 + 24
-FLOPS_PER_STEP_FIXED = 32 + 40 + 36
-
+# Engine clock and SIMD count for the instruction-issue bound of the float64-heavy kernels: a SIMD issues one vector
+# instruction of a wavefront every 4 cycles (64 lanes over 16 ALU lanes; MI355X_MICROARCH.md), so a launch whose
+# SIMDs each hold W wavefronts of V executed vector instructions cannot take less than W * V * 4 cycles.
+# The counts V (and the float64 flops of config 5) are NOT a model: they are rocprofv3 PMC figures of the very
+# instantiations, read from profiles/pmc_counts.json (scripts/profile_gpu.sh -> scripts/collect_profiles.py), and
+# withheld when the tree's kernel sources hash differently from the ones they were measured on.
+PEAK_ENGINE_CLOCK_HZ = 2.4e9
+SIMDS_PER_CU, LANES_PER_WAVE, ISSUE_CYCLES = 4, 64, 4
+INFINITY_CACHE_BYTES = 256 << 20                    # MI355X_MICROARCH.md: 256 MiB memory-side cache
 
 def parse(argv=None):
     p = argparse.ArgumentParser()
@@ -92,6 +95,11 @@ def parse(argv=None):
                    help="also time cs_rollout_pid / cs_rollout_random with this many steps per launch (0 = skip)")
     p.add_argument("--served", type=int, default=500,
                    help="also time served stepping (cs_serve_*) with this many steps per session (0 = skip)")
+    p.add_argument("--served-all", action="store_true",
+                   help="also time the plain-rows compatibility form of served stepping (cs_serve_submit + cs_serve_collect "
+                        "per step: the slowest form, ~4 s of run time)")
+    p.add_argument("--no-span", action="store_true",
+                   help="skip the kernel-only span figure (a child process on the span build, before this one touches the GPU)")
     p.add_argument("--served-graph", type=int, default=-1, help="diagnostic: feeders of the served legs from a hipGraph (1) "
                    "or eagerly (0); default: as the headline")
     p.add_argument("--many", type=int, default=100,
@@ -482,6 +490,58 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def load_stamped(name):
+    """profiles/<name> (a JSON written by scripts/collect_profiles.py) if it was measured on THIS tree's kernel
+    sources, else (None, why)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, "profiles/%s is absent" % name
+    try:
+        tj = json.load(open(path))
+    except Exception as e:
+        return None, "profiles/%s unreadable: %r" % (name, e)
+    here = kernel_source_hash()
+    if tj.get("kernel_source_sha16") != here:
+        return None, ("profiles/%s was measured on kernel sources %s, this tree has %s: withheld"
+                      % (name, tj.get("kernel_source_sha16"), here))
+    return tj, ("profiles/%s: rocprofv3 PMC of these kernels at commit %s (kernel sources %s = this tree's) -- NOT "
+                "measured by this run" % (name, tj.get("commit"), here))
+
+
+def issue_bound(valu_per_wave_step, n_envs, s_per_step, cus, clock_hz):
+    """The instruction-issue floor of one step: every SIMD holds ceil(waves / SIMDs) wavefronts, each of which executes
+    `valu_per_wave_step` vector instructions at 4 cycles apiece -> (floor in us, floor / measured = frac)."""
+    simds = cus * SIMDS_PER_CU
+    waves = (n_envs + LANES_PER_WAVE - 1) // LANES_PER_WAVE
+    per_simd = (waves + simds - 1) // simds
+    floor_s = per_simd * valu_per_wave_step * ISSUE_CYCLES / clock_hz
+    return {"bound": "valu_f64_issue", "valu_per_wavefront_step": valu_per_wave_step, "wavefronts_per_simd": per_simd,
+            "floor_us": floor_s * 1e6, "achieved_us": s_per_step * 1e6, "frac": floor_s / s_per_step,
+            "ceiling_env_steps_per_s": n_envs / floor_s, "simds": simds, "clock_GHz": clock_hz / 1e9,
+            "arithmetic": "wavefronts_per_simd x valu_per_wavefront_step x 4 cycles / clock = floor; frac = floor / achieved"}
+
+
+def kernel_span_child(task, n, law, substeps, timeout=180):
+    """The step kernel's OWN duration per launch (first wavefront start -> last wavefront end on the chip-wide 100 MHz
+    clock), from the span build of the library (make span: two clock reads and one 16-byte store per wavefront, phases
+    not serialised, no profiler) in a CHILD process -- started before this process initialises the GPU and finished
+    before it does.  -> the JSON tools/kernel_span.py prints, or {"error": ...}."""
+    lib = os.path.join(ROOT, "gym_copter_amd", "csrc", "build", "libcopterstep_span.so")
+    tool = os.path.join(ROOT, "tools", "kernel_span.py")
+    if not os.path.exists(lib):
+        return {"error": "span build absent (make -C gym_copter_amd/csrc span)"}
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"error": "skipped under a profiler"}
+    try:
+        p = subprocess.run([sys.executable, tool, task, str(n), law, str(substeps)], capture_output=True, text=True,
+                           timeout=timeout)
+        if p.returncode != 0:
+            return {"error": "rc %d: %s" % (p.returncode, p.stderr[-300:])}
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def graph_chunk_for(steps, graph_chunk):
     """Launches per captured hipGraph: whole passes of the K steps, as many as fit `graph_chunk`
     (a 20-step graph pays its ~4 us replay boundary every 20 launches: 0.2 us per step)."""
@@ -539,6 +599,11 @@ def main(argv=None):
         # before torch.cuda / RCCL are initialised in this process (the baseline forks workers)
         cpu = cpu_baseline(a.task, a.actions, a.cpu_seconds)
 
+    span = None
+    if rank == 0 and world == 1 and not a.no_span and not a.no_graph and a.state == "float32" and not a.produce_actions:
+        # the kernel-only figure of the headline: a child on the span build, before this process touches the GPU
+        span = kernel_span_child(a.task, a.envs, a.actions, a.substeps)
+
     import torch
     dist = None
     launched = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # by torch.distributed.run
@@ -578,6 +643,11 @@ def main(argv=None):
     import gym_copter_amd as gca
     n = a.envs
     min_region_s = a.min_region_ms * 1e-3
+    props = torch.cuda.get_device_properties(device)
+    cus = int(getattr(props, "multi_processor_count", 256) or 256)
+    clock_hz = float(getattr(props, "clock_rate", 0) or 0) * 1e3 or PEAK_ENGINE_CLOCK_HZ     # (kHz -> Hz)
+    pmc, pmc_src = load_stamped("pmc_counts.json")
+    pmc = pmc or {}
     env = gca.CopterVecEnv(task=a.task, num_envs=n, device=local, seed=1234,
                            autoreset_mode="next_step", state_dtype=a.state,
                            substeps=a.substeps, env_id_base=rank * n)
@@ -595,7 +665,111 @@ def main(argv=None):
     value = total_envs / m["s_per_step"]
 
     extra = {}
-    if a.gather and dist is not None:
+
+    def assemble():
+        """The ONE JSON line from what has been measured so far (also called by the deadline of the default N > 1
+        gather leg)."""
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                here = kernel_source_hash()
+                if tj.get("kernel_source_sha16") != here:
+                    tsrc = ("profiles/traffic.json was measured on kernel sources %s, this tree has %s: traffic withheld"
+                            % (tj.get("kernel_source_sha16"), here))
+                else:
+                    traffic = tj.get("%s_%d" % (a.task, n))
+                    if traffic is not None:
+                        tsrc = ("profiles/traffic.json: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes) of this "
+                                "kernel and batch at commit %s (kernel sources %s = this tree's) -- NOT measured by this run"
+                                % (tj.get("commit"), here))
+            except Exception:
+                traffic = None
+
+        out = {
+            "metric": "env-steps/sec Lander3D at 65 536 envs" if (a.task, n) == ("lander3d", 65536)
+                      else "env-steps/sec %s at %d envs" % (a.task, n),
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": m["s_per_step"] * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repeats": m["repeats"], "regions": m["regions"], "timed_steps_per_region": m["steps"] * m["repeats"],
+            # `steps` echoes --steps; what was actually timed (the driver's consistency arithmetic should use these):
+            "timed_steps_total": m["steps"] * m["repeats"] * m["regions"],
+            "timed_region_s": m["wall_s"],
+            "timing": "median of %d regions of %d x %d steps (hipGraphs of %d launches), each bracketed by barrier + "
+                      "synchronize, MAX over ranks" % (m["regions"], m["repeats"], m["steps"], chunk),
+            "single_pass": m["single_pass"],
+            "config": {"workload": "%s, %d envs/GPU, %s actions, auto-reset NEXT_STEP, %s state words, "
+                                   "dt=%g x %d substeps, %s" % (a.task, n, a.actions, a.state,
+                                                              1.0 / (100 * a.substeps), a.substeps,
+                                                              "hipGraph replay of %d-step chunks" % chunk
+                                                              if use_graph else "eager launches"),
+                       "envs_per_gpu": n, "total_envs": total_envs, "task": a.task,
+                       "actions": a.actions, "state_words": a.state, "substeps": a.substeps,
+                       "action_ring": a.ring, "next_action_prefetch": bool(a.prefetch),
+                       "actions_produced_by_a_preceding_kernel": bool(a.produce_actions),
+                       "parallelism": "env-shard x%d" % world},
+            "roofline": roofline_block(a.task, n, m["launch_s"], a.state, traffic, tsrc),
+        }
+        rf = out["roofline"]
+        rf["resident"] = "infinity_cache" if n <= 1048576 else "hbm"
+        # the kernel alone, without the dependent-launch gap that `frac` contains: the span build in a child process
+        if span is not None and "kernel_span_ns" in span:
+            ks = span["kernel_span_ns"]["median"] * 1e-9
+            rf["kernel_span_us"] = ks * 1e6
+            rf["kernel_frac"] = ALGO_BYTES[a.task] * n / ks / 1e9 / HBM_PEAK_GBPS
+            rf["kernel_span"] = {"p10_us": span["kernel_span_ns"]["p10"] * 1e-3, "min_us": span["kernel_span_ns"]["min"] * 1e-3,
+                                 "launches": span["launches"],
+                                 "gap_between_eager_launches_us": span["gap_between_eager_launches_ns"]["median"] * 1e-3,
+                                 "note": "first wavefront start -> last wavefront end on the 100 MHz chip clock, span build "
+                                         "of the library (make span) in a child process run before this one touched the GPU "
+                                         "(tools/kernel_span.py; eager launches, no profiler).  frac = with the "
+                                         "inter-kernel gap of a dependent hipGraph chain, kernel_frac = the kernel alone"}
+        elif span is not None:
+            rf["kernel_span"] = span
+        key = "%s_%d%s" % (a.task, n, "_substeps%d" % a.substeps if a.substeps > 1 else "")
+        v = pmc.get("valu_per_wavefront", {}).get(key) if a.state == "float32" else None
+        if v:
+            rf["issue"] = dict(issue_bound(v, n, m["launch_s"], cus, clock_hz), source=pmc_src)
+        out.update(extra)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if rccl is not None:
+            out["rccl"] = rccl
+        # a compact digest as the LAST key (a log tail keeps the end of the line) and inside `roofline` (a contract key)
+        pick = lambda d, *ks: {k: d[k] for k in ks if isinstance(d, dict) and k in d}
+        digest = {"timed_steps_total": out["timed_steps_total"], "timed_region_s": out["timed_region_s"],
+                  "headline": pick(out["roofline"], "launch_us", "frac", "kernel_span_us", "kernel_frac", "resident"),
+                  "sweep_frac": {"%s_%d_%s" % (e.get("task"), e.get("envs", 0), e.get("actions")): round(e["frac"], 4)
+                                 for e in extra.get("sweep", []) if "frac" in e},
+                  "sweep_resident": {"%s_%d_%s" % (e.get("task"), e.get("envs", 0), e.get("actions")): e["resident"].split(",")[0][:24]
+                                     for e in extra.get("sweep", []) if "resident" in e},
+                  "config5": [pick(b, "bound", "frac") for b in extra.get("config5", {}).get("bounds", [])],
+                  "config5_launch_us": extra.get("config5", {}).get("launch_us"),
+                  "k_step_us": {k: round(extra[k]["us_per_step"], 3) for k in ("step_many", "rollout_pid", "rollout_random", "rollout_policy_linear")
+                                if "us_per_step" in extra.get(k, {})},
+                  "k_step_issue_frac": {k: round(extra[k]["roofline"]["frac"], 3)
+                                        for k in ("step_many", "rollout_pid", "rollout_random", "rollout_policy_linear")
+                                        if isinstance(extra.get(k, {}).get("roofline", {}).get("frac"), float)},
+                  "with_packed_allgather": pick(extra, "value_with_packed_allgather", "ms_per_step_with_packed_allgather"),
+                  "served_us": {k: round(extra[k]["us_per_step"], 3)
+                                for k in ("served_closed_loop", "served_closed_loop_persistent_policy",
+                                          "served_submit_collect", "served_producers_ahead")
+                                if "us_per_step" in extra.get(k, {})},
+                  "fused_caller_policy_us": {k: extra["rollout_custom"][k] for k in
+                                             ("closed_loop_law_with_state", "linear_policy_44_weights", "replay_policy")
+                                             if k in extra.get("rollout_custom", {})},
+                  "rccl": rccl}
+        out["roofline"]["digest"] = digest
+        out["summary"] = digest
+        return out
+
+    # --gather: all three collective legs, right after the headline.  N > 1 without the flag (the driver's command):
+    # still ONE packed all-gather leg, so that the multi-GPU line shows value_with_packed_allgather beside the
+    # collective-free value -- run LAST and under a deadline (below): the N > 1 collective path has only ever run on
+    # one GPU and under gloo, and a leg that hangs must not cost the line
+    def run_gather_legs(gather_legs):
         from gym_copter_amd.sharded import ShardGather, PackedOutputs
         gather = ShardGather(n, world)           # the product's RCCL all-gather of the obs rows
 
@@ -613,17 +787,19 @@ def main(argv=None):
             g = timer.measure(st, a.steps, min(a.warmup, 50), min_region_s, a.regions,
                               quantum=chunk if mode == "graph" else 1)
             return g, mode
-        g2, mode2 = gather_leg(lambda: gather("obs", env._obs))
-        extra["value_with_allgather"] = total_envs / g2["s_per_step"]
-        extra["ms_per_step_with_allgather"] = g2["s_per_step"] * 1e3
+        modes = {}
+        if "obs" in gather_legs:
+            g2, modes["obs"] = gather_leg(lambda: gather("obs", env._obs))
+            extra["value_with_allgather"] = total_envs / g2["s_per_step"]
+            extra["ms_per_step_with_allgather"] = g2["s_per_step"] * 1e3
         # everything a global learner needs (obs, reward, both flags) in ONE all-gather: the kernel
         # writes its outputs straight into the packed per-rank buffer
         pk = PackedOutputs(n, env.obs_dim, world, device)
-        g3, mode3 = gather_leg(pk.all_gather, bind=lambda: env.bind_outputs(pk.obs, pk.reward, pk.term, pk.trunc))
+        g3, modes["packed"] = gather_leg(pk.all_gather, bind=lambda: env.bind_outputs(pk.obs, pk.reward, pk.term, pk.trunc))
         extra["value_with_packed_allgather"] = total_envs / g3["s_per_step"]
         extra["ms_per_step_with_packed_allgather"] = g3["s_per_step"] * 1e3
-        modes = {"obs": mode2, "packed": mode3}
-        if n % 2 == 0:
+        extra["packed_allgather_bytes_per_rank"] = pk.nbytes
+        if n % 2 == 0 and "pipelined" in gather_legs:
             # double-buffered half-batches: each half's step + packed all-gather on its own
             # stream, so one half's collective is on the links while the other half steps
             from gym_copter_amd.sharded import HalfBatchPipeline
@@ -647,6 +823,9 @@ def main(argv=None):
         extra["allgather_launch_mode"] = modes
         extra["allgather_is_a_collective"] = bool(world > 1 or os.environ.get("COPTERSTEP_FORCE_COLLECTIVE") == "1")
 
+    if a.gather and dist is not None:
+        run_gather_legs(("obs", "packed", "pipelined"))
+
     def k_step_leg(name, k, call, bytes_step, note):
         class Runner:
             def run(self, count):
@@ -657,6 +836,12 @@ def main(argv=None):
                        "us_per_step": g["launch_s"] * 1e6, "repeats": g["repeats"],
                        "algorithmic_bytes_per_env_step": bytes_step,
                        "achieved_GBps": bytes_step * n / g["launch_s"] / 1e9, "note": note}
+        # these kernels keep the env in registers: what bounds them is float64 instruction issue, not memory
+        v = pmc.get("valu_per_wavefront_step", {}).get(name) if (a.task, n, a.state) == ("lander3d", 65536, "float32") else None
+        if v:
+            extra[name]["roofline"] = dict(issue_bound(v, n, g["launch_s"], cus, clock_hz), source=pmc_src)
+        else:
+            extra[name]["roofline"] = {"bound": "valu_f64_issue", "frac": None, "source": pmc_src}
 
     od = env.obs_dim
     if a.many > 0:
@@ -699,8 +884,7 @@ struct Policy {
   }
 };"""
             t0 = time.perf_counter()
-            import tempfile
-            pol = compile_policy(env, src, cache_dir=os.path.join(tempfile.gettempdir(), "copterstep_bench_policies_%d" % os.getuid()))
+            pol = compile_policy(env, src)       # cached in a directory only this user can write (policy_jit)
             compile_s = time.perf_counter() - t0
             ad = env.action_dim
             W = torch.zeros(ad * od + ad, device=device)
@@ -765,12 +949,13 @@ struct Policy {
                        "the same closed loop with the POLICY persistent as well (cs_serve_policy_pid_many: one policy "
                        "kernel per session, controllers in registers): no launch left in the loop -- two hand-offs "
                        "through device memory and the two kernels' arithmetic per step")
-        served_leg("served_submit_collect",
-                   lambda s: (env.serve_submit(s, actions[s % actions.shape[0]]), env.serve_collect(s)), 4,
-                   wire + 4 * env.action_dim + 4 * od + 6,
-                   "plain tensors in and out: cs_serve_submit + cs_serve_collect per step (two small launches on one "
-                   "stream) against the persistent env kernel; bit-identical to cs_step "
-                   "(tests/test_gpu_round3.py::test_served_steps_are_bit_identical_to_cs_step)")
+        if a.served_all:
+            served_leg("served_submit_collect",
+                       lambda s: (env.serve_submit(s, actions[s % actions.shape[0]]), env.serve_collect(s)), 4,
+                       wire + 4 * env.action_dim + 4 * od + 6,
+                       "plain tensors in and out: cs_serve_submit + cs_serve_collect per step (two small launches on one "
+                       "stream) against the persistent env kernel; bit-identical to cs_step "
+                       "(tests/test_gpu_round3.py::test_served_steps_are_bit_identical_to_cs_step)")
         side = served_side
 
         def submit_two_streams(s):
@@ -820,6 +1005,29 @@ struct Policy {
     if a.pid > 0 and world == 1 and not any(k.startswith("ROCPROF") for k in os.environ) \
             and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
         fused_policy_leg()
+    state = {"deadline_hit": False}
+    if world > 1 and dist is not None and not a.gather:
+        import threading
+
+        def give_up():
+            # the leg did not come back: the line goes out without it (rank 0), every rank leaves
+            state["deadline_hit"] = True
+            extra["value_with_packed_allgather"] = None
+            extra["packed_allgather_note"] = "the default packed all-gather leg did not finish within 150 s: abandoned"
+            try:
+                if rank == 0:
+                    os.write(real_stdout, (json.dumps(assemble()) + "\n").encode())
+            finally:
+                os._exit(0)
+        dog = threading.Timer(150.0, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            run_gather_legs(("packed",))
+        except Exception as e:
+            extra["value_with_packed_allgather"] = None
+            extra["packed_allgather_note"] = "failed: %r" % (e,)
+        dog.cancel()
     env.close()
     del stepper, env, actions
     torch.cuda.empty_cache()
@@ -828,10 +1036,25 @@ struct Policy {
     if not a.no_sweep and world == 1:
         sweep = []
         points = [("hover3d", 262144, "uniform", 16),            # BASELINE configs[2] first
+                  # north_star's other action law at the headline size: lander.py's own constant thrust (MOTORVAL)
+                  ("lander3d", 65536, "const", 64), ("lander3d", 65536, "near_hover", 64),
                   ("lander3d", 262144, "uniform", 16), ("lander3d", 262144, "near_hover", 16),
                   ("lander3d", 1048576, "uniform", 8),
                   ("hover3d", 1048576, "uniform", 8), ("lander3d", 4194304, "uniform", 4),
                   ("hover3d", 4194304, "uniform", 4)]
+
+        def resident(task, nn, ring):
+            """Where a step's working set lives between launches: the state tiles (5 376 B per 64 envs in the float32
+            modes), the action ring and the output buffers against the 256 MiB Infinity Cache.  A point that fits is
+            served from that cache (its `frac` is algorithmic bytes over time against the HBM peak, as the contract
+            defines it, but the bytes do not come from HBM); only the others are HBM-resident."""
+            tile = 5376 if a.state != "float64" else 10496
+            obs = 12 if task == "hover3d" else 10
+            ws = (nn + 63) // 64 * tile + ring * nn * 16 + nn * (4 * obs + 4 + 2)
+            tiles = (nn + 63) // 64 * tile
+            where = ("infinity_cache" if ws <= INFINITY_CACHE_BYTES else
+                     "hbm" if tiles > INFINITY_CACHE_BYTES else "state in the infinity cache, action ring + outputs streamed from / to hbm")
+            return where, ws
         for task, nn, law, ring in points:
             if (task, nn, law) == (a.task, n, a.actions):
                 continue
@@ -839,10 +1062,12 @@ struct Policy {
                 g = run_config(torch, timer, gca, a, task, nn, law, 1, device, rank, 100, 100, ring,
                                min_region_s, 3, prefetch=bool(a.prefetch))
                 r = roofline_block(task, nn, g["launch_s"], a.state)
+                where, ws = resident(task, nn, ring)
                 sweep.append({"task": task, "envs": nn, "actions": law, "ring": ring,
                               "value": nn / g["s_per_step"], "unit": "env-steps/s",
                               "ms_per_step": g["s_per_step"] * 1e3, "launch_us": r["launch_us"],
                               "achieved_GBps": r["achieved"], "frac": r["frac"], "repeats": g["repeats"],
+                              "resident": where, "working_set_bytes": ws,
                               "config": "BASELINE configs[2]" if (task, nn, law) == ("hover3d", 262144, "uniform") else None})
             except Exception as e:          # a sweep point never costs the headline
                 sweep.append({"task": task, "envs": nn, "actions": law, "error": repr(e)})
@@ -854,18 +1079,25 @@ struct Policy {
             g = run_config(torch, timer, gca, a, "lander3d", 65536, "near_hover", nsub, device, rank, 100, 100,
                            a.ring, min_region_s, 3, prefetch=bool(a.prefetch))
             r = roofline_block("lander3d", 65536, g["launch_s"], a.state)
-            flops = (FLOPS_PER_SUBSTEP * nsub + FLOPS_PER_STEP_FIXED) * 65536
-            tf = flops / g["launch_s"] / 1e12
+            key = "lander3d_65536_substeps10"
+            bounds = [{"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"]}]
+            flop = pmc.get("f64_flops_per_env_step", {}).get(key) if a.state == "float32" else None
+            if flop:
+                tf = flop * 65536 / g["launch_s"] / 1e12
+                bounds.append({"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / F64_VALU_PEAK_TFLOPS, "flop_per_env_step": flop,
+                               "note": "float64 vector ALU (no MFMA on this path).  flop_per_env_step is EXECUTED float64 "
+                                       "arithmetic by PMC: (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + TRANS_F64 + 2 x FMA_F64) "
+                                       "per wavefront = per env (one lane each)", "source": pmc_src})
+            else:
+                bounds.append({"bound": "valu_f64", "frac": None, "source": pmc_src})
+            v = pmc.get("valu_per_wavefront", {}).get(key) if a.state == "float32" else None
+            if v:
+                bounds.append(dict(issue_bound(v, 65536, g["launch_s"], cus, clock_hz), source=pmc_src))
             extra["config5"] = {
                 "workload": "lander3d, 65536 envs, near_hover actions, dt=0.001 x 10 substeps (BASELINE configs[4])",
                 "value": 65536 / g["s_per_step"], "unit": "env-steps/s", "ms_per_step": g["s_per_step"] * 1e3,
-                "launch_us": r["launch_us"], "repeats": g["repeats"],
-                "bounds": [
-                    {"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"]},
-                    {"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tf / F64_VALU_PEAK_TFLOPS,
-                     "flop_per_env_step": FLOPS_PER_SUBSTEP * nsub + FLOPS_PER_STEP_FIXED,
-                     "note": "float64 vector ALU (no MFMA on this path): algorithmic flops of DESIGN.md section 4"}]}
+                "launch_us": r["launch_us"], "repeats": g["repeats"], "resident": "infinity_cache", "bounds": bounds}
         except Exception as e:
             extra["config5"] = {"error": repr(e)}
             torch.cuda.empty_cache()
@@ -886,74 +1118,7 @@ struct Policy {
         except Exception as e:
             extra["dependent_launch_floor"] = {"error": repr(e)}
 
-    traffic, tsrc = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            here = kernel_source_hash()
-            if tj.get("kernel_source_sha16") != here:
-                tsrc = ("profiles/traffic.json was measured on kernel sources %s, this tree has %s: traffic withheld"
-                        % (tj.get("kernel_source_sha16"), here))
-            else:
-                traffic = tj.get("%s_%d" % (a.task, n))
-                if traffic is not None:
-                    tsrc = ("profiles/traffic.json: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes) of this "
-                            "kernel and batch at commit %s (kernel sources %s = this tree's) -- NOT measured by this run"
-                            % (tj.get("commit"), here))
-        except Exception:
-            traffic = None
-
-    out = {
-        "metric": "env-steps/sec Lander3D at 65 536 envs" if (a.task, n) == ("lander3d", 65536)
-                  else "env-steps/sec %s at %d envs" % (a.task, n),
-        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": m["s_per_step"] * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "repeats": m["repeats"], "regions": m["regions"], "timed_steps_per_region": m["steps"] * m["repeats"],
-        # `steps` echoes --steps; what was actually timed (the driver's consistency arithmetic should use these):
-        "timed_steps_total": m["steps"] * m["repeats"] * m["regions"],
-        "timed_region_s": m["wall_s"],
-        "timing": "median of %d regions of %d x %d steps (hipGraphs of %d launches), each bracketed by barrier + "
-                  "synchronize, MAX over ranks" % (m["regions"], m["repeats"], m["steps"], chunk),
-        "single_pass": m["single_pass"],
-        "config": {"workload": "%s, %d envs/GPU, %s actions, auto-reset NEXT_STEP, %s state words, "
-                               "dt=%g x %d substeps, %s" % (a.task, n, a.actions, a.state,
-                                                          1.0 / (100 * a.substeps), a.substeps,
-                                                          "hipGraph replay of %d-step chunks" % chunk
-                                                          if use_graph else "eager launches"),
-                   "envs_per_gpu": n, "total_envs": total_envs, "task": a.task,
-                   "actions": a.actions, "state_words": a.state, "substeps": a.substeps,
-                   "action_ring": a.ring, "next_action_prefetch": bool(a.prefetch),
-                   "actions_produced_by_a_preceding_kernel": bool(a.produce_actions),
-                   "parallelism": "env-shard x%d" % world},
-        "roofline": roofline_block(a.task, n, m["launch_s"], a.state, traffic, tsrc),
-    }
-    out.update(extra)
-    if cpu is not None:
-        out["cpu_baseline"] = cpu
-    if rccl is not None:
-        out["rccl"] = rccl
-    # a compact digest as the LAST key (a log tail keeps the end of the line) and inside `roofline` (a contract key)
-    pick = lambda d, *ks: {k: d[k] for k in ks if isinstance(d, dict) and k in d}
-    digest = {"timed_steps_total": out["timed_steps_total"], "timed_region_s": out["timed_region_s"],
-              "headline": pick(out["roofline"], "launch_us", "frac"),
-              "sweep_frac": {"%s_%d_%s" % (e.get("task"), e.get("envs", 0), e.get("actions")): round(e["frac"], 4)
-                             for e in extra.get("sweep", []) if "frac" in e},
-              "config5": [pick(b, "bound", "frac") for b in extra.get("config5", {}).get("bounds", [])],
-              "config5_launch_us": extra.get("config5", {}).get("launch_us"),
-              "k_step_us": {k: round(extra[k]["us_per_step"], 3) for k in ("step_many", "rollout_pid", "rollout_random", "rollout_policy_linear")
-                            if "us_per_step" in extra.get(k, {})},
-              "served_us": {k: round(extra[k]["us_per_step"], 3)
-                            for k in ("served_closed_loop", "served_closed_loop_persistent_policy",
-                                      "served_submit_collect", "served_producers_ahead")
-                            if "us_per_step" in extra.get(k, {})},
-              "fused_caller_policy_us": {k: extra["rollout_custom"][k] for k in
-                                         ("closed_loop_law_with_state", "linear_policy_44_weights", "replay_policy")
-                                         if k in extra.get("rollout_custom", {})},
-              "rccl": rccl}
-    out["roofline"]["digest"] = digest
-    out["summary"] = digest
+    out = assemble()
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.close(real_stdout)

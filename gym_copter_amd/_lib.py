@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # COPTERSTEP_LIB selects a diagnostic build of the same ABI (e.g. the stamp build); default = product
 LIB_PATH = os.environ.get("COPTERSTEP_LIB", os.path.join(_HERE, "libcopterstep.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 TASK_LANDER3D, TASK_HOVER3D, TASK_LANDER2D, TASK_LANDER1D, TASK_HOVER2D, TASK_HOVER1D = range(6)
 STATE_F32G, STATE_F32_RN, STATE_F64 = 0, 1, 2
 AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2

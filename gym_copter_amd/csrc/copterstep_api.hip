@@ -38,6 +38,7 @@ struct cs_ctx {
   cs_serve_view serve{};
   bool serve_active = false;
   bool serve_joined = false;  // serve_join has been recorded (a closed session's exit)
+  bool serve_draining = false;  // ... and that exit has not been observed yet (check_idle)
   int64_t serve_cap[4] = {0, 0, 0, 0};  // cs_serve_max_envs by kernel variant (queried once: begin may be captured)
 };
 
@@ -185,6 +186,10 @@ cs::DevConst make_const(const cs_ctx* ctx) {
   c.key_force = (uint32_t)h;
   c.key_action = (uint32_t)(h >> 32);
   c.id_lo = (uint32_t)(uint64_t)g.env_id_base;
+  c.steps_bits = (uint32_t)cs::steps_bits_for(g.max_steps);
+  c.steps_mask = (1u << c.steps_bits) - 1u;
+  c.ep_mask = (1u << (cs::kMetaCounterBits - (int)c.steps_bits)) - 1u;
+  c.meta_pad_ = 0;
   cs::trig_constants(c.trig);
   return c;
 }
@@ -243,12 +248,34 @@ int check_ctx(const cs_ctx* ctx) {
   return CS_OK;
 }
 
+bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 // While a served session is open the env state lives in the registers of its persistent kernel (which writes the
 // tiles back when it exits): everything else that reads or writes the tiles has to wait for cs_serve_end.
-int check_idle(const cs_ctx* ctx, const char* who) {
+// A session closed WITHOUT waiting (cs_serve_end(steps_done = NULL)) may still be running, and cs_serve_end ordered
+// only the stream it was given behind the kernel's exit: until that exit has been observed the context is
+// "draining", and every other entry point orders ITS stream behind the exit as well (or, where it has no stream
+// or the stream is being captured, waits for it on the host: bounded by the session's timeout).
+int check_idle(cs_ctx* ctx, const char* who, void* stream_ = nullptr, bool have_stream = false) {
   if (ctx == nullptr) return fail(CS_ERR_ARG, "null context");
   if (ctx->serve_active)
     return fail(CS_ERR_ARG, std::string(who) + ": a served session is open on this context (cs_serve_end first)");
+  if (ctx->serve_draining) {
+    const hipError_t q = hipEventQuery(ctx->serve_join);
+    if (q == hipSuccess) {
+      ctx->serve_draining = false;
+    } else if (q != hipErrorNotReady) {
+      return hip_fail(q, (std::string(who) + ": hipEventQuery(served session exit)").c_str());
+    } else if (have_stream && !capturing((hipStream_t)stream_)) {
+      CS_HIP(hipStreamWaitEvent((hipStream_t)stream_, ctx->serve_join, 0));  // (still draining for other streams)
+    } else {
+      CS_HIP(hipEventSynchronize(ctx->serve_join));
+      ctx->serve_draining = false;
+    }
+  }
   return CS_OK;
 }
 
@@ -357,7 +384,7 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
     return fail(CS_ERR_ARG, "cs_create: global env ids must lie in [0, 2^32)");
   if (cfg->substeps < 1 || cfg->substeps > 1000)
     return fail(CS_ERR_ARG, "cs_create: substeps must be in [1, 1000]");
-  if (cfg->max_steps < 1 || cfg->max_steps > (int32_t)cs::kMetaStepsMask - 2)
+  if (cfg->max_steps < 1 || cfg->max_steps > (1 << (cs::kMetaStepsBitsMax - 1)) - 3)
     return fail(CS_ERR_ARG, "cs_create: max_steps must be in [1, 2^20 - 3]");
   if (cfg->action_arith != CS_ARITH_F64 && cfg->action_arith != CS_ARITH_F32)
     return fail(CS_ERR_ARG, "cs_create: unknown action_arith");
@@ -501,7 +528,7 @@ int cs_set_altitude(cs_ctx* ctx, double altitude) {
 
 int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, float* obs_dev,
              void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_reset")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_reset", stream, true)) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
                                   force_xyz_dev, obs_dev, ctx->pid_state, ctx->pid_stride, nullptr, 1,
@@ -512,7 +539,7 @@ int cs_reset(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, f
 
 int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, int32_t perturb,
                   const float* force_xyz_dev, float* obs_dev, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_reset_pose")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_reset_pose", stream, true)) return rc_;
   if (pose_dev == nullptr) return fail(CS_ERR_ARG, "cs_reset_pose: pose_dev is required");
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_reset(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, mask_dev,
@@ -523,7 +550,7 @@ int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, i
 }
 
 int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_step_ex")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_step_ex", stream, true)) return rc_;
   if (io == nullptr || io->actions_dev == nullptr)
     return fail(CS_ERR_ARG, "cs_step: actions_dev is required");
   if (io->done_return_dev != nullptr && !ctx->cfg.episode_stats)
@@ -570,7 +597,7 @@ int cs_step_prefetch(cs_ctx* ctx, const float* actions_dev, const float* next_ac
 
 int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float* obs_dev,
                  float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_step_many")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_step_many", stream, true)) return rc_;
   if (actions_dev == nullptr) return fail(CS_ERR_ARG, "cs_step_many: actions_dev is required");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_step_many: num_steps must be >= 1");
   const cs::DevConst& c = constants(ctx);
@@ -720,7 +747,7 @@ int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* g) {
 }
 
 int cs_pid_get_state(cs_ctx* ctx, double* state_host, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_pid_get_state")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_pid_get_state", stream, true)) return rc_;
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_pid_get_state: call cs_pid_configure first");
   if (state_host == nullptr) return fail(CS_ERR_ARG, "cs_pid_get_state: null buffer");
   const size_t n = (size_t)ctx->cfg.num_envs;
@@ -732,7 +759,7 @@ int cs_pid_get_state(cs_ctx* ctx, double* state_host, void* stream) {
 }
 
 int cs_pid_set_state(cs_ctx* ctx, const double* state_host, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_pid_set_state")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_pid_set_state", stream, true)) return rc_;
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_pid_set_state: call cs_pid_configure first");
   if (state_host == nullptr) return fail(CS_ERR_ARG, "cs_pid_set_state: null buffer");
   const size_t n = (size_t)ctx->cfg.num_envs;
@@ -746,7 +773,7 @@ int cs_pid_set_state(cs_ctx* ctx, const double* state_host, void* stream) {
 int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
                    float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
                    void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_rollout_pid")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_rollout_pid", stream, true)) return rc_;
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_rollout_pid: call cs_pid_configure first");
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_rollout_pid: the heuristic flies the 3D tasks only");
@@ -763,7 +790,7 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
 int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float* obs_dev,
                       float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev,
                       void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_rollout_random")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_rollout_random", stream, true)) return rc_;
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_random: num_steps must be >= 1");
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
@@ -775,7 +802,7 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
 }
 
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_set_motors")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_set_motors", stream, true)) return rc_;
   if (motors_dev == nullptr) return fail(CS_ERR_ARG, "cs_set_motors: motors_dev is required");
   const cs::DevConst& c = constants(ctx);
   hipError_t e =
@@ -786,7 +813,7 @@ int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream) {
 
 int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* steps_dev, int32_t* ticks_dev,
                     void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_export_state")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_export_state", stream, true)) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_export_state(ctx->cfg.state_mode, c, ctx->st, x_dev, status_dev, steps_dev, ticks_dev,
                                          (hipStream_t)stream);
@@ -795,7 +822,7 @@ int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* ste
 }
 
 int cs_set_perturbation(cs_ctx* ctx, const uint8_t* mask_dev, const float* force_xyz_dev, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_set_perturbation")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_set_perturbation", stream, true)) return rc_;
   if (force_xyz_dev == nullptr) return fail(CS_ERR_ARG, "cs_set_perturbation: force_xyz_dev is required");
   hipError_t e = cs::launch_set_perturbation(ctx->cfg.state_mode, ctx->st, mask_dev, force_xyz_dev,
                                              (hipStream_t)stream);
@@ -804,10 +831,10 @@ int cs_set_perturbation(cs_ctx* ctx, const uint8_t* mask_dev, const float* force
 }
 
 int cs_episode_stats(cs_ctx* ctx, double* stats_dev, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_episode_stats")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_episode_stats", stream, true)) return rc_;
   if (stats_dev == nullptr) return fail(CS_ERR_ARG, "cs_episode_stats: stats_dev is required");
   CS_HIP(hipMemsetAsync(stats_dev, 0, CS_EPISODE_STATS * sizeof(double), (hipStream_t)stream));
-  hipError_t e = cs::launch_episode_stats(ctx->cfg.state_mode, ctx->st, stats_dev, (hipStream_t)stream);
+  hipError_t e = cs::launch_episode_stats(ctx->cfg.state_mode, constants(ctx), ctx->st, stats_dev, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_episode_stats: kernel launch");
   return CS_OK;
 }
@@ -836,11 +863,6 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out) {
 
 // ---- served stepping: one persistent env kernel per session (copterstep_serve.hip) ---------------------
 namespace {
-
-bool capturing(hipStream_t s) {
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
-}
 
 int serve_read_ctrl(cs_ctx* ctx, uint32_t (&w)[CS_SERVE_CTRL_WORDS]) {
   CS_HIP(hipMemcpy(w, ctx->serve.ctrl, sizeof w, hipMemcpyDeviceToHost));
@@ -941,6 +963,11 @@ int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_
 int cs_serve_submit(cs_ctx* ctx, int32_t step, const float* actions_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_submit: no session has been opened yet");
+  // a feeder launched eagerly with no session open would poll for its whole timeout; captured into a graph (to be
+  // replayed against later sessions) it is fine
+  if (!ctx->serve_active && !capturing((hipStream_t)stream))
+    return fail(CS_ERR_ARG, "cs_serve_submit: no session is open (cs_serve_begin first; only a stream capture may record "
+                            "feeders without one)");
   if (actions_dev == nullptr || step < 0 || (uint32_t)step >= ctx->serve.num_steps)
     return fail(CS_ERR_ARG, "cs_serve_submit: actions_dev is required and step must be in [0, num_steps)");
   hipError_t e = cs::launch_serve_submit(ctx->serve, (uint32_t)step, actions_dev, (hipStream_t)stream);
@@ -952,6 +979,8 @@ int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_de
                      uint8_t* truncated_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_collect: no session has been opened yet");
+  // (allowed after cs_serve_end as well: the output ring of a closed session still holds the steps it completed; a
+  // step it never reached is waited for until the timeout, as during a session)
   if (step < -1 || step >= (int32_t)ctx->serve.num_steps)
     return fail(CS_ERR_ARG, "cs_serve_collect: step must be in [-1, num_steps)");
   hipError_t e = cs::launch_serve_collect(ctx->serve, step, obs_dev, reward_dev, terminated_dev, truncated_dev,
@@ -963,6 +992,11 @@ int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_de
 int cs_serve_policy_pid_many(cs_ctx* ctx, int32_t first_step, int32_t num_steps, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_policy_pid: no session has been opened yet");
+  // a feeder launched eagerly with no session open would poll for its whole timeout; captured into a graph (to be
+  // replayed against later sessions) it is fine
+  if (!ctx->serve_active && !capturing((hipStream_t)stream))
+    return fail(CS_ERR_ARG, "cs_serve_policy_pid: no session is open (cs_serve_begin first; only a stream capture may record "
+                            "feeders without one)");
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_serve_policy_pid: call cs_pid_configure first");
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_serve_policy_pid: the heuristic flies the 3D tasks only");
@@ -984,6 +1018,7 @@ int cs_serve_status(cs_ctx* ctx, int32_t* steps_done_min, int32_t* steps_done_ma
     return fail(CS_ERR_ARG, "cs_serve_status: no session was ever opened");
   DeviceGuard guard(ctx->cfg.device);
   CS_HIP(hipStreamSynchronize(ctx->serve_stream));
+  if (!ctx->serve_active) ctx->serve_draining = false;  // the closed session's exit has now been observed
   uint32_t w[CS_SERVE_CTRL_WORDS];
   if (int rc = serve_read_ctrl(ctx, w)) return rc;
   if (steps_done_min) *steps_done_min = (int32_t)(ctx->serve.num_steps - w[CS_SERVE_CTRL_SHORTFALL]);
@@ -1009,8 +1044,10 @@ int cs_serve_end(cs_ctx* ctx, void* stream_, int32_t* steps_done) {
   CS_HIP(hipStreamWaitEvent(stream, ctx->serve_join, 0));
   ctx->serve_joined = true;
   ctx->serve_active = false;
+  ctx->serve_draining = true;  // until the exit has been observed: other streams are ordered behind it (check_idle)
   if (steps_done == nullptr) return CS_OK;  // enqueue only: cs_serve_status reports later
   CS_HIP(hipStreamSynchronize(stream));
+  ctx->serve_draining = false;
   return cs_serve_status(ctx, steps_done, nullptr, nullptr);
 }
 
@@ -1117,7 +1154,7 @@ int cs_allgather(cs_comm* comm, const void* send_dev, void* recv_dev, int64_t by
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,
                  double* episode_return_host, uint32_t* episode_host, int32_t* ticks_host, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_get_state")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_get_state", stream, true)) return rc_;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_get_state: episode_stats is disabled");
   DeviceGuard guard_dev(ctx->cfg.device);
@@ -1149,7 +1186,7 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
                  const double* force_xyz_host, const uint8_t* flags_host,
                  const double* episode_return_host, const uint32_t* episode_host,
                  const int32_t* ticks_host, void* stream) {
-  if (int rc_ = check_idle(ctx, "cs_set_state")) return rc_;
+  if (int rc_ = check_idle(ctx, "cs_set_state", stream, true)) return rc_;
   if (episode_return_host && !ctx->cfg.episode_stats)
     return fail(CS_ERR_ARG, "cs_set_state: episode_stats is disabled");
   if (ticks_host && !ctx->cfg.track_time)
@@ -1160,8 +1197,9 @@ int cs_set_state(cs_ctx* ctx, const double* x_host, const uint8_t* status_host,
       if (status_host[i] > 3) return fail(CS_ERR_ARG, "cs_set_state: status out of range");
   if (steps_host)
     for (size_t i = 0; i < n; ++i)
-      if (steps_host[i] < 0 || steps_host[i] > (int32_t)cs::kMetaStepsMask)
-        return fail(CS_ERR_ARG, "cs_set_state: steps out of range");
+      if (steps_host[i] < 0 || steps_host[i] > (int32_t)constants(ctx).steps_mask)
+        return fail(CS_ERR_ARG, "cs_set_state: steps out of range (the step counter of this context has " +
+                                    std::to_string(constants(ctx).steps_bits) + " bits)");
   DeviceGuard guard_dev(ctx->cfg.device);
   constexpr int NA = Staging::kArrays;
   const void* host[NA] = {x_host, status_host, steps_host, prev_shaping_host, force_xyz_host, flags_host,

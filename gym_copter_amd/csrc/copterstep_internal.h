@@ -25,8 +25,8 @@ namespace cs {
 //   T1  {x, dx, y, dy}                        translational half of the rigid body ...
 //   T2  {z, dz, gT, meta}                     ... with its guard bits, flight status and counters
 //   R1  {phi, dphi, theta, dtheta}            rotational half ...
-//   R2  {psi, dpsi, gR, episode}              ... with its guard bits and the episode counter
-//   PS  prev_shaping (dword/qword row; NaN = upstream's None)
+//   R2  {psi, dpsi, gR, prev_shaping}         ... with its guard bits and the Lander's previous shaping
+//                                             potential (a state word; NaN = upstream's None)
 //   FE  {force_x, force_y, force_z, ticks}    EXPLICIT reset perturbation [N] (options['forces'],
 //                                             Dynamics.perturb); touched only while one is installed.
 //                                             ticks = Dynamics._ticks (only under cs_config.track_time)
@@ -34,16 +34,20 @@ namespace cs {
 //
 //   gT    = 5 guard bits of each of x, dx, y, dy, z, dz (bit 5j.. = slot j) | flight status (bits 30..31)
 //   gR    = 5 guard bits of each of phi .. dpsi         (bit 5j.. = slot 6+j)
-//   meta  = steps (bits 0..19) | perturbation pending (20) | perturbation is the explicit
-//           one of the FE group (21; otherwise it is the Philox draw of this episode) |
-//           reset pending (22, NEXT_STEP auto-reset)
-//   episode = episodes started so far (the Philox counter word of the reset draw)
+//   meta  = steps (bits 0..S-1) | episode (bits S..28) | perturbation pending (29) | perturbation is
+//           the explicit one of the FE group (30; otherwise it is the Philox draw of this episode) |
+//           reset pending (31, NEXT_STEP auto-reset).  S = bits of 2 * (max_steps + 1): 11 at the default step
+//           limit, which leaves the episode counter 18 bits (see DevConst::steps_bits)
 //
-// In the float64 mode a group's third 8-byte word carries (gT or gR) in its low and (meta or
-// episode) in its high dword and the fourth word is unused; there are no guard bits.
+// Round 4: an ordinary step reads and writes EXACTLY these four groups -- prev_shaping used to be a row of
+// its own and the episode counter a full word of R2 (190 instead of 198 bytes per env-step now; -3 % per step
+// at 65 536 envs and -13 % at 4 M envs, profiles/r04_ab_layout_and_config5.txt).
+//
+// In the float64 mode T2's third 8-byte word carries gT in its low and meta in its high dword (the fourth word
+// is unused); R2's third word carries gR and its fourth prev_shaping; there are no guard bits.
 //
 // (The split into a translational and a rotational half is the split of the physics itself: within
-// one Dynamics.setMotors() the two halves only READ each other's old values.)  A wavefront touches one contiguous 5.5 KB region, and every field is reached from a per-lane
+// one Dynamics.setMotors() the two halves only READ each other's old values.)  A wavefront touches one contiguous 5.25 KB region, and every field is reached from a per-lane
 // base address with an instruction immediate.
 // ---------------------------------------------------------------------------------
 constexpr int kTileEnvs = 64;
@@ -57,7 +61,7 @@ struct Layout {
   uint32_t word;          // bytes per float word (4 or 8)
   bool guard;             // guard bits kept (CS_STATE_F32G)
   uint32_t grp[4];        // offsets of T1, T2, R1, R2 (lane stride 4*word)
-  uint32_t ps, fe, ret;   // PS row (stride word), FE group (stride 4*word), RET row (stride 4)
+  uint32_t fe, ret;       // FE group (stride 4*word), RET row (stride 4)
   uint32_t tile_bytes;
 };
 
@@ -71,8 +75,6 @@ constexpr Layout make_layout(int mode) {
     l.grp[j] = o;
     o += n * 4 * l.word;
   }
-  l.ps = o;
-  o += n * l.word;
   l.fe = o;
   o += n * 4 * l.word;
   l.ret = o;
@@ -81,10 +83,20 @@ constexpr Layout make_layout(int mode) {
   return l;
 }
 
-constexpr uint32_t kMetaStepsMask = 0x000FFFFFu;    // 20 bits
-constexpr uint32_t kMetaPerturbPending = 1u << 20;  // the episode's reset perturbation is not consumed yet
-constexpr uint32_t kMetaExplicitForce = 1u << 21;   // ... and it is the FE group's force, not the Philox draw
-constexpr uint32_t kMetaResetPending = 1u << 22;    // NEXT_STEP: env finished, reset on next step
+// meta word: the three flags sit on top, the two counters share the 29 bits below them
+constexpr uint32_t kMetaPerturbPending = 1u << 29;  // the episode's reset perturbation is not consumed yet
+constexpr uint32_t kMetaExplicitForce = 1u << 30;   // ... and it is the FE group's force, not the Philox draw
+constexpr uint32_t kMetaResetPending = 1u << 31;    // NEXT_STEP: env finished, reset on next step
+constexpr int kMetaCounterBits = 29;                // steps (low) + episode (above it)
+constexpr int kMetaStepsBitsMax = 21;               // cs_config.max_steps <= 2^20 - 3
+// Bits of the step counter for a step limit: the counter saturates at 2^S - 1.  Upstream's counter never
+// saturates (task.py:130) and an env nobody resets keeps counting past the limit (the golden traces run to 1026
+// at the default limit of 1000), so the field gets room for twice the limit: 2^S - 1 >= 2 * (max_steps + 1).
+constexpr int steps_bits_for(int32_t max_steps) {
+  int s = 1;
+  while (((int64_t)1 << s) - 1 < 2 * ((int64_t)max_steps + 1)) ++s;
+  return s;
+}
 
 // Uniform (per-launch) constants, all float64, derived once on the host from cs_config.
 struct DevConst {
@@ -107,6 +119,11 @@ struct DevConst {
   int32_t max_steps, nsub, autoreset, tl_trunc, stats, status0;
   uint32_t key_force, key_action;  // Philox keys (the counter holds env id + episode number)
   uint32_t id_lo;                  // global id of local env 0
+  // the two counters of the meta word: steps = meta & steps_mask, episode = (meta >> steps_bits) & ep_mask.
+  // The episode counter (episodes started; the Philox counter word of the reset draw and the random policy)
+  // has 29 - steps_bits bits and wraps from ep_mask to 1 (0 = never reset): 18 bits at the default limit of
+  // 1000 steps, i.e. an env's perturbation sequence repeats after 262 143 episodes.
+  uint32_t steps_bits, steps_mask, ep_mask, meta_pad_;
   int32_t gyro;                    // 1 = the rotor-inertia term is live (full-featured kernels only)
   int32_t act_f32;                 // 1 = NumPy's float32 evaluation of the motor model (f32_* below)
   int32_t ticks;                   // 1 = keep Dynamics._ticks per env (cs_config.track_time; full-featured kernels only)
@@ -225,7 +242,8 @@ hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* m
 // Running episode statistics: stats[0] = envs, [1] = envs airborne, [2] = sum of steps, [3] = max steps,
 // [4] = episodes started (sum), [5] = running episode return (sum; needs episode_stats), [6] = envs with a
 // non-finite state word, as float64.
-hipError_t launch_episode_stats(int mode, const DevState& s, double* stats_dev, hipStream_t stream);
+hipError_t launch_episode_stats(int mode, const DevConst& c, const DevState& s, double* stats_dev,
+                                hipStream_t stream);
 
 // served stepping (copterstep_serve.hip; include/copterstep.h: cs_serve_*)
 hipError_t launch_serve(int task, int mode, const DevConst& c, const DevState& s, const cs_serve_view& v,

@@ -57,7 +57,6 @@ __device__ __forceinline__ void step_body(
     char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
     const float* const next_actions_dev, const DevConst& c, const DevState& s_rest, const cs_step_io& io_rest) {
-  using T = typename ModeOf<MODE>::T;
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
@@ -90,7 +89,7 @@ __device__ __forceinline__ void step_body(
   CS_SPAN_BEGIN();
   CS_STAMP(0);
 
-  // ---- loads: 4 x 16 B (state, guards, counters) + prev_shaping + the action row ----
+  // ---- loads: 4 x 16 B (state, guards, counters, prev_shaping) + the action row ----
   // T2 first (status, flags, step counter: what the control flow needs), the attitude groups next
   // (the physics starts from the angles)
   const typename TILE::Group t2 = tile.load_group(1);
@@ -99,8 +98,6 @@ __device__ __forceinline__ void step_body(
   float4 act = load_action<TASK, STREAM_ACT>(io.actions_dev, valid ? i : 0u);
   const typename TILE::Group t1 = tile.load_group(0);
   Env<MODE> e;
-  e.prev_sh = 0.0;
-  if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
   e.ep_ret = 0.f;
   if (o.stats) e.ep_ret = tile.load_ret();
   e.ticks = 0u;
@@ -124,15 +121,13 @@ __device__ __forceinline__ void step_body(
   advance<TASK, MODE, OBS, LEAN, ONE_CALL, false>(c, q, o, e, act, io, i, lane, valid, tile, out);
   CS_STAMP(5);
 
-  // ---- stores: 4 x 16 B (state, guards, counters) + prev_shaping ----
-  store_env<MODE, TILE>(tile, e);
-  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
+  // ---- stores: 4 x 16 B (state, guards, counters, prev_shaping) ----
+  store_env<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
   if (valid) {
     if (io.reward_dev) CS_NT_STORE((float)out.reward, at32<float>(io.reward_dev, i << 2));
-    if (io.terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(io.terminated_dev, i));
-    if (io.truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(io.truncated_dev, i));
+    write_flags(io.terminated_dev, io.truncated_dev, 0, i, out.term, out.trunc);
   }
   write_rows<OBS>(io.obs_dev, lds, lane, env0, n, valid, out.row);
   CS_STAMP(6);
@@ -179,7 +174,6 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
     const int num_steps, const DevConst c_arg, const DevState s_rest, const PidConst pc_arg,
     double* const pid_state, const uint32_t pid_stride) {
-  using T = typename ModeOf<MODE>::T;
   // The loop body needs more uniform values than there are scalar registers (the kernel
   // argument block alone is > 100 dwords); what the compiler cannot keep it parks in VGPR lanes
   // and fetches back with v_readlane in every iteration.  Vector registers are plentiful at
@@ -214,8 +208,6 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     const typename TILE::Group t1 = tile.load_group(0);
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
-  e.prev_sh = 0.0;
-  if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
   const bool opt_stats = !LEAN && c.stats;
   e.ep_ret = opt_stats ? tile.load_ret() : 0.f;
   const bool opt_ticks = !LEAN && c.ticks;
@@ -304,8 +296,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     }
     if (valid) {
       if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
-      if (terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(terminated_dev + row, i));
-      if (truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(truncated_dev + row, i));
+      write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
     }
     if constexpr (DIRECT_ROWS) {
       // one wavefront per SIMD: instruction issue is the limit, and three row stores per lane cost fewer
@@ -321,8 +312,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     act = act_next;
   }
 
-  store_env<MODE, TILE>(tile, e);
-  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
+  store_env<MODE, TILE>(c, tile, e);
   if (opt_stats) tile.store_ret(e.ep_ret);
   if (opt_ticks) tile.store_ticks(e.ticks);
   if constexpr (kPid) {
@@ -374,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, co
   // auto-reset mode, so rebuild it from the stored word)
   const uint32_t meta0 = TILE::int_hi(tile.load_group(1));
   e.reset_pending = (meta0 & kMetaResetPending) != 0;
-  store_env<MODE, TILE>(tile, e);
+  store_env<MODE, TILE>(c, tile, e);
 }
 
 // ---------------------------------------------------------------------------------
@@ -444,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
       fe.v[3] = (T)0;
       tile.store_fe(fe);
     }
-    e.episode += 1u;
+    e.episode = next_episode(c, e.episode);
     e.reset_pending = false;
     e.steps = 1;
 #pragma unroll
@@ -452,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     if (pose == nullptr) {
       e.x[4] = (double)(T)c.z0;
       e.fs = c.status0;
-      tile.store_prev((T)c.reset_shaping);  // NaN (= None) for Hover3D
+      e.prev_sh = c.reset_shaping;  // NaN (= None) for Hover3D
     } else {
       // _reset(pose=(x, y, altitude, phi_deg, theta_deg)), task.py:163-170: NED z, np.radians
       const double deg = 3.14159265358979323846 / 180.0;
@@ -466,12 +456,12 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
       e.fs = e.x[4] < 0.0 ? CS_STATUS_AIRBORNE : CS_STATUS_LANDED;  // setState, :215-217
       // the 'initializing' step's shaping (task.py:197 -> lander.py:48-57), NaN (= None) for Hover
       if constexpr (task_is_lander(TASK)) {
-        tile.store_prev((T)lander_shaping(c, e.x));
+        e.prev_sh = (double)(T)lander_shaping(c, e.x);
       } else {
-        tile.store_prev((T)c.reset_shaping);
+        e.prev_sh = c.reset_shaping;
       }
     }
-    store_env<MODE, TILE>(tile, e);
+    store_env<MODE, TILE>(c, tile, e);
     tile.store_ret(0.f);
     if (c.ticks) tile.store_ticks(0u);  // a new Dynamics object (task.py:161)
   }
@@ -503,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void set_perturbation_kernel(const DevState
   fe.v[3] = (T)0;
   tile.store_fe(fe);
   typename TILE::Group t2 = tile.load_group(1);
-  TILE::set_ints(t2, TILE::int_lo(t2), TILE::int_hi(t2) | kMetaPerturbPending | kMetaExplicitForce);
+  TILE::set_t2(t2, TILE::int_lo(t2), TILE::int_hi(t2) | kMetaPerturbPending | kMetaExplicitForce);
   tile.store_group(1, t2);
 }
 
@@ -534,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void state_gather_kernel(const DevConst c, 
   if (a.steps) a.steps[i] = (int32_t)e.steps;
   if (a.flags)
     a.flags[i] = (uint8_t)((e.pend ? 1 : 0) | ((meta & kMetaResetPending) ? 2 : 0) | (e.expl ? 4 : 0));
-  if (a.prev) a.prev[i] = (double)tile.load_prev();
+  if (a.prev) a.prev[i] = e.prev_sh;
   if (a.force) {
     // this episode's reset perturbation: the explicit force of the FE group, or the Philox draw of
     // (seed, global env id, episode - 1); zero before the first reset
@@ -574,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void state_scatter_kernel(const DevConst c,
     for (int k = 0; k < 12; ++k) e.x[k] = round_stored<MODE>(a.x[(size_t)k * n + i]);
   }
   if (a.status) e.fs = (int)a.status[i];
-  if (a.steps) e.steps = (int)a.steps[i];
+  if (a.steps) e.steps = min(max((int)a.steps[i], 0), (int)c.steps_mask);
   if (a.flags) {
     e.pend = (a.flags[i] & 1) != 0;
     e.reset_pending = (a.flags[i] & 2) != 0;
@@ -594,10 +584,10 @@ __global__ __launch_bounds__(kBlock) void state_scatter_kernel(const DevConst c,
     }
     e.expl = expl;
   }
-  if (a.episode) e.episode = a.episode[i];
+  if (a.episode) e.episode = a.episode[i] & c.ep_mask;
   if (a.ticks && c.ticks) tile.store_ticks((uint32_t)a.ticks[i]);
-  store_env<MODE, TILE>(tile, e);
-  if (a.prev) tile.store_prev((T)a.prev[i]);
+  if (a.prev) e.prev_sh = (double)(T)a.prev[i];
+  store_env<MODE, TILE>(c, tile, e);
   if (a.ret) tile.store_ret((float)a.ret[i]);
 }
 
@@ -619,7 +609,8 @@ __device__ __forceinline__ bool word_nonfinite(W w) {  // exponent field all one
   }
 }
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevState s, double* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevConst c, const DevState s,
+                                                               double* __restrict__ out) {
   const uint32_t tile_index = blockIdx.x;
   const uint32_t i = tile_index * kBlock + threadIdx.x;
   using TILE = TileIO<MODE>;
@@ -628,9 +619,9 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevState s,
   const typename TILE::Group t1 = tile.load_group(0), t2 = tile.load_group(1), r1 = tile.load_group(2),
                              r2 = tile.load_group(3);
   const uint32_t meta = TILE::int_hi(t2);
-  const double steps = valid ? (double)(meta & kMetaStepsMask) : 0.0;
+  const double steps = valid ? (double)(meta & c.steps_mask) : 0.0;
   const double air = valid && (TILE::int_lo(t2) >> kStatusShift) == CS_STATUS_AIRBORNE ? 1.0 : 0.0;
-  const double epi = valid ? (double)TILE::int_hi(r2) : 0.0;
+  const double epi = valid ? (double)((meta >> c.steps_bits) & c.ep_mask) : 0.0;
   const double ret = valid ? (double)tile.load_ret() : 0.0;
   // envs with a non-finite state word: upstream lets NaN / inf propagate silently (task.py:133 just casts);
   // the batch counts them (wave ballot -> one atomic per wavefront)
@@ -803,8 +794,9 @@ hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* m
   CS_MODE_LAUNCH(set_perturbation_kernel, s, mask, force_xyz);
 }
 
-hipError_t launch_episode_stats(int mode, const DevState& s, double* stats_dev, hipStream_t stream) {
-  CS_MODE_LAUNCH(episode_stats_kernel, s, stats_dev);
+hipError_t launch_episode_stats(int mode, const DevConst& c, const DevState& s, double* stats_dev,
+                                hipStream_t stream) {
+  CS_MODE_LAUNCH(episode_stats_kernel, c, s, stats_dev);
 }
 
 hipError_t launch_state_gather(int mode, const DevConst& c, const DevState& s, const StateArrays& a,

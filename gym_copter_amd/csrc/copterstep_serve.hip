@@ -43,7 +43,6 @@ template <int TASK, int MODE, bool LEAN, bool ONE_CALL>
 __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const uint32_t n_envs,
                                                        const cs_serve_view v, const DevConst c_arg,
                                                        const DevState s_rest) {
-  using T = typename ModeOf<MODE>::T;
   constexpr int OBS = task_obs_dim(TASK), FIRST = task_obs_first(TASK), ACT = task_act_dim(TASK);
   constexpr int AP = (ACT + 1) / 2, OP = (OBS + 2) / 2;
   static_assert((OBS + 2) % 2 == 0, "obs + reward + flags fill whole granule pairs");
@@ -67,8 +66,6 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
     const typename TILE::Group t1 = tile.load_group(0);
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
-  e.prev_sh = 0.0;
-  if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
   StepOpts o;
   o.stats = !LEAN && c.stats;
   o.ticks = !LEAN && c.ticks;
@@ -178,8 +175,7 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
     done = step + 1u;
   }
 
-  store_env<MODE, TILE>(tile, e);
-  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
+  store_env<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
   if (lane == 0) {
@@ -231,8 +227,10 @@ __global__ __launch_bounds__(kBlock) void serve_collect_kernel(const cs_serve_vi
   for (int k = 0; k < OBS; ++k) row[k] = __uint_as_float(w[k]);
   if (valid) {
     if (reward) reward[i] = __uint_as_float(w[OBS]);
-    if (term) term[i] = (uint8_t)(w[OBS + 1] & 1u);
-    if (trunc) trunc[i] = (uint8_t)((w[OBS + 1] >> 1) & 1u);
+    // (interleaved flags, include/copterstep.h: truncated == terminated + 1 = the columns of one [N,2] array)
+    const size_t fstride = (term != nullptr && trunc == term + 1) ? 2 : 1;
+    if (term) term[i * fstride] = (uint8_t)(w[OBS + 1] & 1u);
+    if (trunc) trunc[i * fstride] = (uint8_t)((w[OBS + 1] >> 1) & 1u);
   }
   write_rows<OBS>(obs, lds, lane, tile * kBlock, v.num_envs, valid, row);
 }

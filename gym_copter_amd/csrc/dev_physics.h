@@ -174,8 +174,8 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, co
 // trigonometric reduction is the identity, and no perturbation pending.  Then every lane takes branch (5) of
 // setMotors (integrate, :180-191) and nothing of the status machine has to be evaluated: the same arithmetic as
 // physics_call() on its integrating lanes -- same operations, same order, dt a uniform value instead of a
-// per-lane select -- in ~70 instead of ~115 instructions.  (ax + 0.0 of the general form is ax here: only the
-// sign of a zero can differ.)
+// per-lane select -- in ~63 instead of ~115 instructions.  Bit-identical to it: the general form adds its
+// "no perturbation" as -0.0 (pending_perturbation), and a + (-0.0) is a, sign of zero included.
 template <bool FULL, bool GYRO>
 __device__ __forceinline__ void physics_flight(const DevConst& c, const Coef& q, const Wrench& w, double (&x)[12]) {
   Trig t;
@@ -218,7 +218,9 @@ __device__ __forceinline__ bool flight_assured(const Coef& q, const Wrench& w, i
   if constexpr (GYRO) grow = fma((fabs(q.g_phi) + fabs(q.g_the)) * fabs(w.om), Sb, grow);
   const bool rates_ok = fma(T, grow, S0) <= Sb;
   const double ang = fmax(fmax(fabs(x[6]), fabs(x[8])), fabs(x[10]));
-  const bool angles_ok = fma(T, Sb, ang) < 0.785;
+  // (0.78, not free_flight()'s 0.785: slack for the rounding of this bound itself; the reduction is the identity
+  // up to pi/4 = 0.78539...)
+  const bool angles_ok = fma(T, Sb, ang) < 0.78;
   const bool finite = (x[6] == x[6]) && (x[8] == x[8]) && (x[10] == x[10]) && (S0 == S0) && (x[7] == x[7]) &&
                       (x[9] == x[9]) && (x[11] == x[11]);
   return fs == CS_STATUS_AIRBORNE && no_contact && rates_ok && angles_ok && finite;
@@ -265,7 +267,7 @@ __device__ __forceinline__ uint32_t physics_substeps(const DevConst& c, const Co
   ticked += (uint32_t)(sub - 1);
 #pragma clang loop unroll(disable)
   for (; sub < c.nsub; ++sub) {
-    const int what = physics_call<FULL, GYRO, true>(c, q, w, x, fs, 0.0, 0.0, 0.0);
+    const int what = physics_call<FULL, GYRO, true>(c, q, w, x, fs, -0.0, -0.0, -0.0);
     ticked += what == kCallFroze ? 0u : 1u;
   }
   return ticked;

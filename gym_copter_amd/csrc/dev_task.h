@@ -46,6 +46,22 @@ __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_w
   }
 }
 
+// The two per-step flags.  `terminated` and `truncated` are separate [N] byte arrays in the ABI; a caller that
+// passes truncated == terminated + 1 declares them the two columns of ONE [N,2] byte array (include/copterstep.h:
+// "interleaved flags") and gets a single 2-byte store per env: the wavefront then writes one full 128-byte line
+// instead of two half lines (-1.1 % per step at 65 536 envs, more at HBM-resident sizes:
+// profiles/r04_ab_layout_and_config5.txt).  `row` = envs before this launch's row 0 (K-step kernels: k * n).
+__device__ __forceinline__ void write_flags(uint8_t* terminated, uint8_t* truncated, size_t row, uint32_t i,
+                                            bool term, bool trunc) {
+  if (terminated != nullptr && truncated == terminated + 1) {  // uniform: both pointers are kernel arguments
+    const uint16_t both = (uint16_t)((term ? 1u : 0u) | (trunc ? 0x100u : 0u));
+    CS_NT_STORE(both, at32<uint16_t>(terminated + 2 * row, i << 1));
+    return;
+  }
+  if (terminated) CS_NT_STORE((uint8_t)(term ? 1 : 0), at32<uint8_t>(terminated + row, i));
+  if (truncated) CS_NT_STORE((uint8_t)(trunc ? 1 : 0), at32<uint8_t>(truncated + row, i));
+}
+
 // ---------------------------------------------------------------------------------
 // one env, register-resident, and one _Task.step() on it
 // ---------------------------------------------------------------------------------
@@ -57,7 +73,7 @@ struct Env {
   bool pend;           // this episode's reset perturbation is not yet consumed
   bool expl;           // ... and it is the explicit force of the FE group (else: the Philox draw)
   bool reset_pending;  // NEXT_STEP: finished, resets at the next step
-  uint32_t episode;    // episodes started
+  uint32_t episode;    // episodes started (DevConst::ep_mask bits, wrapping to 1)
   uint32_t ticks;      // Dynamics._ticks of this episode (kept only under cs_config.track_time)
   double prev_sh;
   float ep_ret;
@@ -81,8 +97,9 @@ __device__ __forceinline__ void unpack_env(const DevConst& c, const typename TIL
                                            const typename TILE::Group& t2, const typename TILE::Group& r1,
                                            const typename TILE::Group& r2, Env<MODE>& e) {
   const uint32_t gT = TILE::int_lo(t2), meta = TILE::int_hi(t2), gR = TILE::int_lo(r2);
-  e.episode = TILE::int_hi(r2);
-  e.steps = (int)(meta & kMetaStepsMask);
+  e.episode = (meta >> c.steps_bits) & c.ep_mask;  // one v_bfe_u32 with uniform operands
+  e.steps = (int)(meta & c.steps_mask);
+  e.prev_sh = (double)TILE::prev_of(r2);
   e.fs = (int)(gT >> kStatusShift);
   e.pend = (meta & kMetaPerturbPending) != 0;
   e.expl = (meta & kMetaExplicitForce) != 0;
@@ -99,13 +116,20 @@ __device__ __forceinline__ void unpack_env(const DevConst& c, const typename TIL
   }
 }
 
-__device__ __forceinline__ uint32_t pack_meta(int steps, bool pend, bool expl, bool reset_pending) {
-  return (uint32_t)steps | (pend ? kMetaPerturbPending : 0u) | (expl ? kMetaExplicitForce : 0u) |
-         (reset_pending ? kMetaResetPending : 0u);
+__device__ __forceinline__ uint32_t pack_meta(const DevConst& c, int steps, uint32_t episode, bool pend, bool expl,
+                                              bool reset_pending) {
+  return ((episode << c.steps_bits) | (uint32_t)steps) | (pend ? kMetaPerturbPending : 0u) |
+         (expl ? kMetaExplicitForce : 0u) | (reset_pending ? kMetaResetPending : 0u);
+}
+// The episode counter after one more reset: it wraps from ep_mask to 1 (0 is "never reset"), so the Philox
+// counter word episode - 1 runs through [0, ep_mask).
+__device__ __forceinline__ uint32_t next_episode(const DevConst& c, uint32_t episode) {
+  const uint32_t n = episode + 1u;
+  return n > c.ep_mask ? 1u : n;
 }
 
 template <int MODE, class TILE>
-__device__ __forceinline__ void store_env(const TILE& tile, const Env<MODE>& e) {
+__device__ __forceinline__ void store_env(const DevConst& c, const TILE& tile, const Env<MODE>& e) {
   using T = typename ModeOf<MODE>::T;
   T w[12];
   words6<MODE>(e.x, w);
@@ -122,8 +146,8 @@ __device__ __forceinline__ void store_env(const TILE& tile, const Env<MODE>& e) 
   t2.v[1] = as_bits(w[5]);
   r2.v[0] = as_bits(w[10]);
   r2.v[1] = as_bits(w[11]);
-  TILE::set_ints(t2, gT, pack_meta(e.steps, e.pend, e.expl, e.reset_pending));
-  TILE::set_ints(r2, gR, e.episode);
+  TILE::set_t2(t2, gT, pack_meta(c, e.steps, e.episode, e.pend, e.expl, e.reset_pending));
+  TILE::set_r2(r2, gR, (T)e.prev_sh);
   tile.store_group(0, t1);
   tile.store_group(1, t2);
   tile.store_group(2, r1);
@@ -155,7 +179,10 @@ __device__ __forceinline__ void pending_perturbation(const DevConst& c, const Co
                                                      uint32_t i, uint32_t episode, bool pend, bool expl,
                                                      double& px, double& py, double& pz) {
   using T = typename ModeOf<MODE>::T;
-  px = py = pz = 0.0;
+  // "none pending" is MINUS zero: a + (-0.0) == a for every a including -0.0, so the general call and the
+  // free-flight call (which adds nothing) leave the same bits, also in the sign of a zero velocity -- which call a
+  // wavefront takes depends on its neighbouring lanes (__all), and an env's bytes must not
+  px = py = pz = -0.0;
   if (pend) {
     double f[3];
     draw_force<T>(c, i, episode - 1u, f);
@@ -280,7 +307,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     reward = v.reward;
     term = v.term;
     trunc = v.trunc;
-    e.steps = min(e.steps + 1, (int)kMetaStepsMask);
+    e.steps = min(e.steps + 1, (int)c.steps_mask);
     e.ep_ret += (float)reward;
   }
   const bool fin = term || trunc;
@@ -320,7 +347,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
       e.x[k] = (double)w0;
       if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
     }
-    e.episode += 1u;
+    e.episode = next_episode(c, e.episode);
     e.fs = c.status0;
     e.pend = true;
     e.expl = false;

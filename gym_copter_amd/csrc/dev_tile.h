@@ -1,4 +1,4 @@
-// dev_tile.h -- the wavefront tile in HBM: storage modes, stream hints, TileIO (one env = 4 x 16 B + 1 dword in, the same out).
+// dev_tile.h -- the wavefront tile in HBM: storage modes, stream hints, TileIO (one env = 4 x 16 B in, the same out).
 // Device code of copterstep_kernels.hip (included there, inside its floating-point-contraction pragma);
 // not a stand-alone header.
 #pragma once
@@ -114,13 +114,11 @@ struct TileIO {
   static constexpr Layout L = ModeOf<MODE>::L;
   char* bg;  // lane stride 4*word  (T1, T2, R1, R2, FE groups)
   char* b4;  // lane stride 4       (RET row)
-  char* bw;  // lane stride word    (PS row)
 
   __device__ __forceinline__ TileIO(const DevState& s, uint32_t tile, uint32_t lane) {
     char* tb = s.tiles + (size_t)tile * L.tile_bytes;  // wave-uniform: scalar arithmetic, 64-bit
     bg = tb + (uint32_t)(kBias + lane * (4u * L.word));
     b4 = tb + (uint32_t)(kBias + lane * 4u);
-    bw = tb + (uint32_t)(kBias + lane * L.word);
   }
   template <class U>
   static __device__ __forceinline__ U ld(const char* p, uint32_t off) {
@@ -145,8 +143,6 @@ struct TileIO {
   }
   __device__ __forceinline__ Group load_group(int j) const { return ld<Group>(bg, L.grp[j]); }
   __device__ __forceinline__ void store_group(int j, const Group& g) const { st(bg, L.grp[j], g); }
-  __device__ __forceinline__ T load_prev() const { return ld<T>(bw, L.ps); }
-  __device__ __forceinline__ void store_prev(T v) const { st(bw, L.ps, v); }
   __device__ __forceinline__ float load_ret() const { return ld<float>(b4, L.ret); }
   __device__ __forceinline__ void store_ret(float v) const { st(b4, L.ret, v); }
   // FE group: the EXPLICIT pending force [N] in its first three words (plain accesses: rare); the fourth
@@ -169,25 +165,30 @@ struct TileIO {
     *reinterpret_cast<uint32_t*>(bg + ((int)(L.fe + 3u * L.word) - kBias)) = t;
   }
 
-  // the two integer words of a T2 / R2 group
+  // the integer words of the T2 group (gT, meta) and of the R2 group (gR), and R2's fourth word: prev_shaping
   static __device__ __forceinline__ uint32_t int_lo(const Group& g) {  // gT or gR
     return (uint32_t)g.v[2];
   }
-  static __device__ __forceinline__ uint32_t int_hi(const Group& g) {  // meta or episode
+  static __device__ __forceinline__ uint32_t int_hi(const Group& g) {  // meta (T2 only)
     if constexpr (sizeof(W) == 4) {
       return g.v[3];
     } else {
       return (uint32_t)(g.v[2] >> 32);
     }
   }
-  static __device__ __forceinline__ void set_ints(Group& g, uint32_t lo, uint32_t hi) {
+  static __device__ __forceinline__ void set_t2(Group& g, uint32_t gT, uint32_t meta) {
     if constexpr (sizeof(W) == 4) {
-      g.v[2] = lo;
-      g.v[3] = hi;
+      g.v[2] = gT;
+      g.v[3] = meta;
     } else {
-      g.v[2] = (W)lo | ((W)hi << 32);
+      g.v[2] = (W)gT | ((W)meta << 32);
       g.v[3] = 0;
     }
+  }
+  static __device__ __forceinline__ T prev_of(const Group& r2) { return as_word(r2.v[3]); }
+  static __device__ __forceinline__ void set_r2(Group& g, uint32_t gR, T prev) {
+    g.v[2] = (W)gR;
+    g.v[3] = as_bits(prev);
   }
 };
 

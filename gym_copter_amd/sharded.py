@@ -61,7 +61,7 @@ class ShardGather:
 
 
 class PackedOutputs:
-    """One byte buffer per rank holding [obs f32 | reward f32 | terminated u8 | truncated u8]
+    """One byte buffer per rank holding [obs f32 | reward f32 | flags u8 [n,2] = (terminated, truncated) per env]
     (each section 16-byte aligned), and its all-gathered counterpart [world, bytes].  The local
     sections are the tensors the step kernel writes; the global ones are strided views of the
     gathered buffer, so one collective moves everything."""
@@ -73,9 +73,8 @@ class PackedOutputs:
         up = lambda b: (b + 15) // 16 * 16
         self.off_obs = 0
         self.off_rew = up(n_local * obs_dim * 4)
-        self.off_term = self.off_rew + up(n_local * 4)
-        self.off_trunc = self.off_term + up(n_local)
-        self.nbytes = self.off_trunc + up(n_local)
+        self.off_flags = self.off_rew + up(n_local * 4)
+        self.nbytes = self.off_flags + up(2 * n_local)
         self.local = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.gathered = torch.zeros((world_size, self.nbytes), dtype=torch.uint8, device=device)
         self.obs, self.reward, self.term, self.trunc = self._sections(self.local.view(1, -1), 1)
@@ -87,9 +86,10 @@ class PackedOutputs:
         n, od = self.n, self.od
         obs = buf2d[:, self.off_obs:self.off_obs + n * od * 4].view(torch.float32).view(rows, n, od)
         rew = buf2d[:, self.off_rew:self.off_rew + n * 4].view(torch.float32)
-        term = buf2d[:, self.off_term:self.off_term + n]
-        trunc = buf2d[:, self.off_trunc:self.off_trunc + n]
-        return obs, rew, term, trunc
+        # terminated / truncated: the columns of the flags section (the step kernel writes each env's pair with
+        # one 2-byte store, include/copterstep.h "interleaved flags")
+        flags = buf2d[:, self.off_flags:self.off_flags + 2 * n].view(rows, n, 2)
+        return obs, rew, flags[:, :, 0], flags[:, :, 1]
 
     def all_gather(self):
         """-> (obs [world, n, od], reward [world, n], terminated [world, n] u8, truncated u8):

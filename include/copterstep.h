@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define CS_ABI_VERSION 3
+#define CS_ABI_VERSION 4
 
 typedef enum cs_status {
   CS_OK = 0,
@@ -168,7 +168,12 @@ typedef struct cs_step_io {
   float* obs_dev;            /* [N,obs_dim] row-major (10 Lander3D / 12 Hover3D) */
   float* reward_dev;         /* [N] */
   uint8_t* terminated_dev;   /* [N] */
-  uint8_t* truncated_dev;    /* [N] */
+  uint8_t* truncated_dev;    /* [N].  INTERLEAVED FLAGS (ABI 4, every stepping entry point): truncated_dev ==
+                                terminated_dev + 1 declares the two the columns of ONE [N,2] byte array
+                                (terminated of env i at byte 2i, truncated at 2i+1; K-step forms: [K,N,2]) and the
+                                kernels write each env's pair with one 2-byte store -- a wavefront then emits one
+                                full 128-byte line instead of two half lines.  Any other pair of pointers: two
+                                plain [N] arrays, as before. */
   float* final_obs_dev;      /* [N,obs_dim]; SAME_STEP only: pre-reset observation of
                                 envs that finished this step (other rows untouched) */
   /* done-mask compaction (wave ballot): ids of the envs that finished this step,
@@ -405,10 +410,14 @@ int cs_serve_max_envs(const cs_ctx* ctx, int64_t* out);
 /* ring: slots per ring, a power of two in [2, 64] (0 = 4).  timeout_s <= 0 = 2 s.  view_out may be NULL. */
 int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_s, void* stream,
                    cs_serve_view* view_out);
-/* plain action rows [N,A] of step `step` -> the action ring (waits for the ring slot, see copterstep_serve.h) */
+/* plain action rows [N,A] of step `step` -> the action ring (waits for the ring slot, see copterstep_serve.h).
+ * The feeders that WRITE into a session (cs_serve_submit, cs_serve_policy_pid*) are refused with CS_ERR_ARG when no
+ * session is open and `stream` is not being captured: launched eagerly against no session they would only poll
+ * until their timeout.  (Captured into a graph they may be recorded at any time and replayed against sessions.) */
 int cs_serve_submit(cs_ctx* ctx, int32_t step, const float* actions_dev, void* stream);
 /* wait for the outputs of step `step` (-1 = the observation before step 0) and write them as cs_step would
- * (each pointer nullable) */
+ * (each pointer nullable; interleaved flags as in cs_step_io).  Also valid after cs_serve_end for the steps the
+ * closed session completed (its output ring is kept until the next cs_serve_begin). */
 int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
                      uint8_t* truncated_dev, void* stream);
 /* One closed-loop policy step as its own kernel: the PID heuristic of cs_pid_configure on the outputs of step
@@ -423,7 +432,10 @@ int cs_serve_policy_pid_many(cs_ctx* ctx, int32_t first_step, int32_t num_steps,
 /* Ask the env kernel to stop at the first step whose actions are not there, and order `stream` behind its
  * exit.  With steps_done != NULL it then synchronises `stream` and reports: CS_OK, or CS_ERR_TIMEOUT if a
  * wavefront gave up; *steps_done = steps completed by every tile.  With steps_done == NULL it only enqueues
- * (CS_OK): the next session can be opened right behind it, and cs_serve_status reports when asked. */
+ * (CS_OK): the next session can be opened right behind it, and cs_serve_status reports when asked.  Until the
+ * env kernel's exit has been observed the context is "draining": every other entry point that touches the env
+ * state (cs_step, cs_reset, cs_get_state, ...) first orders ITS stream behind that exit (or waits for it on the
+ * host when it has no stream to order or the stream is being captured), whatever stream cs_serve_end was given. */
 int cs_serve_end(cs_ctx* ctx, void* stream, int32_t* steps_done);
 int cs_serve_status(cs_ctx* ctx, int32_t* steps_done_min, int32_t* steps_done_max, int32_t* timeouts);
 

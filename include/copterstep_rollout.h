@@ -93,8 +93,6 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     const typename TILE::Group t1 = tile.load_group(0);
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
-  e.prev_sh = 0.0;
-  if constexpr (task_is_lander(TASK)) e.prev_sh = (double)tile.load_prev();
   StepOpts o;
   o.stats = !LEAN && c.stats;
   o.ticks = !LEAN && c.ticks;
@@ -143,8 +141,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     fresh = out.did_reset;
     if (valid) {
       if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
-      if (terminated_dev) CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(terminated_dev + row, i));
-      if (truncated_dev) CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(truncated_dev + row, i));
+      write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
     }
     if constexpr (DIRECT_ROWS) {  /* one wavefront per SIMD: three row stores per lane cost fewer instructions */
       if (obs_dev != nullptr && valid) {
@@ -158,8 +155,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
   }
   policy.store(i, valid);
 
-  store_env<MODE, TILE>(tile, e);
-  if constexpr (task_is_lander(TASK)) tile.store_prev((T)e.prev_sh);
+  store_env<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
 }

@@ -151,7 +151,16 @@ class VecOracle:
         self.time_limit_truncates = bool(time_limit_truncates)
         self.dt = 1. / (tp.frames_per_second * self.substeps)
         self.max_angle = np.radians(tp.max_angle)
-        self.episode = np.zeros(self.n, dtype=np.uint32)   # episodes started (Philox counter word)
+        # episodes started (the Philox counter word is episode - 1).  The device keeps the step counter and this
+        # counter in one 29-bit field of its meta word (copterstep_internal.h): the step counter gets the bits
+        # 2 * (max_steps + 1) needs and saturates at steps_cap (upstream's never does: task.py:130), the episode
+        # counter the rest and wraps from ep_mask to 1
+        self.episode = np.zeros(self.n, dtype=np.uint32)
+        sbits = 1
+        while (1 << sbits) - 1 < 2 * (tp.max_steps + 1):
+            sbits += 1
+        self.steps_cap = (1 << sbits) - 1
+        self.ep_mask = (1 << (29 - sbits)) - 1
         n = self.n
         self.x = np.zeros((12, n), dtype=xdtype)          # struct-of-arrays state
         self.status = np.full(n, LANDED, dtype=np.uint8)
@@ -267,14 +276,15 @@ class VecOracle:
             x0[6], x0[8] = np.radians(p[3]), np.radians(p[4])
             self.x[:, m] = self._round(x0)
         self.status[m] = np.where(self.x[4, m].astype(np.float64) < 0, AIRBORNE, LANDED)
+        nxt = self.episode[m].astype(np.int64) + 1
+        self.episode[m] = np.where(nxt > self.ep_mask, 1, nxt).astype(np.uint32)
         if not perturb:
             f = np.zeros((3, int(np.sum(m))))
         elif forces is None:
-            f = draw_forces(self.seed, self.env_ids[m], self.episode[m], tp.initial_random_force)
+            f = draw_forces(self.seed, self.env_ids[m], self.episode[m] - np.uint32(1), tp.initial_random_force)
         else:
             f = np.asarray(forces, dtype=np.float64)[:, m]
         self.force[:, m] = f.astype(self.T)
-        self.episode[m] += np.uint32(1)
         self.pending[m] = bool(perturb)
         self.done_pending[m] = False
         xs = self.x[:, m].astype(np.float64)
@@ -375,7 +385,7 @@ class VecOracle:
         else:
             tr = np.zeros(n, dtype=bool)
             done |= limit
-        self.steps[live] += 1
+        self.steps[live] = np.minimum(self.steps[live] + 1, self.steps_cap)
 
         reward[live] = r[live]
         term[live] = done[live]

@@ -47,6 +47,14 @@ for k, v in summ.items():
     if isinstance(v, (int, float)) and (k.startswith("lander3d_") or k.startswith("hover3d_")):
         t[k] = v
 json.dump(t, open(R + "/profiles/traffic.json", "w"), indent=1)
+# executed-instruction / executed-flop counts (bench.py: issue bounds of the K-step legs and of the headline, config 5's
+# float64-ALU bound), under the same stamp
+pc = dict(summ.get("pmc_counts", {}), commit=commit, kernel_source_sha16=bench.kernel_source_hash(),
+          note="rocprofv3 PMC per wavefront (SQ_INSTS_VALU / SQ_WAVES; K-step kernels: also per env-step; flops = "
+               "SQ_INSTS_VALU_ADD_F64 + MUL_F64 + TRANS_F64 + 2 x FMA_F64 per wavefront = per env), scripts/profile_gpu.sh; "
+               "bench.py uses a figure only while the kernel sources hash to kernel_source_sha16")
+json.dump(pc, open(R + "/profiles/pmc_counts.json", "w"), indent=1)
+print(json.dumps(pc, indent=1))
 print(json.dumps(t, indent=1))
 b = json.load(open(P + "/bench_unprofiled.json"))
 print("bench default: %.2f G env-steps/s, %.3f us/step, frac %.3f" % (b["value"] / 1e9, b["ms_per_step"] * 1e3,

@@ -58,6 +58,12 @@ for cfgname in "c5 --envs 65536 --substeps 10 --actions near_hover" "c3 --task h
   $T rocprofv3 --pmc $SQ1 -d $OUT/sq1_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/sq1_$name.log 2>&1
   $T rocprofv3 --pmc $SQ2 -d $OUT/sq2_$name --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 "$@" > $OUT/sq2_$name.log 2>&1
 done
+step pmc_flops
+# 3b. float64 arithmetic executed (the flop count bench.py prices config 5 with): ADD + MUL + TRANS + 2 x FMA per
+#     wavefront = per env, for configs[4], the headline and the K-step kernels (SQ counters: their own pass)
+FL="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"
+$T rocprofv3 --pmc $FL -d $OUT/fl_c5 --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 --envs 65536 --substeps 10 --actions near_hover > $OUT/fl_c5.log 2>&1
+$T rocprofv3 --pmc $FL -d $OUT/fl --output-format csv -- $SQB > $OUT/fl.log 2>&1
 step spans
 # 4. the kernel's own duration per launch, un-profiled: first wavefront start -> last wavefront end on the
 #    100 MHz clock in the span build (tools/kernel_span.py; phases not serialised)

@@ -159,12 +159,32 @@ for tag, kern, label in (("", "step_kernel<0, 0, true", "headline: Lander3D 65 5
     res.update({"pmc%s_%s" % (tag, k): v for k, v in c.items()})
     print()
 
+# ---- 4b. float64 arithmetic executed, by PMC (what bench.py prices config 5's float64-ALU bound with) --------------
+counts = {"valu_per_wavefront": {}, "f64_flops_per_env_step": {}, "valu_per_wavefront_step": {}}
+for key, sub, kern in (("lander3d_65536_substeps10", "fl_c5", "step_kernel<0, 0, true"), ("lander3d_65536", "fl", "step_kernel<0, 0, true")):
+    c = counters(sub, kern)
+    if c.get("SQ_WAVES"):
+        w = c["SQ_WAVES"]
+        ops = {k: c.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) / w for k in ("ADD", "MUL", "FMA", "TRANS")}
+        flops = ops["ADD"] + ops["MUL"] + ops["TRANS"] + 2 * ops["FMA"]
+        counts["f64_flops_per_env_step"][key] = flops
+        counts["valu_per_wavefront"][key] = c["SQ_INSTS_VALU"] / w
+        print("== PMC, float64 arithmetic executed per wavefront (= per env: one lane each), %s ==" % key)
+        print("ADD_F64 %.1f  MUL_F64 %.1f  FMA_F64 %.1f  TRANS_F64 %.1f  -> %.1f flop per env-step (FMA = 2); all vector "
+              "instructions %.1f" % (ops["ADD"], ops["MUL"], ops["FMA"], ops["TRANS"], flops, c["SQ_INSTS_VALU"] / w))
+        print()
+for key, tag in (("lander3d_65536", ""), ("lander3d_65536_substeps10", "_c5"), ("hover3d_262144", "_c3")):
+    per = res.get("pmc_per_wave" + tag)
+    if per and "SQ_INSTS_VALU" in per:
+        counts["valu_per_wavefront"].setdefault(key, per["SQ_INSTS_VALU"])
+
 # the K-step kernels of the same runs (bench.py extras): executed instructions per wavefront and env-step
 print("== PMC, K-step kernels: per wavefront and env-step ==")
 res["pmc_k_step"] = {}
-for name, label, k in (("step_many_kernel<0, 0, true, 0,", "open loop", 64),
-                       ("step_many_kernel<0, 0, true, 1,", "PID policy", 100),
-                       ("step_many_kernel<0, 0, true, 2,", "random policy", 100)):
+for name, label, k, leg in (("step_many_kernel<0, 0, true, 0,", "open loop", 64, "step_many"),
+                            ("step_many_kernel<0, 0, true, 1,", "PID policy", 100, "rollout_pid"),
+                            ("step_many_kernel<0, 0, true, 2,", "random policy", 100, "rollout_random"),
+                            ("rollout_custom_kernel<0, 0, true,", "caller's linear policy", 100, "rollout_policy_linear")):
     m = {}
     for sub in ("sq1", "sq2"):
         m.update(counters(sub, name))
@@ -172,6 +192,17 @@ for name, label, k in (("step_many_kernel<0, 0, true, 0,", "open loop", 64),
         per = {c: m[c] / m["SQ_WAVES"] / k for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD",
                                                     "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES") if c in m}
         res["pmc_k_step"][name] = per
-        print("%-14s (%3d steps/launch): " % (label, k) +
+        counts["valu_per_wavefront_step"][leg] = per["SQ_INSTS_VALU"]
+        print("%-22s (%3d steps/launch): " % (label, k) +
               "  ".join("%s %.1f" % (c.replace("SQ_INSTS_", "").replace("SQ_", ""), v) for c, v in per.items()))
+res["pmc_counts"] = counts
+print()
+print("== issue floors from the counts above: wavefronts per SIMD x vector instructions x 4 cycles / 2.4 GHz (1 024 SIMDs) ==")
+for leg, v in counts["valu_per_wavefront_step"].items():
+    print("%-24s %6.1f VALU per wavefront and env-step -> floor %.3f us per step at 65 536 envs, ceiling %.1f G env-steps/s"
+          % (leg, v, v * 4 / 2.4e9 * 1e6, 65536 / (v * 4 / 2.4e9) / 1e9))
+for key, v in counts["valu_per_wavefront"].items():
+    n = int(key.split("_")[1])
+    per_simd = -(-(n // 64) // 1024)
+    print("%-28s %6.1f VALU per wavefront, %d wavefront(s) per SIMD -> floor %.3f us per launch" % (key, v, per_simd, per_simd * v * 4 / 2.4e9 * 1e6))
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)

@@ -64,7 +64,23 @@ def step_both(env, orc, actions):
     return got, want, infos
 
 
+def reward_limit(wobs, wr, r_abs=2e-3, r_rel=2e-6):
+    """Per-env tolerance of the float32 reward against the oracle's float64 one: the golden-trace formula
+    5e-5 + 1e-5 |r| + 6e-7 |prev_shaping| (tests/test_gpu_parity.py: prev_shaping is a float32 word, so the reward
+    carries its rounding), with |prev_shaping| bounded from what the step returned: |shaping now| + |r|, shaping now
+    <= 25 * |first six observed components| + 110 (the |dz| penalty and a yaw term the observation does not show).
+    About 2.7e-4 for an env at altitude 10; never looser than the (r_abs, r_rel) a test passes -- that pair is what
+    full-throttle lanes with shaping in the thousands get, selected by their magnitude, not globally."""
+    wobs = np.asarray(wobs, dtype=np.float64)
+    wr = np.abs(np.asarray(wr, dtype=np.float64))
+    with np.errstate(invalid="ignore", over="ignore"):
+        s = wr + 25.0 * np.sqrt(np.sum(np.square(wobs[:, :6]), axis=1)) + 110.0
+    s = np.where(np.isfinite(s), s, np.inf)
+    return np.minimum(5e-5 + 1e-5 * wr + 6e-7 * s, r_abs + r_rel * wr)
+
+
 def assert_step_close(got, want, x_tol, r_abs=5e-5, r_rel=1e-5, ctx=""):
+    """r_abs = "auto": the magnitude-aware reward tolerance of reward_limit() (bounded by 2e-3 + 2e-6 |r|)."""
     obs, r, term, trunc = got
     wobs, wr, wterm, wtrunc = want
     assert np.array_equal(term.astype(bool), wterm), "terminated mismatch %s" % ctx
@@ -72,7 +88,7 @@ def assert_step_close(got, want, x_tol, r_abs=5e-5, r_rel=1e-5, ctx=""):
     e = scaled_err(obs, wobs)
     assert e <= x_tol, "obs err %.3e > %.1e %s" % (e, x_tol, ctx)
     dr = np.abs(r.astype(np.float64) - wr)
-    lim = r_abs + r_rel * np.abs(wr)
+    lim = reward_limit(wobs, wr) if isinstance(r_abs, str) else r_abs + r_rel * np.abs(wr)
     j = int(np.argmax(dr - lim))
     assert np.all(dr <= lim), "reward err %.3e at env %d (got %r want %r term %r obs %r) %s" % (
         float(dr[j]), j, r[j], wr[j], term[j], obs[j], ctx)

@@ -22,7 +22,7 @@ hipError_t launch_set_motors(int, const DevConst&, const DevState&, const float*
 hipError_t launch_reset(int, int, const DevConst&, const DevState&, const uint8_t*, const float*, float*, double*, uint32_t,
                         const float*, int, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_set_perturbation(int, const DevState&, const uint8_t*, const float*, hipStream_t) { return hipErrorUnknown; }
-hipError_t launch_episode_stats(int, const DevState&, double*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_episode_stats(int, const DevConst&, const DevState&, double*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_state_gather(int, const DevConst&, const DevState&, const StateArrays&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_state_scatter(int, const DevConst&, const DevState&, const StateArrays&, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_serve(int, int, const DevConst&, const DevState&, const cs_serve_view&, hipStream_t) { return hipErrorUnknown; }
@@ -82,6 +82,8 @@ int main() {
       REQUIRE(c.k_thrust < 0 && c.k_roll > 0 && c.k_yaw > 0 && c.dt == 0.01 && c.two_inv_M == 2.0 / 1.380);
       REQUIRE(std::isnan(c.reset_shaping) == !cs::task_is_lander(task));
       REQUIRE(c.gyro == 0 && c.act_f32 == 0 && c.key_force != c.key_action);
+      // the two counters of the meta word at the default step limit (1000): 11 + 18 of its 29 counter bits
+      REQUIRE(c.steps_bits == 11 && c.steps_mask == 2047 && c.ep_mask == (1u << 18) - 1);
       REQUIRE(c.f32_pi == 3.14159274101257324f && c.f32_LB == (float)(0.35 * 5e-3));
       fake.cfg.thrust_model = CS_THRUST_LIFT;
       fake.cfg.rotor_gyro = 1;
@@ -95,8 +97,8 @@ int main() {
       // ---- tile layout: the groups and rows of a tile follow each other without overlap ----
       const cs::Layout& L = fake.layout;
       const uint32_t gsz = 64u * 4u * L.word;
-      REQUIRE(L.grp[0] == 0 && L.grp[1] == gsz && L.grp[2] == 2 * gsz && L.grp[3] == 3 * gsz && L.ps == 4 * gsz);
-      REQUIRE(L.fe == L.ps + 64u * L.word && L.ret == L.fe + gsz && L.tile_bytes >= L.ret + 256u && L.tile_bytes % 256u == 0);
+      REQUIRE(L.grp[0] == 0 && L.grp[1] == gsz && L.grp[2] == 2 * gsz && L.grp[3] == 3 * gsz && L.fe == 4 * gsz);
+      REQUIRE(L.ret == L.fe + gsz && L.tile_bytes >= L.ret + 256u && L.tile_bytes % 256u == 0);
     }
   }
 
@@ -110,6 +112,11 @@ int main() {
     const bool none[Staging::kArrays] = {};
     REQUIRE(Staging(5, none).bytes == 0);
   }
+
+  // ---- step-counter width by step limit: the saturated counter stays above max_steps + 1 ----
+  REQUIRE(cs::steps_bits_for(1) == 3 && cs::steps_bits_for(2) == 3 && cs::steps_bits_for(3) == 4);
+  REQUIRE(cs::steps_bits_for(1000) == 11 && cs::steps_bits_for(1022) == 11 && cs::steps_bits_for(1023) == 12);
+  REQUIRE(cs::steps_bits_for((1 << 20) - 3) == 21 && cs::kMetaCounterBits - cs::kMetaStepsBitsMax == 8);
 
   // ---- seed mixing, environment overrides ----
   REQUIRE(splitmix64(0) == 0xE220A8397B1DCDAFull && splitmix64(1) != splitmix64(0x100000000ull));

@@ -248,3 +248,29 @@ def test_policy_cache_directory_must_be_private(tmp_path, monkeypatch):
     made = []
     monkeypatch.setattr(tempfile, "mkdtemp", lambda prefix="": made.append(prefix) or str(tmp_path / "fresh"))
     assert policy_jit._private_cache_dir(None) == str(tmp_path / "fresh") and made
+
+
+def test_env_pickles_as_its_constructor_keywords(monkeypatch):
+    """The reference's envs pickle through EzPickle = their constructor arguments (task.py:23, :40).  Here:
+    __reduce__ -> (_rebuild_env, (keywords,)); unpickling calls the constructor with exactly those keywords (checked
+    with a recording stand-in: there is no device here to build a real env on)."""
+    import pickle
+    from gym_copter_amd import vecenv
+    e = object.__new__(vecenv.CopterVecEnv)
+    e._ctor_kwargs = dict(task="hover3d", num_envs=5, device=0, seed=9, max_steps=77, bounds=12.0,
+                          vehicle_params={"M": 2.0})
+    e.closed, e._ctx = True, None
+    blob = pickle.dumps(e)
+    seen = {}
+
+    class Recorder:
+        def __init__(self, **kw):
+            seen.update(kw)
+    monkeypatch.setattr(vecenv, "CopterVecEnv", Recorder)
+    back = pickle.loads(blob)
+    assert isinstance(back, Recorder) and seen == e._ctor_kwargs
+    monkeypatch.undo()
+    import torch
+    if not torch.cuda.is_available():            # the real constructor is reached and fails loudly without a device
+        with pytest.raises(_lib.CopterStepError):
+            pickle.loads(blob)

@@ -70,3 +70,42 @@ def test_the_real_launch_reaches_the_ranks_on_a_machine_without_gpus():
     assert p.returncode != 0
     assert "bench.py: starting 2 ranks" in p.stderr
     assert p.stderr.count("bench.py") >= 2 and ("HIP" in p.stderr or "CUDA" in p.stderr or "cuda" in p.stderr)
+
+
+def test_issue_bound_arithmetic_and_stamped_profile_figures(tmp_path, monkeypatch):
+    """The bounds bench.py prints beside the K-step legs, config 5 and the headline follow from profiles/ by stated
+    arithmetic: floor = wavefronts per SIMD x executed vector instructions x 4 cycles / clock; a PMC figure is used
+    only while the kernel sources hash to the stamp it was measured under."""
+    b = bench.issue_bound(330.0, 65536, 0.94e-6, cus=256, clock_hz=2.4e9)
+    assert b["wavefronts_per_simd"] == 1 and b["simds"] == 1024
+    assert abs(b["floor_us"] - 330 * 4 / 2.4e3) < 1e-12 and abs(b["frac"] - 0.55 / 0.94) < 1e-9
+    assert abs(b["ceiling_env_steps_per_s"] - 65536 / 0.55e-6) < 1e3
+    assert bench.issue_bound(386.0, 262144, 7e-6, 256, 2.4e9)["wavefronts_per_simd"] == 4
+    assert bench.issue_bound(10.0, 65, 1e-6, 256, 2.4e9)["wavefronts_per_simd"] == 1
+    # stamped figures: right hash -> used; any other -> withheld with the reason
+    import json
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "abc")
+    d, why = bench.load_stamped("pmc_counts.json")
+    assert d is None and "absent" in why
+    (tmp_path / "profiles" / "pmc_counts.json").write_text(json.dumps({"kernel_source_sha16": "abc", "commit": "c0ffee",
+                                                                      "valu_per_wavefront_step": {"step_many": 330.0}}))
+    d, why = bench.load_stamped("pmc_counts.json")
+    assert d["valu_per_wavefront_step"]["step_many"] == 330.0 and "c0ffee" in why
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "other")
+    d, why = bench.load_stamped("pmc_counts.json")
+    assert d is None and "withheld" in why
+
+
+def test_span_child_reports_instead_of_raising_when_it_cannot_run(tmp_path, monkeypatch):
+    """The kernel-only figure comes from a child process on the span build; without that build (or under a profiler)
+    the line carries the reason, never an exception."""
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert "absent" in bench.kernel_span_child("lander3d", 65536, "uniform", 1)["error"]
+    os.makedirs(tmp_path / "gym_copter_amd" / "csrc" / "build")
+    (tmp_path / "gym_copter_amd" / "csrc" / "build" / "libcopterstep_span.so").write_bytes(b"")
+    monkeypatch.setenv("ROCPROFILER_TEST", "1")
+    assert "profiler" in bench.kernel_span_child("lander3d", 65536, "uniform", 1)["error"]
+    monkeypatch.delenv("ROCPROFILER_TEST")
+    assert "error" in bench.kernel_span_child("lander3d", 65536, "uniform", 1)      # (no tools/kernel_span.py there)

@@ -238,7 +238,7 @@ def test_served_steps_at_full_size_vs_cs_step_and_oracle():
         if s < 60:
             obs, r, term, trunc = (to_np(t).copy() for t in got)
             assert_step_close((obs, r, term, trunc), orc.step(to_np(a).astype(np.float64)), MODE_TOL["float32"] * 100,
-                              r_abs=2e-3, ctx="step %d" % s)
+                              r_abs="auto", ctx="step %d" % s)
     assert served.serve_end() == K
     assert int(bad) == 0
     _assert_same_state(served, plain)

@@ -1,0 +1,457 @@
+"""-m gpu tests added in round 4: the four-group tile (prev_shaping inside the R2 group, the episode counter inside
+the meta word), interleaved flags, array-likes that are not torch / NumPy, pickling of the constructor arguments."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gpu_util import MODE_TOL, assert_state_close, assert_step_close, have_gpu, make_pair, step_both, to_np
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
+
+
+# ---------------------------------------------------------------------------------------
+# interleaved flags (include/copterstep.h, cs_step_io): truncated == terminated + 1
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task,mode,trunc", [("lander3d", "float32", False), ("hover3d", "float64", True),
+                                             ("lander2d", "float32", True)])
+def test_interleaved_flags_equal_separate_flag_arrays(task, mode, trunc):
+    """The two flags as the columns of ONE [N,2] byte array (one 2-byte store per env) against two plain [N]
+    arrays, on twins: cs_step, cs_step_many, cs_rollout_random; ragged batch, short episodes so that both flags
+    fire.  Canary bytes around the interleaved buffer stay untouched."""
+    import torch
+    import gym_copter_amd
+    n, K = 1000 + 37, 12
+    kw = dict(task=task, num_envs=n, state_dtype=mode, seed=11, autoreset_mode="next_step", max_steps=9,
+              time_limit_truncates=trunc)
+    a_env, b_env = gym_copter_amd.CopterVecEnv(**kw), gym_copter_amd.CopterVecEnv(**kw)
+    dev, od, ad = a_env.device, a_env.obs_dim, a_env.action_dim
+    # A: the wrapper's default outputs are interleaved
+    assert a_env._term.stride() == (2,) and a_env._trunc.data_ptr() == a_env._term.data_ptr() + 1
+    # B: caller-bound, two contiguous arrays
+    b_out = (torch.zeros((n, od), device=dev), torch.zeros(n, device=dev),
+             torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
+    b_env.bind_outputs(*b_out)
+    # C: caller-bound interleaved pair inside a canary-guarded buffer
+    c_env = gym_copter_amd.CopterVecEnv(**kw)
+    guard = torch.full((2 * n + 64,), 0xA5, dtype=torch.uint8, device=dev)
+    fl = guard[32:32 + 2 * n].view(n, 2)
+    c_env.bind_outputs(torch.zeros((n, od), device=dev), torch.zeros(n, device=dev), fl[:, 0], fl[:, 1])
+    for e in (a_env, b_env, c_env):
+        e.reset()
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    seen_term = seen_trunc = 0
+    for t in range(30):
+        act = torch.rand((n, ad), generator=g, device=dev) * 0.04
+        ra, rb, rc = a_env.step(act), b_env.step(act), c_env.step(act)
+        for k in range(4):
+            assert torch.equal(ra[k], rb[k]) and torch.equal(ra[k], rc[k]), (t, k)
+        seen_term += int(ra[2].sum())
+        seen_trunc += int(ra[3].sum())
+    assert seen_term + seen_trunc > 0 and (seen_trunc > 0) == trunc and (seen_term > 0 or task == "hover3d")
+    assert bool((guard[:32] == 0xA5).all()) and bool((guard[32 + 2 * n:] == 0xA5).all())
+    # K-step forms: the wrapper's [K,N,2] flags against separate [K,N] arrays through the C ABI
+    acts = torch.rand((K, n, ad), generator=g, device=dev) * 0.04
+    oa = a_env.step_many(acts)
+    assert oa[2].stride() == (2 * n, 2)
+    sep = (torch.zeros((K, n, od), device=dev), torch.zeros((K, n), device=dev),
+           torch.zeros((K, n), dtype=torch.uint8, device=dev), torch.zeros((K, n), dtype=torch.uint8, device=dev))
+    p = lambda x: C.c_void_p(x.data_ptr())
+    from gym_copter_amd import _lib
+    _lib.check(b_env._lib.cs_step_many(b_env._ctx, K, p(acts), p(sep[0]), p(sep[1]), p(sep[2]), p(sep[3]),
+                                       b_env._stream()))
+    for k in range(4):
+        assert torch.equal(oa[k].to(sep[k].dtype) if k >= 2 else oa[k], sep[k]), k
+    ra = a_env.rollout_random(K)
+    _lib.check(b_env._lib.cs_rollout_random(b_env._ctx, K, None, p(sep[0]), p(sep[1]), p(sep[2]), p(sep[3]),
+                                            b_env._stream()))
+    for k in range(4):
+        assert torch.equal(ra[k].to(sep[k].dtype) if k >= 2 else ra[k], sep[k]), k
+    sa, sb = a_env.get_state(), b_env.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    # NumPy convenience path: flags come back as bool arrays
+    o, r, te, tr, _ = a_env.step(np.zeros((n, ad), np.float32))
+    assert te.dtype == np.bool_ and tr.dtype == np.bool_ and te.shape == (n,) == tr.shape
+    for e in (a_env, b_env, c_env):
+        e.close()
+
+
+def test_served_collect_writes_interleaved_flags():
+    """cs_serve_collect into the wrapper's default (interleaved) flag buffers against cs_step on a twin."""
+    import torch
+    import gym_copter_amd
+    n, K = 700, 10
+    kw = dict(task="lander3d", num_envs=n, seed=5, autoreset_mode="next_step", max_steps=6)
+    a_env, b_env = gym_copter_amd.CopterVecEnv(**kw), gym_copter_amd.CopterVecEnv(**kw)
+    a_env.reset()
+    b_env.reset()
+    g = torch.Generator(device=a_env.device)
+    g.manual_seed(1)
+    acts = torch.rand((K, n, 4), generator=g, device=a_env.device) * 0.04
+    a_env.serve_begin(K, timeout=5.0)
+    fired = 0
+    for s in range(K):
+        a_env.serve_submit(s, acts[s])
+        got = a_env.serve_collect(s)
+        want = b_env.step(acts[s])
+        for k in range(4):
+            assert torch.equal(got[k], want[k]), (s, k)
+        fired += int(got[2].sum())
+    assert a_env.serve_end() == K and fired > 0
+    a_env.close()
+    b_env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# the meta word's two counters (copterstep_internal.h): episode wraps, steps saturate
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("max_steps,sbits", [(1000, 11), (5, 4), (3000, 13)])
+def test_episode_counter_wraps_and_step_counter_saturates_like_the_oracle(max_steps, sbits):
+    """The episode counter has 29 - S bits and wraps from its maximum to 1 (the Philox counter word episode - 1
+    runs through [0, max)); the step counter has S bits and saturates.  Both against the oracle, which restates
+    the same rule, across a wrap: forces drawn on the device = the oracle's draw for the wrapped number."""
+    import torch
+    n = 300
+    env, orc = make_pair("lander3d", n, "float32", "next_step", seed=21, max_steps=max_steps)
+    ep_mask = (1 << (29 - sbits)) - 1
+    assert orc.ep_mask == ep_mask and orc.steps_cap == (1 << sbits) - 1
+    env.reset()
+    orc.reset()
+    # park the counters just below the wrap (a few envs at other values)
+    ep = np.full(n, ep_mask - 1, np.uint32)
+    ep[::7] = ep_mask
+    ep[1::7] = 5
+    env.set_state(episode=ep)
+    orc.episode[:] = ep
+    assert np.array_equal(env.get_state(only=("episode",))["episode"], ep)
+    rng = np.random.default_rng(2)
+    wrapped = False
+    for t in range(60):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        got, want, _ = step_both(env, orc, a)
+        assert_step_close(got, want, 2e-6, r_abs="auto", ctx="t=%d" % t)
+        st = env.get_state()
+        assert np.array_equal(st["episode"], orc.episode), t
+        assert np.array_equal(st["force"].astype(np.float32), orc.force.astype(np.float32)), t
+        wrapped |= bool(np.any(orc.episode < 5))
+    assert wrapped and orc.episode.max() <= ep_mask and orc.episode.min() >= 1
+    assert_state_close(env, orc, MODE_TOL["float32"])
+    assert float(to_np(env.batch_stats())[4]) == float(orc.episode.sum())
+    env.close()
+    # saturation: nobody resets these envs
+    env, orc = make_pair("hover3d", 64, "float32", "disabled", seed=2, max_steps=max_steps)
+    env.reset()
+    orc.reset()
+    cap = (1 << sbits) - 1
+    env.set_state(steps=np.full(64, cap - 2, np.int32))
+    orc.steps[:] = cap - 2
+    hover = np.full((64, 4), 0.0165, np.float32)
+    for t in range(5):
+        step_both(env, orc, hover)
+    assert np.array_equal(env.get_state()["steps"], orc.steps) and int(orc.steps.max()) == cap
+    with pytest.raises(Exception, match="steps out of range"):
+        env.set_state(steps=np.full(64, cap + 1, np.int32))
+    env.close()
+
+
+def test_prev_shaping_travels_inside_the_r2_group():
+    """prev_shaping is a word of the R2 group now: set / get round trip incl. NaN (= None), the reward of the next
+    step is shaping - that value, in both word widths, and a Hover env keeps its NaN."""
+    import torch
+    for mode in ("float32", "float64"):
+        env, orc = make_pair("lander3d", 130, mode, "disabled", seed=4)
+        env.reset()
+        orc.reset()
+        prev = np.linspace(-300, -200, 130)
+        prev[3] = np.nan
+        env.set_state(prev_shaping=prev)
+        orc.prev_shaping[:] = prev.astype(orc.T)
+        got = env.get_state(only=("prev_shaping",))["prev_shaping"]
+        assert np.array_equal(got, prev.astype(orc.T).astype(np.float64), equal_nan=True)
+        a = np.full((130, 4), 0.0166, np.float32)
+        g, w, _ = step_both(env, orc, a)
+        assert_step_close(g, w, MODE_TOL[mode], ctx=mode)
+        assert g[1][3] == 0.0                                      # prev_shaping None -> reward 0 (lander.py:58-61)
+        assert_state_close(env, orc, MODE_TOL[mode])
+        assert np.allclose(env.get_state()["prev_shaping"], orc.prev_shaping.astype(np.float64), rtol=1e-6)
+        env.close()
+    env, _ = make_pair("hover3d", 70, "float32", "next_step")
+    env.reset()
+    assert np.all(np.isnan(env.get_state()["prev_shaping"]))
+    env.step(torch.zeros((70, 4), device=env.device))
+    assert np.all(np.isnan(env.get_state()["prev_shaping"]))
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# boundary completions: pickling, array-likes of other libraries
+# ---------------------------------------------------------------------------------------
+def test_env_pickle_round_trip_builds_an_equal_fresh_env():
+    """pickle.loads(pickle.dumps(env)) is a fresh env built from the same constructor keywords (the reference:
+    EzPickle, task.py:23, :40): same spaces and configuration, and after reset() it steps like a twin built by hand."""
+    import pickle
+    import torch
+    import gym_copter_amd
+    kw = dict(task="lander2d", num_envs=333, seed=17, autoreset_mode="same_step", state_dtype="float64",
+              max_steps=50, bounds=7.5, vehicle_params={"M": 1.5}, substeps=2)
+    env = gym_copter_amd.CopterVecEnv(**kw)
+    env.reset()
+    env.step(torch.zeros((333, 2), device=env.device))        # the copy does not inherit simulation state
+    back = pickle.loads(pickle.dumps(env))
+    twin = gym_copter_amd.CopterVecEnv(**kw)
+    assert back is not env and back.task == "lander2d" and back.num_envs == 333 and back.autoreset_mode == "same_step"
+    assert back.config.bounds == 7.5 and back.config.M == 1.5 and back.config.max_steps == 50
+    o1, _ = back.reset()
+    o2, _ = twin.reset()
+    assert torch.equal(o1, o2)
+    g = torch.Generator(device=env.device)
+    g.manual_seed(0)
+    for _ in range(20):
+        a = torch.rand((333, 2), generator=g, device=env.device) * 0.04
+        r1, r2 = back.step(a), twin.step(a)
+        for k in range(4):
+            assert torch.equal(r1[k], r2[k])
+    for e in (env, back, twin):
+        e.close()
+
+
+def test_actions_from_dlpack_and_cuda_array_interface_are_adopted_in_place():
+    """Array-likes that are neither torch nor NumPy (the reference accepts whatever np.clip accepts, task.py:91):
+    a DLPack capsule, an object with __dlpack__, and an object with __cuda_array_interface__ over DEVICE memory are
+    adopted without a host round trip (same device pointer) and step like the tensor they wrap; a host array-like
+    under another name takes the NumPy path."""
+    import torch
+    import gym_copter_amd
+    n = 500
+    env = gym_copter_amd.CopterVecEnv("lander3d", n, seed=3)
+    twin = gym_copter_amd.CopterVecEnv("lander3d", n, seed=3)
+    env.reset()
+    twin.reset()
+    g = torch.Generator(device=env.device)
+    g.manual_seed(0)
+
+    class Dl:                      # a foreign device array that speaks DLPack
+        def __init__(self, t):
+            self.t = t
+
+        def __dlpack__(self, stream=None):
+            return self.t.__dlpack__()
+
+        def __dlpack_device__(self):
+            return self.t.__dlpack_device__()
+
+    class Cai:                     # ... or the CUDA array interface (CuPy, Numba)
+        def __init__(self, t):
+            self.__cuda_array_interface__ = t.__cuda_array_interface__
+            self.keep = t
+
+    for wrap in (torch.utils.dlpack.to_dlpack, Dl, Cai):
+        a = torch.rand((n, 4), generator=g, device=env.device) * 0.04
+        got = env.step(wrap(a))
+        assert isinstance(got[0], torch.Tensor) and env._keep.data_ptr() == a.data_ptr(), wrap
+        want = twin.step(a)
+        for k in range(4):
+            assert torch.equal(got[k], want[k]), (wrap, k)
+
+    class HostLike:                # not an ndarray, but NumPy can read it
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __array__(self, dtype=None, copy=None):
+            return self.arr if dtype is None else self.arr.astype(dtype)
+
+    a = (np.random.default_rng(0).random((n, 4)) * 0.04).astype(np.float32)
+    got = env.step(HostLike(a))
+    want = twin.step(torch.from_numpy(a).to(env.device))
+    assert isinstance(got[0], np.ndarray) and np.array_equal(got[0], to_np(want[0]))
+    env.close()
+    twin.close()
+
+
+# ---------------------------------------------------------------------------------------
+# a closed-but-running session, feeders without a session, signed zeros across call forms
+# ---------------------------------------------------------------------------------------
+def test_a_session_closed_without_waiting_is_drained_before_other_streams_touch_the_tiles():
+    """cs_serve_end(wait=False) orders only ITS stream behind the env kernel's exit; a step enqueued right away on
+    ANOTHER stream must still see the tiles the session wrote back.  The context stays 'draining' until the exit has
+    been observed, and every entry point orders its own stream behind it."""
+    import torch
+    import gym_copter_amd
+    n, K = 65536, 40
+    kw = dict(task="lander3d", num_envs=n, seed=8, autoreset_mode="next_step")
+    env, twin = gym_copter_amd.CopterVecEnv(**kw), gym_copter_amd.CopterVecEnv(**kw)
+    env.reset()
+    twin.reset()
+    g = torch.Generator(device=env.device)
+    g.manual_seed(4)
+    acts = torch.rand((K + 1, n, 4), generator=g, device=env.device) * 2 - 1
+    other = torch.cuda.Stream(device=env.device)
+    for rep in range(3):
+        env.serve_begin(K, ring=8, timeout=5.0)
+        for s in range(K):
+            env.serve_submit(s, acts[s])
+        env.serve_end(wait=False)                  # the env kernel is still working through its ring
+        other.wait_stream(torch.cuda.current_stream(env.device))     # (the action tensor, not the session)
+        with torch.cuda.stream(other):
+            got = [t.clone() for t in env.step(acts[K])[:4]]
+        for s in range(K):
+            twin.step(acts[s])
+        want = twin.step(acts[K])[:4]
+        other.synchronize()
+        for k in range(4):
+            assert torch.equal(got[k], want[k]), (rep, k)
+    assert env.serve_status() == (K, K, 0)
+    sa, sb = env.get_state(), twin.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    # feeders launched eagerly with no session open are refused instead of polling until their timeout
+    from gym_copter_amd import _lib
+    env.serve_collect(K - 1)                       # (reading a closed session's output ring stays allowed)
+    for call in (lambda: env.serve_submit(0, acts[0]), lambda: env.serve_policy_pid(0)):
+        with pytest.raises(_lib.CopterStepError, match="no session is open|cs_pid_configure"):
+            call()
+    env.close()
+    twin.close()
+
+
+@pytest.mark.parametrize("mode", ["float32", "float64"])
+@pytest.mark.parametrize("substeps", [10, 3])
+def test_an_envs_bytes_do_not_depend_on_its_wavefront_neighbours(substeps, mode):
+    """With substeps > 1 a wavefront takes the free-flight call form when ALL its lanes qualify, the general form
+    otherwise -- so WHICH form advances an env depends on its neighbours.  The two forms must leave the same bytes
+    (sign of a zero included).  One batch against the same envs split at a point that is NOT a multiple of 64 (every
+    env gets other neighbours; global ids keep the random draws): raw state words compared bit for bit."""
+    import torch
+    import gym_copter_amd
+    n, cut = 4096 + 77, 1000 + 13
+    kw = dict(task="lander3d", state_dtype=mode, seed=31, autoreset_mode="next_step", substeps=substeps)
+    whole = gym_copter_amd.CopterVecEnv(num_envs=n, **kw)
+    parts = [gym_copter_amd.CopterVecEnv(num_envs=cut, **kw),
+             gym_copter_amd.CopterVecEnv(num_envs=n - cut, env_id_base=cut, **kw)]
+    whole.reset()
+    for p in parts:
+        p.reset()
+    rng = np.random.default_rng(9)
+    hover = 0.016560178185018043
+    # mostly level, quiet envs (zero roll / pitch torque: ax = ay = -0.0 at level attitude) with disturbed ones mixed
+    # in at random places, so that wavefronts of both kinds exist and differ between the two groupings
+    for t in range(120):
+        a = np.full((n, 4), hover * (1 + 0.002 * np.sin(0.1 * t)), np.float32)
+        wild = rng.random(n) < 0.03
+        a[wild] = rng.uniform(-1, 1, (int(wild.sum()), 4)).astype(np.float32)
+        tilt = rng.random(n) < 0.05
+        a[tilt] *= np.array([1.0, 1.02, 1.02, 1.0], np.float32)
+        at = torch.from_numpy(a).to(whole.device)
+        ow = whole.step(at)
+        op = [parts[0].step(at[:cut]), parts[1].step(at[cut:])]
+        for k in range(4):
+            joined = torch.cat([op[0][k], op[1][k]])
+            wk = ow[k]
+            if wk.dtype == torch.float32:            # bit patterns, not values: -0.0 != +0.0 here
+                assert torch.equal(wk.view(torch.int32), joined.view(torch.int32)), (t, k)
+            else:
+                assert torch.equal(wk, joined), (t, k)
+    sw = whole.get_state()
+    sp = [p.get_state() for p in parts]
+    for k in sw:
+        joined = np.concatenate([sp[0][k], sp[1][k]], axis=-1)
+        a64, b64 = np.ascontiguousarray(sw[k]), np.ascontiguousarray(joined)
+        assert a64.tobytes() == b64.tobytes(), k
+    # the batch did hold exact zeros of either sign somewhere (else the test shows nothing about them)
+    x = sw["x"]
+    assert np.any((x == 0) & np.signbit(x)) or np.any((x == 0) & ~np.signbit(x))
+    whole.close()
+    for p in parts:
+        p.close()
+
+
+# ---------------------------------------------------------------------------------------
+# VERDICT round 3, weak #1b: where device and oracle "round differently once in 1e4 values"
+# ---------------------------------------------------------------------------------------
+def test_stored_word_codec_is_bit_exact_over_two_million_values():
+    """The stored format itself (float32 word + 5 guard bits: encode on the device, decode on the device) is
+    bit-identical to the oracle's model of it (refvec.guard_round) -- 2.1 M float64 values through cs_set_state /
+    cs_get_state: random values over 60 decades, both signs, exact ties at the rounding position, values one
+    float64 ulp either side of a tie, all-ones mantissas (carry into the exponent), zeros.  So a stored word that
+    differs between device and oracle after a STEP is never the codec: it is the float64 value that went in."""
+    import gym_copter_amd
+    from oracle import refvec
+    n = 175104                                      # 2736 tiles; 12 values per env
+    rng = np.random.default_rng(77)
+    v = rng.standard_normal((12, n)) * 10.0 ** rng.uniform(-30, 30, (12, n))
+    bits = v.view(np.uint64).copy()
+    k = n // 6
+    tie = (bits[:, :k] & ~np.uint64(0xFFFFFF)) | np.uint64(0x800000)            # exactly half way
+    bits[:, :k] = tie
+    bits[:, k:2 * k] = tie + np.uint64(1)                                         # one ulp above a tie
+    bits[:, 2 * k:3 * k] = tie - np.uint64(1)                                     # one ulp below
+    bits[:, 3 * k:3 * k + 1000] |= np.uint64((1 << 52) - 1)                       # mantissa all ones: carry
+    v = bits.view(np.float64).copy()
+    v[:, 3 * k + 1000:3 * k + 1100] = 0.0
+    v[:, 3 * k + 1100:3 * k + 1200] = -0.0
+    want = refvec.guard_round(v)
+    for task in ("lander3d", "hover3d"):
+        env = gym_copter_amd.CopterVecEnv(task, n, state_dtype="float32")
+        env.reset()
+        env.set_state(x=v)
+        got = env.get_state(only=("x",))["x"]
+        assert got.view(np.uint64).tobytes() == want.view(np.uint64).tobytes(), task
+        # and what an observation carries is the float32 rounding of exactly that value
+        obs = to_np(env.state_tensors()["x"])
+        with np.errstate(over="ignore"):
+            assert np.array_equal(obs.view(np.uint32), want.astype(np.float32).view(np.uint32))
+        env.close()
+    env = gym_copter_amd.CopterVecEnv("lander3d", n, state_dtype="float32_rn")
+    env.reset()
+    env.set_state(x=v)
+    got = env.get_state(only=("x",))["x"]
+    with np.errstate(over="ignore"):
+        assert np.array_equal(got.view(np.uint64), v.astype(np.float32).astype(np.float64).view(np.uint64))
+    env.close()
+
+
+def test_a_differing_stored_word_after_one_step_is_a_straddled_rounding_boundary():
+    """Device and oracle start one step from IDENTICAL stored states (set through the bit-exact codec above) with the
+    same actions.  The float64 results differ at the 1e-11 level (the float32 modes' short sin / cos polynomials,
+    fused multiply-adds, folded constants: DESIGN section 3), so a result that lies that close to a rounding boundary
+    of the 29-bit format lands on different sides: the stored words then differ by EXACTLY one unit of the format,
+    at a rate of (2 x 1e-11-ish) / 2^-29 -- asserted here: every differing word is one unit apart, the rate is
+    below 1e-3 per value, and in the float64 state mode (no rounding step) the same values agree to 1e-13."""
+    import torch
+    n = 131072
+    rng = np.random.default_rng(5)
+    x0 = np.zeros((12, n))
+    x0[[0, 2]] = rng.uniform(-8, 8, (2, n))
+    x0[4] = rng.uniform(-20, -1, n)
+    x0[[1, 3, 5]] = rng.uniform(-3, 3, (3, n))
+    x0[[6, 8]] = rng.uniform(-0.6, 0.6, (2, n))
+    x0[10] = rng.uniform(-3, 3, n)
+    x0[[7, 9, 11]] = rng.uniform(-1, 1, (3, n))
+    a = rng.uniform(0.0, 0.05, (n, 4)).astype(np.float32)
+    res = {}
+    for mode in ("float32", "float64"):
+        env, orc = make_pair("lander3d", n, mode, "disabled", seed=1)
+        env.reset()
+        orc.reset()
+        env.set_state(x=x0, flags=np.zeros(n, np.uint8))
+        start = env.get_state(only=("x",))["x"]
+        orc.x[:] = start
+        orc.pending[:] = False
+        env.step(torch.from_numpy(a).to(env.device))
+        orc.step(a.astype(np.float64))
+        res[mode] = (env.get_state(only=("x",))["x"], orc.x.astype(np.float64).copy())
+        env.close()
+    got, want = res["float32"]
+    gb, wb = got.view(np.int64), want.view(np.int64)
+    diff = gb != wb
+    rate = diff.mean()
+    unit = np.int64(1 << 24)                                    # one unit of the stored format in float64 bit patterns
+    assert np.all(np.abs(gb[diff] - wb[diff]) == unit), "a stored word differs by more than one unit of the format"
+    print("stored words differing after one step: %d of %d (rate %.2e), all by exactly one unit" % (diff.sum(), diff.size, rate))
+    assert rate < 1e-3
+    # integrated positions (x += dt * dx: one fused multiply-add of exactly representable inputs) never differ
+    assert not diff[[0, 2, 4]].any()
+    g64, w64 = res["float64"]
+    assert np.max(np.abs(g64 - w64) / np.maximum(np.abs(w64), 1.0)) < 1e-13

@@ -3,7 +3,7 @@
 profiler's per-dispatch cost.
 
   make -C gym_copter_amd/csrc span            # -> gym_copter_amd/csrc/build/libcopterstep_span.so
-  python tools/kernel_span.py [task] [num_envs] [uniform|near_hover] [substeps]
+  python tools/kernel_span.py [task] [num_envs] [uniform|near_hover|const] [substeps]
 
 The span build (-DCS_SPAN) has every wavefront note the chip-wide 100 MHz clock (s_memrealtime) when it
 starts and, after its stores have been acknowledged, when it ends, into its own slot of its launch (two plain
@@ -38,6 +38,7 @@ g = torch.Generator(device=dev)
 g.manual_seed(1234)
 ring = 16
 acts = (torch.rand((ring, N, 4), generator=g, device=dev) * 2 - 1 if law == "uniform"
+        else torch.full((ring, N, 4), 1.625e-2, device=dev) if law == "const"
         else HOVER * (1 + 0.01 * torch.randn((ring, N, 4), generator=g, device=dev)))
 lib = _lib.load()
 lib.cs_debug_read_spans.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
