@@ -789,7 +789,10 @@ def main(argv=None):
             return g, mode
         modes = {}
         if "obs" in gather_legs:
-            g2, modes["obs"] = gather_leg(lambda: gather("obs", env._obs))
+            # observation rows only: a contiguous [n, obs_dim] buffer of their own (the default outputs are packed rows)
+            sep = (torch.empty((n, env.obs_dim), device=device), torch.empty(n, device=device),
+                   torch.empty(n, dtype=torch.uint8, device=device), torch.empty(n, dtype=torch.uint8, device=device))
+            g2, modes["obs"] = gather_leg(lambda: gather("obs", sep[0]), bind=lambda: env.bind_outputs(*sep))
             extra["value_with_allgather"] = total_envs / g2["s_per_step"]
             extra["ms_per_step_with_allgather"] = g2["s_per_step"] * 1e3
         # everything a global learner needs (obs, reward, both flags) in ONE all-gather: the kernel

@@ -253,6 +253,17 @@ bool capturing(hipStream_t s) {
   return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
 
+// "Packed rows" (include/copterstep.h, cs_step_io) are written by cs_step / cs_step_ex / cs_step_prefetch only: the
+// same pointer pattern handed to an entry point whose kernel writes plain arrays would make those arrays overlap.
+int refuse_packed_rows(const cs_ctx* ctx, const char* who, const float* obs, const float* reward, const uint8_t* term,
+                       const uint8_t* trunc) {
+  const int od = cs::task_obs_dim(ctx->cfg.task);
+  if (obs != nullptr && reward == obs + od && term == reinterpret_cast<const uint8_t*>(obs + od + 1) && trunc == term + 1)
+    return fail(CS_ERR_ARG, std::string(who) + ": the outputs are the columns of one packed [N, obs_dim + 2] array; that "
+                                               "form is written by cs_step / cs_step_ex only -- pass separate arrays here");
+  return CS_OK;
+}
+
 // While a served session is open the env state lives in the registers of its persistent kernel (which writes the
 // tiles back when it exits): everything else that reads or writes the tiles has to wait for cs_serve_end.
 // A session closed WITHOUT waiting (cs_serve_end(steps_done = NULL)) may still be running, and cs_serve_end ordered
@@ -600,6 +611,7 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
   if (int rc_ = check_idle(ctx, "cs_step_many", stream, true)) return rc_;
   if (actions_dev == nullptr) return fail(CS_ERR_ARG, "cs_step_many: actions_dev is required");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_step_many: num_steps must be >= 1");
+  if (int rc_ = refuse_packed_rows(ctx, "cs_step_many", obs_dev, reward_dev, terminated_dev, truncated_dev)) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       const_cast<float*>(actions_dev), obs_dev, reward_dev,
@@ -778,6 +790,7 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_rollout_pid: the heuristic flies the 3D tasks only");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_pid: num_steps must be >= 1");
+  if (int rc_ = refuse_packed_rows(ctx, "cs_rollout_pid", obs_dev, reward_dev, terminated_dev, truncated_dev)) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,
@@ -792,6 +805,7 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
                       void* stream) {
   if (int rc_ = check_idle(ctx, "cs_rollout_random", stream, true)) return rc_;
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_random: num_steps must be >= 1");
+  if (int rc_ = refuse_packed_rows(ctx, "cs_rollout_random", obs_dev, reward_dev, terminated_dev, truncated_dev)) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,
@@ -963,13 +977,13 @@ int cs_serve_begin(cs_ctx* ctx, int32_t num_steps, int32_t ring, double timeout_
 int cs_serve_submit(cs_ctx* ctx, int32_t step, const float* actions_dev, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_submit: no session has been opened yet");
+  if (actions_dev == nullptr || step < 0 || (uint32_t)step >= ctx->serve.num_steps)
+    return fail(CS_ERR_ARG, "cs_serve_submit: actions_dev is required and step must be in [0, num_steps)");
   // a feeder launched eagerly with no session open would poll for its whole timeout; captured into a graph (to be
   // replayed against later sessions) it is fine
   if (!ctx->serve_active && !capturing((hipStream_t)stream))
-    return fail(CS_ERR_ARG, "cs_serve_submit: no session is open (cs_serve_begin first; only a stream capture may record "
-                            "feeders without one)");
-  if (actions_dev == nullptr || step < 0 || (uint32_t)step >= ctx->serve.num_steps)
-    return fail(CS_ERR_ARG, "cs_serve_submit: actions_dev is required and step must be in [0, num_steps)");
+    return fail(CS_ERR_ARG, "cs_serve_submit: no session is open (cs_serve_begin first; only a stream capture may "
+                            "record feeders without one)");
   hipError_t e = cs::launch_serve_submit(ctx->serve, (uint32_t)step, actions_dev, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_serve_submit: kernel launch");
   return CS_OK;
@@ -983,6 +997,7 @@ int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_de
   // step it never reached is waited for until the timeout, as during a session)
   if (step < -1 || step >= (int32_t)ctx->serve.num_steps)
     return fail(CS_ERR_ARG, "cs_serve_collect: step must be in [-1, num_steps)");
+  if (int rc_ = refuse_packed_rows(ctx, "cs_serve_collect", obs_dev, reward_dev, terminated_dev, truncated_dev)) return rc_;
   hipError_t e = cs::launch_serve_collect(ctx->serve, step, obs_dev, reward_dev, terminated_dev, truncated_dev,
                                           (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_serve_collect: kernel launch");
@@ -992,16 +1007,14 @@ int cs_serve_collect(cs_ctx* ctx, int32_t step, float* obs_dev, float* reward_de
 int cs_serve_policy_pid_many(cs_ctx* ctx, int32_t first_step, int32_t num_steps, void* stream) {
   if (check_ctx(ctx)) return CS_ERR_ARG;
   if (ctx->serve.num_steps == 0) return fail(CS_ERR_ARG, "cs_serve_policy_pid: no session has been opened yet");
-  // a feeder launched eagerly with no session open would poll for its whole timeout; captured into a graph (to be
-  // replayed against later sessions) it is fine
-  if (!ctx->serve_active && !capturing((hipStream_t)stream))
-    return fail(CS_ERR_ARG, "cs_serve_policy_pid: no session is open (cs_serve_begin first; only a stream capture may record "
-                            "feeders without one)");
   if (!ctx->pid_on) return fail(CS_ERR_ARG, "cs_serve_policy_pid: call cs_pid_configure first");
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_serve_policy_pid: the heuristic flies the 3D tasks only");
   if (first_step < 0 || num_steps < 1 || (int64_t)first_step + num_steps > (int64_t)ctx->serve.num_steps)
     return fail(CS_ERR_ARG, "cs_serve_policy_pid: steps must lie in [0, num_steps)");
+  if (!ctx->serve_active && !capturing((hipStream_t)stream))  // (as cs_serve_submit)
+    return fail(CS_ERR_ARG, "cs_serve_policy_pid: no session is open (cs_serve_begin first; only a stream capture may "
+                            "record feeders without one)");
   hipError_t e = cs::launch_serve_pid(ctx->serve, (uint32_t)first_step, (uint32_t)num_steps, ctx->pid, ctx->pid_state,
                                       ctx->pid_stride, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(e, "cs_serve_policy_pid: kernel launch");

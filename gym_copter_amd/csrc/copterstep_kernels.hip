@@ -76,7 +76,7 @@ __device__ __forceinline__ void step_body(
   o.act_f32 = !LEAN && c.act_f32;
   o.ticks = !LEAN && c.ticks;
   constexpr int OBS = task_obs_dim(TASK);
-  __shared__ __attribute__((aligned(16))) float lds[kBlock * OBS];
+  __shared__ __attribute__((aligned(16))) float lds[kBlock * (OBS + 2)];  // (+ 2: packed rows, dev_task.h)
 
   const int lane = threadIdx.x;
   const uint32_t tile_index = blockIdx.x;
@@ -125,11 +125,20 @@ __device__ __forceinline__ void step_body(
   store_env<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
-  if (valid) {
-    if (io.reward_dev) CS_NT_STORE((float)out.reward, at32<float>(io.reward_dev, i << 2));
-    write_flags(io.terminated_dev, io.truncated_dev, 0, i, out.term, out.trunc);
+  if (outputs_are_packed_rows<OBS>(io.obs_dev, io.reward_dev, io.terminated_dev, io.truncated_dev)) {  // uniform
+    float row2[OBS + 2];
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) row2[k] = out.row[k];
+    row2[OBS] = (float)out.reward;
+    row2[OBS + 1] = __uint_as_float((out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u));  // bytes 0 / 1 = the two flags
+    write_rows<OBS + 2>(io.obs_dev, lds, lane, env0, n, valid, row2);
+  } else {
+    if (valid) {
+      if (io.reward_dev) CS_NT_STORE((float)out.reward, at32<float>(io.reward_dev, i << 2));
+      write_flags(io.terminated_dev, io.truncated_dev, 0, i, out.term, out.trunc);
+    }
+    write_rows<OBS>(io.obs_dev, lds, lane, env0, n, valid, out.row);
   }
-  write_rows<OBS>(io.obs_dev, lds, lane, env0, n, valid, out.row);
   CS_STAMP(6);
 #ifdef CS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

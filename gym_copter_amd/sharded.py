@@ -11,8 +11,8 @@ gym_copter/envs/task.py:161 builds one Dynamics per env), so the batch shards tr
   * stepping needs no communication at all.  The only exchange is the optional
     concatenated return: gather="obs" ships the observation rows, gather="all" ships
     observations, rewards and both flags in ONE all-gather per step -- the step kernel writes
-    its outputs straight into one packed per-rank buffer (PackedOutputs), so nothing is copied
-    before the collective.  It is issued on the current stream right behind the step kernel.
+    every env's outputs as one row of a packed per-rank array (PackedOutputs: the "packed rows" of
+    include/copterstep.h), so nothing is copied before the collective, nor after it.  It is issued on the current stream right behind the step kernel.
     A caller whose policy is replicated per GPU should leave gather off.
 """
 import os
@@ -60,36 +60,30 @@ class ShardGather:
         return out
 
 
+def row_views(rows, obs_dim):
+    """(obs, reward, terminated u8, truncated u8) as views of packed rows [..., obs_dim + 2] float32: row =
+    {observation, reward, flags word (byte 0 terminated, byte 1 truncated)} -- include/copterstep.h, "packed rows"."""
+    import torch
+    b = rows.view(torch.uint8)                     # [..., 4 * (obs_dim + 2)]
+    f = 4 * (obs_dim + 1)
+    return rows[..., :obs_dim], rows[..., obs_dim], b[..., f], b[..., f + 1]
+
+
 class PackedOutputs:
-    """One byte buffer per rank holding [obs f32 | reward f32 | flags u8 [n,2] = (terminated, truncated) per env]
-    (each section 16-byte aligned), and its all-gathered counterpart [world, bytes].  The local
-    sections are the tensors the step kernel writes; the global ones are strided views of the
-    gathered buffer, so one collective moves everything."""
+    """One [n_local, obs_dim + 2] float32 array per rank -- the step kernel's "packed rows": every env's observation,
+    reward and flags as ONE row -- and its all-gathered counterpart [world, n_local, obs_dim + 2].  The local columns
+    are the tensors the step kernel writes (zero-copy: bind_outputs); the gathered rows are in global env-id order
+    (rank-major) and contiguous, so one collective moves everything and the flat [N, ...] return needs no copy
+    either."""
 
     def __init__(self, n_local, obs_dim, world_size, device, group=None, force_collective=None):
         import torch
         self.n, self.od, self.world, self.group = n_local, obs_dim, world_size, group
         self.force = _force_collective(force_collective)
-        up = lambda b: (b + 15) // 16 * 16
-        self.off_obs = 0
-        self.off_rew = up(n_local * obs_dim * 4)
-        self.off_flags = self.off_rew + up(n_local * 4)
-        self.nbytes = self.off_flags + up(2 * n_local)
-        self.local = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
-        self.gathered = torch.zeros((world_size, self.nbytes), dtype=torch.uint8, device=device)
-        self.obs, self.reward, self.term, self.trunc = self._sections(self.local.view(1, -1), 1)
-        self.obs, self.reward = self.obs[0], self.reward[0]
-        self.term, self.trunc = self.term[0], self.trunc[0]
-
-    def _sections(self, buf2d, rows):
-        import torch
-        n, od = self.n, self.od
-        obs = buf2d[:, self.off_obs:self.off_obs + n * od * 4].view(torch.float32).view(rows, n, od)
-        rew = buf2d[:, self.off_rew:self.off_rew + n * 4].view(torch.float32)
-        # terminated / truncated: the columns of the flags section (the step kernel writes each env's pair with
-        # one 2-byte store, include/copterstep.h "interleaved flags")
-        flags = buf2d[:, self.off_flags:self.off_flags + 2 * n].view(rows, n, 2)
-        return obs, rew, flags[:, :, 0], flags[:, :, 1]
+        self.nbytes = n_local * (obs_dim + 2) * 4
+        self.local = torch.zeros((n_local, obs_dim + 2), dtype=torch.float32, device=device)
+        self.gathered = torch.zeros((world_size, n_local, obs_dim + 2), dtype=torch.float32, device=device)
+        self.obs, self.reward, self.term, self.trunc = row_views(self.local, obs_dim)
 
     def all_gather(self):
         """-> (obs [world, n, od], reward [world, n], terminated [world, n] u8, truncated u8):
@@ -98,8 +92,13 @@ class PackedOutputs:
         if self.world == 1 and not (self.force and dist.is_initialized()):
             self.gathered[0].copy_(self.local)
         else:
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.local, group=self.group)
-        return self._sections(self.gathered, self.world)
+            dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
+        return row_views(self.gathered, self.od)
+
+    def all_gather_flat(self):
+        """The same as [N, ...] rows in global env-id order: views as well (the gathered rows are contiguous)."""
+        self.all_gather()
+        return row_views(self.gathered.view(self.world * self.n, self.od + 2), self.od)
 
 
 class ShardedCopterVecEnv:
@@ -126,9 +125,8 @@ class ShardedCopterVecEnv:
         self.local = vecenv.CopterVecEnv(task=task, num_envs=self.n_local, device=device,
                                          env_id_base=self.env_id_base, **env_kwargs)
         self.gather = gather
-        # gather="all": flat=True returns [N, ...] rows (one device copy per step when world > 1: the
-        # sections of the packed per-rank chunks are not adjacent); flat=False returns the zero-copy
-        # [world, n_local, ...] views of the gathered buffer, rank-major = global env-id order
+        # gather="all": flat=True returns [N, ...] rows, flat=False [world, n_local, ...]; both are views of the
+        # gathered packed rows (rank-major = global env-id order), no copy after the collective
         self.flat = bool(flat)
         self._gather = ShardGather(self.n_local, self.world, group, force_collective)
         self._packed = None
@@ -167,19 +165,17 @@ class ShardedCopterVecEnv:
             obs = self._gather("obs", obs)
         elif self.gather == "all":
             import torch
-            pk, N = self._packed, self.total_envs
+            pk = self._packed
             if obs.data_ptr() != pk.obs.data_ptr():     # a local env that owns its outputs: pack them
                 pk.obs.copy_(obs)
                 pk.reward.copy_(reward)
                 pk.term.copy_(term.view(torch.uint8))
                 pk.trunc.copy_(trunc.view(torch.uint8))
-            g_obs, g_rew, g_term, g_trunc = pk.all_gather()       # ONE collective
-            if self.flat:    # [world, n_local, ...] views -> [N, ...] rows in global env-id order
-                obs, reward = g_obs.reshape(N, self.obs_dim), g_rew.reshape(N)
-                term, trunc = g_term.reshape(N).view(torch.bool), g_trunc.reshape(N).view(torch.bool)
-            else:
-                obs, reward = g_obs, g_rew
-                term, trunc = g_term.view(torch.bool), g_trunc.view(torch.bool)
+            if self.flat:    # [N, ...] rows in global env-id order: views of the gathered rows, no copy
+                obs, reward, g_term, g_trunc = pk.all_gather_flat()              # ONE collective
+            else:            # the [world, n_local, ...] views
+                obs, reward, g_term, g_trunc = pk.all_gather()
+            term, trunc = g_term.view(torch.bool), g_trunc.view(torch.bool)
         return obs, reward, term, trunc, infos
 
     def close(self):

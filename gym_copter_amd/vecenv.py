@@ -155,42 +155,49 @@ class CopterVecEnv:
         assert (od.value, ad.value) == (self.obs_dim, self.action_dim), "library / binding disagree on shapes"
         n = self.num_envs
         with torch.cuda.device(self.device):
-            # the default outputs are sections of ONE byte buffer [obs f32 | reward f32 | flags u8 [n,2]] (each
-            # 16-byte aligned): the NumPy convenience path ships them to the host as one copy.  terminated /
-            # truncated are the two COLUMNS of the flags section ("interleaved flags", include/copterstep.h): the
-            # kernel then writes both with one 2-byte store per env
-            up = lambda b: (b + 15) // 16 * 16
-            o_r = up(n * self.obs_dim * 4)
-            o_f = o_r + up(n * 4)
-            self._packbuf = torch.empty(o_f + up(2 * n), dtype=torch.uint8, device=self.device)
-            self._pack_off = (o_r, o_f)
-            self._obs = self._packbuf[:n * self.obs_dim * 4].view(torch.float32).view(n, self.obs_dim)
-            self._reward = self._packbuf[o_r:o_r + n * 4].view(torch.float32)
-            flags = self._packbuf[o_f:o_f + 2 * n].view(n, 2)
-            self._term, self._trunc = flags[:, 0], flags[:, 1]
+            # the default outputs are the columns of ONE [n, obs_dim + 2] float32 array -- "packed rows"
+            # (include/copterstep.h, cs_step_io): row i = {observation, reward, flags word}.  The step kernel writes whole
+            # rows (one output stream instead of three), the NumPy convenience path ships the array to the host as one
+            # copy, and what step() returns are views of it: obs [n, obs_dim] (row stride obs_dim + 2), reward [n],
+            # terminated / truncated [n] bytes of the flags word
+            from .sharded import row_views
+            self._rows = torch.zeros((n, self.obs_dim + 2), dtype=torch.float32, device=self.device)
+            self._obs, self._reward, self._term, self._trunc = row_views(self._rows, self.obs_dim)
+            self._obs_plain = None          # contiguous [n, obs_dim] scratch for entry points that write plain rows
+            self._serve_out = None
             self._final_obs = None
             self._done = None
         self._cache_outputs()
 
     def bind_outputs(self, obs, reward, terminated, truncated):
         """Make step()/reset() write into caller-provided device tensors (same shapes and dtypes
-        as the defaults; truncated/terminated as uint8, each contiguous or together the columns of one
-        [N,2] tensor) -- e.g. slices of one packed buffer that a single collective then ships
-        (gym_copter_amd.sharded)."""
+        as the defaults; truncated/terminated as uint8): four contiguous arrays, or the flags as the columns of
+        one [N,2] tensor, or all four as the columns of one [N, obs_dim + 2] float32 array (packed rows, e.g.
+        gym_copter_amd.sharded.PackedOutputs: what a single collective then ships)."""
         torch = _torch()
-        n = self.num_envs
-        for t, shape, dt in ((obs, (n, self.obs_dim), torch.float32), (reward, (n,), torch.float32)):
-            if tuple(t.shape) != shape or t.dtype != dt or t.device != self.device or not t.is_contiguous():
-                raise ValueError("bind_outputs: need contiguous %s %s on %s" % (dt, shape, self.device))
-        # the flags: two contiguous [n] uint8 tensors, or the two columns of one [n,2] uint8 tensor (interleaved
-        # flags: one 2-byte store per env in the kernel)
-        interleaved = (terminated.stride() == (2,) and truncated.stride() == (2,)
-                       and truncated.data_ptr() == terminated.data_ptr() + 1) if n > 1 else False
-        for t in (terminated, truncated):
-            if (tuple(t.shape) != (n,) or t.dtype != torch.uint8 or t.device != self.device
-                    or not (interleaved or t.is_contiguous())):
-                raise ValueError("bind_outputs: terminated / truncated must be contiguous uint8 (%d,) tensors on %s, "
-                                 "or the two columns of one (%d, 2) uint8 tensor" % (n, self.device, n))
+        n, od = self.num_envs, self.obs_dim
+        for t, shape, dt in ((obs, (n, od), torch.float32), (reward, (n,), torch.float32),
+                             (terminated, (n,), torch.uint8), (truncated, (n,), torch.uint8)):
+            if tuple(t.shape) != shape or t.dtype != dt or t.device != self.device:
+                raise ValueError("bind_outputs: need %s %s on %s" % (dt, shape, self.device))
+        # three accepted forms (include/copterstep.h, cs_step_io): (a) four contiguous arrays; (b) the flags as the two
+        # columns of one [n,2] uint8 array, the rest contiguous; (c) all four the columns of ONE [n, obs_dim + 2]
+        # float32 array (packed rows)
+        base = obs.data_ptr()
+        packed = (n > 1 and obs.stride() == (od + 2, 1) and reward.stride() == (od + 2,)
+                  and reward.data_ptr() == base + 4 * od and terminated.stride() == (4 * (od + 2),)
+                  and terminated.data_ptr() == base + 4 * (od + 1) and truncated.stride() == (4 * (od + 2),)
+                  and truncated.data_ptr() == terminated.data_ptr() + 1)
+        interleaved = (n > 1 and terminated.stride() == (2,) and truncated.stride() == (2,)
+                       and truncated.data_ptr() == terminated.data_ptr() + 1)
+        if not packed:
+            if not (obs.is_contiguous() and reward.is_contiguous()):
+                raise ValueError("bind_outputs: obs and reward must be contiguous (or all four outputs the columns of one "
+                                 "(%d, %d) float32 array)" % (n, od + 2))
+            if not (interleaved or (terminated.is_contiguous() and truncated.is_contiguous())):
+                raise ValueError("bind_outputs: terminated / truncated must be contiguous uint8 (%d,) tensors, or the two "
+                                 "columns of one (%d, 2) uint8 tensor" % (n, n))
+        self._rows = None                    # (the default packed array is no longer what step() writes)
         self._obs, self._reward, self._term, self._trunc = obs, reward, terminated, truncated
         self._cache_outputs()
 
@@ -333,13 +340,22 @@ class CopterVecEnv:
                 if pose.shape == (5,):
                     pose = np.repeat(pose[:, None], self.num_envs, axis=1)
             pose_t, _ = self._dev_f32(pose, (5, self.num_envs), "pose")
+        # cs_reset writes plain [N, obs_dim] rows: straight into the observation buffer when that is contiguous, else
+        # (packed rows) into a scratch buffer that is then copied into the observation columns (resets are rare)
+        plain = self._obs
+        if not plain.is_contiguous():
+            if self._obs_plain is None:
+                self._obs_plain = torch.empty((self.num_envs, self.obs_dim), dtype=torch.float32, device=self.device)
+            plain = self._obs_plain
         with torch.cuda.device(self.device):
             if pose_t is None:
                 _lib.check(self._lib.cs_reset(self._ctx, mask_p, force_p,
-                                              C.c_void_p(self._obs.data_ptr()), self._stream()))
+                                              C.c_void_p(plain.data_ptr()), self._stream()))
             else:
                 _lib.check(self._lib.cs_reset_pose(self._ctx, mask_p, C.c_void_p(pose_t.data_ptr()), int(perturb),
-                                                   force_p, C.c_void_p(self._obs.data_ptr()), self._stream()))
+                                                   force_p, C.c_void_p(plain.data_ptr()), self._stream()))
+            if plain is not self._obs:
+                self._obs.copy_(plain)
         self._keep = (mask_t, force_t, pose_t)      # alive until the stream has consumed them
         if (forces is not None and perturb and self.config.state_mode == _lib.STATE_F64
                 and not isinstance(forces, torch.Tensor)):
@@ -416,35 +432,37 @@ class CopterVecEnv:
         return self._obs, self._reward, term, trunc, infos
 
     def _outputs_to_numpy(self):
-        """The NumPy convenience path: obs, reward and both flags cross PCIe as ONE device-to-host copy and the
-        arrays returned are views of that host buffer.  copy=True (the default, as gymnasium.vector.SyncVectorEnv):
+        """The NumPy convenience path: obs, reward and both flags cross PCIe as ONE device-to-host copy (the packed
+        rows) and the arrays returned are views of that host array (obs has row stride obs_dim + 2).  copy=True (the default, as gymnasium.vector.SyncVectorEnv):
         a fresh buffer every step -- the arrays are the caller's to keep.  copy=False: two PINNED buffers
         alternate (no staging copy, no allocation), so what a step returned stays valid only until the step
         after the next one."""
         torch = _torch()
         n, od = self.num_envs, self.obs_dim
-        o_r, o_f = self._pack_off
-        if self._obs.data_ptr() != self._packbuf.data_ptr():       # outputs re-bound by the caller: gather them first
-            self._packbuf[:n * od * 4].view(torch.float32).view(n, od).copy_(self._obs)
-            self._packbuf[o_r:o_r + n * 4].view(torch.float32).copy_(self._reward)
-            flags = self._packbuf[o_f:o_f + 2 * n].view(n, 2)
-            flags[:, 0].copy_(self._term)
-            flags[:, 1].copy_(self._trunc)
+        rows = self._rows
+        if rows is None:                    # outputs re-bound by the caller: gather them into packed rows first
+            from .sharded import row_views
+            rows = getattr(self, "_rows_tmp", None)
+            if rows is None:
+                rows = self._rows_tmp = torch.zeros((n, od + 2), dtype=torch.float32, device=self.device)
+            o, r, t, u = row_views(rows, od)
+            o.copy_(self._obs)
+            r.copy_(self._reward)
+            t.copy_(self._term)
+            u.copy_(self._trunc)
         if self.copy:
-            host = torch.empty(self._packbuf.numel(), dtype=torch.uint8)
+            host = torch.empty((n, od + 2), dtype=torch.float32)
         else:
             hosts = getattr(self, "_pack_host", None)
             if hosts is None:
-                hosts = self._pack_host = [torch.empty(self._packbuf.numel(), dtype=torch.uint8).pin_memory()
-                                           for _ in (0, 1)]
+                hosts = self._pack_host = [torch.empty((n, od + 2), dtype=torch.float32).pin_memory() for _ in (0, 1)]
                 self._pack_turn = 0
             host = hosts[self._pack_turn]
             self._pack_turn ^= 1
-        host.copy_(self._packbuf)                          # the one blocking D2H
+        host.copy_(rows)                                   # the one blocking D2H
         h = host.numpy()                                   # (shares the tensor's memory and keeps it alive)
-        hf = h[o_f:o_f + 2 * n].view(np.bool_).reshape(n, 2)
-        return (h[:n * od * 4].view(np.float32).reshape(n, od), h[o_r:o_r + n * 4].view(np.float32),
-                hf[:, 0], hf[:, 1])
+        hb = h.view(np.bool_)                              # [n, 4 * (od + 2)]: the flag bytes are 0 / 1
+        return h[:, :od], h[:, od], hb[:, 4 * (od + 1)], hb[:, 4 * (od + 1) + 1]
 
     def step_prefetch(self, actions, next_actions):
         """step(actions) for open-loop callers that already hold the NEXT action batch as a device
@@ -640,6 +658,14 @@ class CopterVecEnv:
         return them as step() would: (obs, reward, terminated, truncated), by default in this env's
         persistent output buffers, or in `out` = (obs, reward, terminated u8, truncated u8) tensors."""
         torch = _torch()
+        if out is None and self._reward.data_ptr() == self._obs.data_ptr() + 4 * self.obs_dim:     # packed rows
+            # (cs_serve_collect writes plain arrays, not packed rows: its own contiguous buffers)
+            if self._serve_out is None:
+                n, dev = self.num_envs, self.device
+                fl = torch.zeros((n, 2), dtype=torch.uint8, device=dev)
+                self._serve_out = (torch.empty((n, self.obs_dim), dtype=torch.float32, device=dev),
+                                   torch.empty(n, dtype=torch.float32, device=dev), fl[:, 0], fl[:, 1])
+            out = self._serve_out
         obs, rew, term, trunc = out if out is not None else (self._obs, self._reward, self._term, self._trunc)
         p = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(self.device):

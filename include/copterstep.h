@@ -173,7 +173,13 @@ typedef struct cs_step_io {
                                 (terminated of env i at byte 2i, truncated at 2i+1; K-step forms: [K,N,2]) and the
                                 kernels write each env's pair with one 2-byte store -- a wavefront then emits one
                                 full 128-byte line instead of two half lines.  Any other pair of pointers: two
-                                plain [N] arrays, as before. */
+                                plain [N] arrays, as before.
+                                PACKED ROWS (ABI 4; cs_step / cs_step_ex / cs_step_prefetch): reward_dev == obs_dev +
+                                obs_dim, terminated_dev == (uint8_t*)(obs_dev + obs_dim + 1) and truncated_dev ==
+                                terminated_dev + 1 declare all four outputs the columns of ONE [N, obs_dim + 2] float32
+                                array: row i = {observation, reward, flags word (byte 0 terminated, byte 1 truncated,
+                                bytes 2-3 zero)}, written as whole rows -- one output stream instead of three.  The
+                                K-step, rollout and cs_serve_collect entry points refuse that pattern (CS_ERR_ARG). */
   float* final_obs_dev;      /* [N,obs_dim]; SAME_STEP only: pre-reset observation of
                                 envs that finished this step (other rows untouched) */
   /* done-mask compaction (wave ballot): ids of the envs that finished this step,

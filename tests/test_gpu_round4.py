@@ -14,43 +14,56 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs 
 # interleaved flags (include/copterstep.h, cs_step_io): truncated == terminated + 1
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("task,mode,trunc", [("lander3d", "float32", False), ("hover3d", "float64", True),
-                                             ("lander2d", "float32", True)])
-def test_interleaved_flags_equal_separate_flag_arrays(task, mode, trunc):
-    """The two flags as the columns of ONE [N,2] byte array (one 2-byte store per env) against two plain [N]
-    arrays, on twins: cs_step, cs_step_many, cs_rollout_random; ragged batch, short episodes so that both flags
-    fire.  Canary bytes around the interleaved buffer stay untouched."""
+                                             ("lander2d", "float32", True), ("hover1d", "float32", False)])
+def test_output_forms_agree_packed_rows_interleaved_flags_separate_arrays(task, mode, trunc):
+    """The three output forms of cs_step_io on twins: (A) the wrapper's default = all four outputs the columns of ONE
+    packed [N, obs_dim + 2] array (whole rows written), (B) four plain arrays, (C) plain obs / reward + the flags as
+    the columns of one [N,2] byte array (one 2-byte store per env), (D) packed rows bound by the caller.  Ragged batch,
+    short episodes so that both flags fire; canary words around the caller's buffers stay untouched.  Then the K-step
+    forms ([K,N,2] flags against separate [K,N] arrays through the C ABI) and the refusals."""
     import torch
     import gym_copter_amd
+    from gym_copter_amd import _lib
+    from gym_copter_amd.sharded import row_views
     n, K = 1000 + 37, 12
     kw = dict(task=task, num_envs=n, state_dtype=mode, seed=11, autoreset_mode="next_step", max_steps=9,
               time_limit_truncates=trunc)
-    a_env, b_env = gym_copter_amd.CopterVecEnv(**kw), gym_copter_amd.CopterVecEnv(**kw)
+    a_env, b_env, c_env, d_env = (gym_copter_amd.CopterVecEnv(**kw) for _ in range(4))
     dev, od, ad = a_env.device, a_env.obs_dim, a_env.action_dim
-    # A: the wrapper's default outputs are interleaved
-    assert a_env._term.stride() == (2,) and a_env._trunc.data_ptr() == a_env._term.data_ptr() + 1
-    # B: caller-bound, two contiguous arrays
-    b_out = (torch.zeros((n, od), device=dev), torch.zeros(n, device=dev),
-             torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
-    b_env.bind_outputs(*b_out)
-    # C: caller-bound interleaved pair inside a canary-guarded buffer
-    c_env = gym_copter_amd.CopterVecEnv(**kw)
+    # A: the default outputs are packed rows
+    assert a_env._obs.stride() == (od + 2, 1) and a_env._reward.data_ptr() == a_env._obs.data_ptr() + 4 * od
+    assert a_env._term.data_ptr() == a_env._obs.data_ptr() + 4 * (od + 1) == a_env._trunc.data_ptr() - 1
+    # B: four contiguous arrays
+    b_env.bind_outputs(torch.zeros((n, od), device=dev), torch.zeros(n, device=dev),
+                       torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
+    # C: interleaved flags inside a canary-guarded buffer
     guard = torch.full((2 * n + 64,), 0xA5, dtype=torch.uint8, device=dev)
     fl = guard[32:32 + 2 * n].view(n, 2)
     c_env.bind_outputs(torch.zeros((n, od), device=dev), torch.zeros(n, device=dev), fl[:, 0], fl[:, 1])
-    for e in (a_env, b_env, c_env):
-        e.reset()
+    # D: packed rows inside a canary-guarded buffer
+    gr = torch.full((n * (od + 2) + 32,), float("nan"), device=dev)
+    rows = gr[16:16 + n * (od + 2)].view(n, od + 2)
+    rows.zero_()
+    d_env.bind_outputs(*row_views(rows, od))
+    envs = (a_env, b_env, c_env, d_env)
+    first = [e.reset()[0] for e in envs]
+    for o in first[1:]:
+        assert torch.equal(first[0], o)
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     seen_term = seen_trunc = 0
     for t in range(30):
         act = torch.rand((n, ad), generator=g, device=dev) * 0.04
-        ra, rb, rc = a_env.step(act), b_env.step(act), c_env.step(act)
-        for k in range(4):
-            assert torch.equal(ra[k], rb[k]) and torch.equal(ra[k], rc[k]), (t, k)
-        seen_term += int(ra[2].sum())
-        seen_trunc += int(ra[3].sum())
-    assert seen_term + seen_trunc > 0 and (seen_trunc > 0) == trunc and (seen_term > 0 or task == "hover3d")
+        res = [e.step(act) for e in envs]
+        for other in res[1:]:
+            for k in range(4):
+                assert torch.equal(res[0][k], other[k]), (t, k)
+        seen_term += int(res[0][2].sum())
+        seen_trunc += int(res[0][3].sum())
+    assert (seen_trunc > 0) == trunc and (seen_term > 0 or trunc)       # (the step limit fires as one or the other)
     assert bool((guard[:32] == 0xA5).all()) and bool((guard[32 + 2 * n:] == 0xA5).all())
+    assert bool(torch.isnan(gr[:16]).all()) and bool(torch.isnan(gr[16 + n * (od + 2):]).all())
+    assert bool((rows.view(torch.uint8)[:, 4 * (od + 1) + 2:] == 0).all())       # bytes 2-3 of the flags word stay zero
     # K-step forms: the wrapper's [K,N,2] flags against separate [K,N] arrays through the C ABI
     acts = torch.rand((K, n, ad), generator=g, device=dev) * 0.04
     oa = a_env.step_many(acts)
@@ -58,7 +71,6 @@ def test_interleaved_flags_equal_separate_flag_arrays(task, mode, trunc):
     sep = (torch.zeros((K, n, od), device=dev), torch.zeros((K, n), device=dev),
            torch.zeros((K, n), dtype=torch.uint8, device=dev), torch.zeros((K, n), dtype=torch.uint8, device=dev))
     p = lambda x: C.c_void_p(x.data_ptr())
-    from gym_copter_amd import _lib
     _lib.check(b_env._lib.cs_step_many(b_env._ctx, K, p(acts), p(sep[0]), p(sep[1]), p(sep[2]), p(sep[3]),
                                        b_env._stream()))
     for k in range(4):
@@ -71,10 +83,18 @@ def test_interleaved_flags_equal_separate_flag_arrays(task, mode, trunc):
     sa, sb = a_env.get_state(), b_env.get_state()
     for k in sa:
         assert np.array_equal(sa[k], sb[k], equal_nan=True), k
-    # NumPy convenience path: flags come back as bool arrays
+    # the packed-rows pattern is written by cs_step only: the K-step entry points refuse it instead of overlapping
+    o, r, te, tr = row_views(rows, od)
+    rc = d_env._lib.cs_step_many(d_env._ctx, 1, p(acts), p(o), p(r), p(te), p(tr), d_env._stream())
+    assert rc == _lib.ERR_ARG and b"packed" in d_env._lib.cs_last_error()
+    rc = d_env._lib.cs_rollout_random(d_env._ctx, 1, None, p(o), p(r), p(te), p(tr), d_env._stream())
+    assert rc == _lib.ERR_ARG
+    # NumPy convenience path: one copy of the packed rows, views of it back
     o, r, te, tr, _ = a_env.step(np.zeros((n, ad), np.float32))
-    assert te.dtype == np.bool_ and tr.dtype == np.bool_ and te.shape == (n,) == tr.shape
-    for e in (a_env, b_env, c_env):
+    assert te.dtype == np.bool_ and tr.dtype == np.bool_ and te.shape == (n,) == tr.shape and o.shape == (n, od)
+    o2, r2, te2, tr2, _ = b_env.step(np.zeros((n, ad), np.float32))       # (re-bound outputs: gathered first)
+    assert np.array_equal(o, o2) and np.array_equal(r, r2) and np.array_equal(te, te2) and np.array_equal(tr, tr2)
+    for e in envs:
         e.close()
 
 
@@ -125,6 +145,10 @@ def test_episode_counter_wraps_and_step_counter_saturates_like_the_oracle(max_st
     ep[1::7] = 5
     env.set_state(episode=ep)
     orc.episode[:] = ep
+    # (the reset's perturbation is still pending: the device draws it where it is consumed, under the episode number
+    # the env has THEN -- the oracle stores the force at reset time, so restate its draw for the new numbers)
+    from oracle import refvec
+    orc.force[:] = refvec.draw_forces(orc.seed, orc.env_ids, ep - np.uint32(1), orc.tp.initial_random_force).astype(orc.T)
     assert np.array_equal(env.get_state(only=("episode",))["episode"], ep)
     rng = np.random.default_rng(2)
     wrapped = False
@@ -288,12 +312,14 @@ def test_a_session_closed_without_waiting_is_drained_before_other_streams_touch_
     g.manual_seed(4)
     acts = torch.rand((K + 1, n, 4), generator=g, device=env.device) * 2 - 1
     other = torch.cuda.Stream(device=env.device)
+    torch.cuda.synchronize()
     for rep in range(3):
         env.serve_begin(K, ring=8, timeout=5.0)
         for s in range(K):
             env.serve_submit(s, acts[s])
         env.serve_end(wait=False)                  # the env kernel is still working through its ring
-        other.wait_stream(torch.cuda.current_stream(env.device))     # (the action tensor, not the session)
+        # `other` is NOT ordered behind the current stream (the action tensors have long been written): the only
+        # thing that keeps its step behind the env kernel's write-back is the context's draining state
         with torch.cuda.stream(other):
             got = [t.clone() for t in env.step(acts[K])[:4]]
         for s in range(K):
@@ -414,11 +440,14 @@ def test_stored_word_codec_is_bit_exact_over_two_million_values():
 
 def test_a_differing_stored_word_after_one_step_is_a_straddled_rounding_boundary():
     """Device and oracle start one step from IDENTICAL stored states (set through the bit-exact codec above) with the
-    same actions.  The float64 results differ at the 1e-11 level (the float32 modes' short sin / cos polynomials,
-    fused multiply-adds, folded constants: DESIGN section 3), so a result that lies that close to a rounding boundary
-    of the 29-bit format lands on different sides: the stored words then differ by EXACTLY one unit of the format,
-    at a rate of (2 x 1e-11-ish) / 2^-29 -- asserted here: every differing word is one unit apart, the rate is
-    below 1e-3 per value, and in the float64 state mode (no rounding step) the same values agree to 1e-13."""
+    same actions.  Which operation makes their stored words differ "about once in 1e4 values" ?  Not
+    the format (previous test) but the float64 value that is rounded into it: in the float32 state modes the device
+    evaluates sin / cos with shorter polynomials (absolute error 1.4e-11 / 2.3e-13), which reaches
+    the three translational velocities through the body-Z -> NED rotation; a value that close to a rounding boundary
+    of the 29-bit format lands on the other side.  Asserted: positions and angles (x += dt * dx: one fused multiply-add
+    of identical inputs) never differ; every differing word is within one unit of the format plus that 1e-10 of
+    absolute slack; the rate per value is below 5e-3 (it is printed, per component); and in the float64 state mode
+    (full fdlibm polynomials, no rounding step) the same step agrees to 1e-13."""
     import torch
     n = 131072
     rng = np.random.default_rng(5)
@@ -444,14 +473,13 @@ def test_a_differing_stored_word_after_one_step_is_a_straddled_rounding_boundary
         res[mode] = (env.get_state(only=("x",))["x"], orc.x.astype(np.float64).copy())
         env.close()
     got, want = res["float32"]
-    gb, wb = got.view(np.int64), want.view(np.int64)
-    diff = gb != wb
-    rate = diff.mean()
-    unit = np.int64(1 << 24)                                    # one unit of the stored format in float64 bit patterns
-    assert np.all(np.abs(gb[diff] - wb[diff]) == unit), "a stored word differs by more than one unit of the format"
-    print("stored words differing after one step: %d of %d (rate %.2e), all by exactly one unit" % (diff.sum(), diff.size, rate))
-    assert rate < 1e-3
-    # integrated positions (x += dt * dx: one fused multiply-add of exactly representable inputs) never differ
-    assert not diff[[0, 2, 4]].any()
+    diff = got.view(np.int64) != want.view(np.int64)
+    per_slot = diff.mean(axis=1)
+    print("stored words differing after one step, per component: " + " ".join("%.1e" % r for r in per_slot))
+    print("overall: %d of %d (rate %.2e)" % (diff.sum(), diff.size, diff.mean()))
+    assert not diff[[0, 2, 4, 6, 8, 10]].any()                  # positions and angles: identical inputs, one fma
+    unit = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(want), 1e-300))) - 28)      # one unit of the 29-bit format
+    assert np.all(np.abs(got - want)[diff] <= unit[diff] + 1e-10)
+    assert diff.mean() < 5e-3
     g64, w64 = res["float64"]
     assert np.max(np.abs(g64 - w64) / np.maximum(np.abs(w64), 1.0)) < 1e-13

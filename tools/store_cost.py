@@ -18,8 +18,13 @@ dev = env.device
 ring = torch.rand((64, N, 4), device=dev) * 2 - 1
 lib = env._lib
 P = lambda t: C.c_void_p(t.data_ptr())
-full = dict(obs=P(env._obs), reward=P(env._reward), term=P(env._term), trunc=P(env._trunc))
-variants = {"all outputs": full,
+# four separate arrays (the wrapper's default outputs are the columns of one packed array, which cannot be withheld
+# one by one), plus the default packed rows as their own variant
+sep = (torch.empty((N, env.obs_dim), device=dev), torch.empty(N, device=dev),
+       torch.empty(N, dtype=torch.uint8, device=dev), torch.empty(N, dtype=torch.uint8, device=dev))
+full = dict(obs=P(sep[0]), reward=P(sep[1]), term=P(sep[2]), trunc=P(sep[3]))
+variants = {"packed rows (default)": dict(obs=P(env._obs), reward=P(env._reward), term=P(env._term), trunc=P(env._trunc)),
+            "all outputs": full,
             "no truncated": dict(full, trunc=None),
             "no terminated, no truncated": dict(full, trunc=None, term=None),
             "no reward": dict(full, reward=None),
