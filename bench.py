@@ -88,6 +88,10 @@ def parse(argv=None):
     p.add_argument("--gather", action="store_true",
                    help="also time with the RCCL all-gathers of the concatenated return (on one GPU it runs them in a "
                         "1-rank RCCL group with the collectives forced)")
+    p.add_argument("--default-gather-leg", action="store_true",
+                   help="one GPU: run the packed all-gather leg the way an N > 1 run does by default (last, under its "
+                        "deadline) in a 1-rank RCCL group with the collective forced -- to exercise that path where "
+                        "only one GPU is at hand")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--no-sweep", action="store_true", help="skip the batch-size / task sweep and config 5")
@@ -607,7 +611,7 @@ def main(argv=None):
     import torch
     dist = None
     launched = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ      # by torch.distributed.run
-    if launched or a.gather:
+    if launched or a.gather or a.default_gather_leg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not launched:           # --gather on one GPU: a real RCCL group of ONE rank
@@ -1008,24 +1012,28 @@ struct Policy {
     if a.pid > 0 and world == 1 and not any(k.startswith("ROCPROF") for k in os.environ) \
             and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
         fused_policy_leg()
-    state = {"deadline_hit": False}
-    if world > 1 and dist is not None and not a.gather:
+    state = {"deadline_hit": False}      # (set by the deadline of the default N > 1 gather leg)
+    if (world > 1 or a.default_gather_leg) and dist is not None and not a.gather:
         import threading
 
         def give_up():
             # the leg did not come back: the line goes out without it (rank 0), every rank leaves
             state["deadline_hit"] = True
             extra["value_with_packed_allgather"] = None
-            extra["packed_allgather_note"] = "the default packed all-gather leg did not finish within 150 s: abandoned"
+            extra["packed_allgather_note"] = "the default packed all-gather leg did not finish within its deadline: abandoned"
             try:
                 if rank == 0:
                     os.write(real_stdout, (json.dumps(assemble()) + "\n").encode())
             finally:
                 os._exit(0)
-        dog = threading.Timer(150.0, give_up)
+        deadline_s = float(os.environ.get("BENCH_GATHER_DEADLINE_S", 150.0))
+        dog = threading.Timer(deadline_s, give_up)
         dog.daemon = True
         dog.start()
         try:
+            if os.environ.get("BENCH_TEST_HANG_GATHER") == "1":      # diagnostic: what a leg that never returns does to the line
+                while True:
+                    time.sleep(1.0)
             run_gather_legs(("packed",))
         except Exception as e:
             extra["value_with_packed_allgather"] = None

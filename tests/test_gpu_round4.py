@@ -483,3 +483,66 @@ def test_a_differing_stored_word_after_one_step_is_a_straddled_rounding_boundary
     assert diff.mean() < 5e-3
     g64, w64 = res["float64"]
     assert np.max(np.abs(g64 - w64) / np.maximum(np.abs(w64), 1.0)) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------
+# bench.py: the line's new parts
+# ---------------------------------------------------------------------------------------
+def _bench(args, tmp_path, extra_env=None):
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+           "--no-cpu-baseline", "--min-region-ms", "5", "--regions", "3"] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    env.pop("COPTERSTEP_FORCE_COLLECTIVE", None)
+    from gpu_util import run_with_rccl
+    p = run_with_rccl(cmd, env, 300, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_default_gather_leg_and_its_deadline(tmp_path):
+    """What `bench.py --gpus N` (N > 1, the driver's command) does by default since round 4, exercised on one GPU with
+    --default-gather-leg: ONE packed all-gather leg, run last in a (here 1-rank, forced) RCCL group, reported beside the
+    collective-free value; and when that leg never comes back the line still goes out, without it, at the deadline."""
+    light = ["--no-sweep", "--pid", "0", "--many", "0", "--served", "0", "--no-span", "--default-gather-leg"]
+    d = _bench(light, tmp_path)
+    assert d["rccl"] == {"backend": "nccl", "world_size": 1, "ranks_seen": 1} and d["allgather_is_a_collective"] is True
+    assert set(d["allgather_launch_mode"]) == {"packed"} and 0 < d["value_with_packed_allgather"] <= d["value"] * 1.05
+    assert d["packed_allgather_bytes_per_rank"] == 65536 * 12 * 4
+    assert d["summary"]["with_packed_allgather"]["value_with_packed_allgather"] == d["value_with_packed_allgather"]
+    d = _bench(light, tmp_path, {"BENCH_GATHER_DEADLINE_S": "4", "BENCH_TEST_HANG_GATHER": "1"})
+    assert d["value"] > 1e9 and d["value_with_packed_allgather"] is None and "deadline" in d["packed_allgather_note"]
+
+
+def test_bench_line_carries_span_issue_bounds_and_residency(tmp_path):
+    """The accounting of VERDICT round 3 #1 in the driver's own line: the kernel-only span figure (a child process on
+    the span build), the issue bound of the headline and of a K-step leg from the stamped PMC counts (or the reason they
+    are withheld), config 5's three bounds, `resident` on every sweep point, the constant-thrust leg."""
+    import os
+    d = _bench(["--pid", "0", "--served", "0", "--many", "64"], tmp_path)
+    rf = d["roofline"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.exists(os.path.join(root, "gym_copter_amd", "csrc", "build", "libcopterstep_span.so")):
+        assert 1.0 < rf["kernel_span_us"] < rf["launch_us"] and rf["frac"] < rf["kernel_frac"] < 1.0
+    assert rf["resident"] == "infinity_cache" and abs(rf["frac"] - 176 * 65536 / (rf["launch_us"] * 1e-6) / 8e12) < 1e-9
+    sm = d["step_many"]["roofline"]
+    assert sm["bound"] == "valu_f64_issue" and "source" in sm
+    if sm["frac"] is not None:          # the stamp matches this tree's kernels: the arithmetic must hold
+        assert abs(sm["floor_us"] - sm["valu_per_wavefront_step"] * 4 / (sm["clock_GHz"] * 1e3)) < 1e-9
+        assert abs(sm["frac"] - sm["floor_us"] / sm["achieved_us"]) < 1e-12 and 0.3 < sm["frac"] < 1.0
+        assert abs(rf["issue"]["frac"] - rf["issue"]["floor_us"] / rf["launch_us"]) < 1e-9
+    c5 = {b["bound"]: b for b in d["config5"]["bounds"]}
+    assert set(c5) >= {"hbm", "valu_f64"} and 0.1 < c5["hbm"]["frac"] < 0.6
+    if c5["valu_f64"].get("frac") is not None:
+        assert 900 < c5["valu_f64"]["flop_per_env_step"] < 1400 and c5["valu_f64"]["frac"] < c5["valu_f64_issue"]["frac"]
+    sweep = {(e["task"], e["envs"], e["actions"]): e for e in d["sweep"]}
+    assert ("lander3d", 65536, "const") in sweep and sweep[("lander3d", 65536, "const")]["frac"] > 0.2
+    assert sweep[("hover3d", 262144, "uniform")]["resident"] == "infinity_cache"
+    assert sweep[("lander3d", 4194304, "uniform")]["resident"] == "hbm"
+    assert "served_submit_collect" not in d and list(d)[-1] == "summary"
+    assert d["summary"]["sweep_resident"]["lander3d_4194304_uniform"] == "hbm"
