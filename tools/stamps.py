@@ -2,7 +2,7 @@
 """Diagnostic (GPU box): per-wavefront phase timing of step_kernel from the stamp build.
 
   make -C gym_copter_amd/csrc stamps          # -> gym_copter_amd/csrc/build/libcopterstep_stamps.so
-  python tools/stamps.py [num_envs] [uniform|near_hover]
+  python tools/stamps.py [num_envs] [uniform|near_hover] [substeps]
   STAMPS_THRASH_MB=512 python tools/stamps.py ...   # a 512 MB read-modify-write before every step (cold caches)
 
 The stamp build (-DCS_STAMPS) records s_memtime at phase boundaries of every wavefront into a
@@ -23,7 +23,8 @@ from gym_copter_amd import _lib  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 law = sys.argv[2] if len(sys.argv) > 2 else "uniform"
-env = gym_copter_amd.CopterVecEnv("lander3d", N, seed=1, autoreset_mode="next_step")
+nsub = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+env = gym_copter_amd.CopterVecEnv("lander3d", N, seed=1, autoreset_mode="next_step", substeps=nsub)
 env.reset()
 dev = env.device
 acts = [torch.rand((N, 4), device=dev) * 2 - 1 if law == "uniform"
@@ -50,6 +51,6 @@ for rep in range(10):
 d = np.median(np.stack(res), axis=0)
 names = ["loads issued -> landed", "decode + step body", "stores issued (+ LDS transpose)", "stores acknowledged",
          "whole wavefront"]
-print("N", N, law, "- shader-clock cycles per phase, median over wavefronts and 10 steps")
+print("N", N, law, "substeps", nsub, "- shader-clock cycles per phase, median over wavefronts and 10 steps")
 for k in range(5):
     print("%-32s %8.0f" % (names[k], np.median(d[:, k])))
