@@ -270,6 +270,53 @@ int main(int argc, char** argv) {
     OK(cs_destroy(twin));
   }
 
+  // ---- output forms (ABI 4, cs_step_io): packed rows and interleaved flags == four plain arrays ----
+  {
+    cs_config c2 = cfg;
+    c2.autoreset = CS_AUTORESET_NEXT_STEP;
+    c2.max_steps = 7;                                   // the step limit fires inside the stretch
+    cs_ctx *a = nullptr, *b = nullptr, *c = nullptr;
+    OK(cs_create(&c2, &a));
+    OK(cs_create(&c2, &b));
+    OK(cs_create(&c2, &c));
+    float* rows;                                        // [n, od + 2]: {observation, reward, flags word} per env
+    uint8_t* fl;                                        // [n, 2]: {terminated, truncated} per env
+    HIP(hipMalloc((void**)&rows, n * (od + 2) * sizeof(float)));
+    HIP(hipMalloc((void**)&fl, 2 * n));
+    float* p_obs = rows;
+    float* p_rew = rows + od;
+    uint8_t* p_term = reinterpret_cast<uint8_t*>(rows + od + 1);
+    for (cs_ctx* e : {a, b, c}) OK(cs_reset(e, nullptr, force, nullptr, stream));
+    std::vector<float> h_rows(n * (od + 2));
+    std::vector<uint8_t> h_fl(2 * n), h_trunc(n);
+    for (int k = 0; k < 12; ++k) {
+      OK(cs_step(a, act, p_obs, p_rew, p_term, p_term + 1, stream));      // packed rows
+      OK(cs_step(b, act, obs, rew, term, trunc, stream));                 // four plain arrays
+      OK(cs_step(c, act, obs, rew, fl, fl + 1, stream));                  // interleaved flags (obs / rew rewritten: same values)
+      HIP(hipMemcpyAsync(h_rows.data(), rows, h_rows.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(h_fl.data(), fl, 2 * n, hipMemcpyDeviceToHost, stream));
+      HIP(hipMemcpyAsync(h_trunc.data(), trunc, n, hipMemcpyDeviceToHost, stream));
+      if (fetch()) return 1;
+      for (int64_t i = 0; i < n; ++i) {
+        const float* r = &h_rows[i * (od + 2)];
+        CHECK(std::memcmp(r, &h_obs[i * od], od * sizeof(float)) == 0 && r[od] == h_rew[i]);
+        uint32_t w;
+        std::memcpy(&w, &r[od + 1], 4);
+        CHECK(w == (uint32_t)h_term[i] + 256u * h_trunc[i]);
+        CHECK(h_fl[2 * i] == h_term[i] && h_fl[2 * i + 1] == h_trunc[i]);
+      }
+      if (k == 6) {                                                       // steps 1..7: the limit, folded into terminated
+        for (int64_t i = 0; i < n; ++i) CHECK(h_term[i] == 1);
+      }
+    }
+    // the K-step entry points write plain arrays: the packed pattern is refused there, not overlapped
+    CHECK(cs_step_many(a, 1, act, p_obs, p_rew, p_term, p_term + 1, stream) == CS_ERR_ARG);
+    CHECK(std::strstr(cs_last_error(), "packed") != nullptr);
+    HIP(hipFree(rows));
+    HIP(hipFree(fl));
+    for (cs_ctx* e : {a, b, c}) OK(cs_destroy(e));
+  }
+
   // ---- errors come back as codes + messages, never as exceptions or aborts ----
   CHECK(cs_step(ctx, nullptr, obs, rew, term, trunc, stream) != 0);
   CHECK(cs_last_error()[0] != '\0');
