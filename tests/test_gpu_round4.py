@@ -546,3 +546,33 @@ def test_bench_line_carries_span_issue_bounds_and_residency(tmp_path):
     assert sweep[("lander3d", 4194304, "uniform")]["resident"] == "hbm"
     assert "served_submit_collect" not in d and list(d)[-1] == "summary"
     assert d["summary"]["sweep_resident"]["lander3d_4194304_uniform"] == "hbm"
+
+
+def test_episode_counter_wraps_naturally_under_the_on_device_random_policy():
+    """No parked counters: a step limit of 100 000 leaves the episode counter 11 bits (it wraps at 2 047), and under
+    the on-device random policy (episodes of ~7 steps) nearly every env wraps within 18 400 steps.  cs_rollout_random in
+    launches of 400 steps against the oracle driven by the oracle's own draw of the same actions (keyed by seed, env
+    id, EPISODE and step: a wrong wrap changes every action after it), every step's flags and the state after every
+    launch; the random policy's and the reset perturbation's Philox counters both run through the wrap."""
+    from oracle.refvec import draw_actions
+    n, K, launches = 192, 400, 46
+    env, orc = make_pair("lander3d", n, "float32", "next_step", seed=99, env_id_base=4096, max_steps=100000)
+    assert orc.ep_mask == 2047
+    env.reset()
+    orc.reset()
+    ids = np.arange(4096, 4096 + n)
+    wrapped = np.zeros(n, bool)
+    for launch in range(launches):
+        obs_k, rew_k, term_k, trunc_k, act_k = (to_np(v) for v in env.rollout_random(K, return_actions=True))
+        for k in range(K):
+            before = orc.episode.copy()
+            a = draw_actions(99, ids, orc.episode, orc.steps, 4)
+            assert np.array_equal(a, act_k[k]), (launch, k)
+            _, _, t, tr = orc.step(a.astype(np.float64))
+            assert np.array_equal(term_k[k], t) and np.array_equal(trunc_k[k], tr), (launch, k)
+            wrapped |= orc.episode < before
+        st = env.get_state()
+        assert np.array_equal(st["episode"], orc.episode) and np.array_equal(st["steps"], orc.steps), launch
+        assert_state_close(env, orc, 2e-6, ctx="launch %d" % launch)
+    assert wrapped.mean() > 0.9 and orc.episode.max() <= 2047 and orc.episode.min() >= 1
+    env.close()
