@@ -576,3 +576,40 @@ def test_episode_counter_wraps_naturally_under_the_on_device_random_policy():
         assert_state_close(env, orc, 2e-6, ctx="launch %d" % launch)
     assert wrapped.mean() > 0.9 and orc.episode.max() <= 2047 and orc.episode.min() >= 1
     env.close()
+
+
+def test_the_ctypes_stub_printed_in_integration_md_works_as_written():
+    """INTEGRATION.md section 3 prints the binding a gym-copter maintainer would add (`gym_copter/envs/_copterstep.py`).
+    The block is taken from the document as it stands, executed against the built library (only the library's path is
+    filled in), and its `Lander` is flown like the reference's own (reset(seed), step(action) -> obs, reward, done,
+    truncated, info) next to CopterVecEnv(num_envs=1) with the same seed: same observations, rewards and flags."""
+    import os
+    import re
+    import torch
+    import gym_copter_amd
+    from gym_copter_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(import ctypes as C, numpy as np, torch\n.*?)```", text, re.S)
+    assert m, "the stub's code block was not found in INTEGRATION.md"
+    code = m.group(1).replace('C.CDLL("libcopterstep.so")', "C.CDLL(%r)" % _lib.LIB_PATH)
+    assert _lib.LIB_PATH in code
+    _lib.load()                                   # (torch's HIP runtime first, as the package does)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md:section-3", "exec"), ns)
+    stub = ns["Lander"](max_steps=60)
+    env = gym_copter_amd.CopterVecEnv("lander3d", 1, seed=0, autoreset_mode="disabled", max_steps=60)
+    o1, info = stub.reset(seed=5)
+    o2, _ = env.reset(seed=5)
+    assert isinstance(info, dict) and o1.shape == (10,) and np.array_equal(o1, to_np(o2)[0])
+    done_seen = False
+    for t in range(70):
+        a = np.full(4, 1.625e-2)                                   # lander.py:21,42
+        obs, r, done, trunc, info = stub.step(a)
+        w = env.step(torch.full((1, 4), 1.625e-2, device=env.device))
+        assert np.array_equal(obs, to_np(w[0])[0]) and r == float(w[1][0]), t
+        assert done == bool(w[2][0]) and trunc == bool(w[3][0]) and isinstance(r, float) and isinstance(done, bool), t
+        done_seen |= done
+    assert done_seen                                               # the step limit (60) was reached
+    stub.close()
+    env.close()
