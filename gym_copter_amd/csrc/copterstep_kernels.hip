@@ -312,8 +312,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       // instructions than the LDS transpose (whose full-line stores win as soon as SIMDs hold two wavefronts)
       if (obs_dev != nullptr && valid) {
         float* dst = obs_dev + (row + i) * OBS;
-#pragma unroll
-        for (int j = 0; j < OBS; ++j) dst[j] = out.row[j];
+        store_row_direct<OBS>(dst, out.row);
       }
     } else {
       write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);

@@ -75,6 +75,26 @@ __device__ __forceinline__ bool outputs_are_packed_rows(const float* obs, const 
          trunc == term + 1;
 }
 
+// One env's observation row straight from its lane (the K-step kernels at one wavefront per SIMD, where instruction
+// issue is the limit and three stores per lane cost fewer instructions than the LDS transpose: dev_tile.h,
+// kDirectRowsMaxEnvs).  Rows are written once and never read back by the kernel: non-temporal, as every other
+// per-step output (-1 ... -2 % per step against plain stores, round 4).  Rows are 8-byte aligned (OBS is even).
+template <int OBS>
+__device__ __forceinline__ void store_row_direct(float* dst, const float (&row)[OBS]) {
+  static_assert(OBS % 2 == 0, "observation rows are whole 8-byte pairs");
+  typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+  constexpr int Q = OBS / 4 * 4;
+#pragma unroll
+  for (int j = 0; j < Q; j += 4) {
+    const f32x4_a8 v4 = {row[j], row[j + 1], row[j + 2], row[j + 3]};
+    CS_NT_STORE(v4, reinterpret_cast<f32x4_a8*>(dst + j));
+  }
+  if constexpr (OBS - Q == 2) {
+    const f32x2 v2 = {row[Q], row[Q + 1]};
+    CS_NT_STORE(v2, reinterpret_cast<f32x2*>(dst + Q));
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // one env, register-resident, and one _Task.step() on it
 // ---------------------------------------------------------------------------------

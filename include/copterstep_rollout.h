@@ -145,9 +145,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     }
     if constexpr (DIRECT_ROWS) {  /* one wavefront per SIMD: three row stores per lane cost fewer instructions */
       if (obs_dev != nullptr && valid) {
-        float* dst = obs_dev + (row + i) * OBS;
-#pragma unroll
-        for (int j = 0; j < OBS; ++j) dst[j] = out.row[j];
+        store_row_direct<OBS>(obs_dev + (row + i) * OBS, out.row);
       }
     } else {
       write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
