@@ -60,6 +60,12 @@
 extern "C" {
 #endif
 
+/* ABI history.  3: next_actions_dev ignored; Philox perturbations restored as draws by cs_set_state.
+ * 4: output forms of cs_step_io (interleaved flags in every stepping entry point, packed rows in cs_step / cs_step_ex /
+ *    cs_step_prefetch); cs_get_launch_view checks view->struct_size; cs_set_last_error; the step counter saturates at
+ *    2^S - 1 with S = bits(2 * (max_steps + 1)) (2047 at the default limit of 1000) and the episode counter has
+ *    29 - S bits, wrapping from its maximum to 1 (18 bits / 262 143 episodes per env at the default limit): it is the
+ *    Philox counter word of the reset draw and the random policy, and what cs_get_state / cs_episode_stats report. */
 #define CS_ABI_VERSION 4
 
 typedef enum cs_status {
