@@ -18,6 +18,7 @@ PyTorch is used only for device memory and streams.  There is no CPU implementat
 this package: construction fails if libcopterstep.so or a HIP device is missing.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -53,6 +54,9 @@ _TASK_KEYS = {"initial_random_force": "initial_random_force",             # task
               "target_radius": "target_radius", "yaw_penalty_factor": "yaw_penalty_factor",
               "xyz_penalty_factor": "xyz_penalty_factor", "dz_max": "dz_max", "dz_penalty": "dz_penalty",
               "inside_radius_bonus": "inside_radius_bonus"}
+
+# default outputs: packed rows up to this many envs (one wavefront per SIMD on 256 CUs x 2), plain arrays above
+PACKED_ROWS_MAX_ENVS = 131072
 
 STATE_NAMES_12 = ['X', 'dX', 'Y', 'dY', 'Z', 'dZ', 'Phi', 'dPhi', 'Theta', 'dTheta', 'Psi', 'dPsi']
 
@@ -155,14 +159,23 @@ class CopterVecEnv:
         assert (od.value, ad.value) == (self.obs_dim, self.action_dim), "library / binding disagree on shapes"
         n = self.num_envs
         with torch.cuda.device(self.device):
-            # the default outputs are the columns of ONE [n, obs_dim + 2] float32 array -- "packed rows"
-            # (include/copterstep.h, cs_step_io): row i = {observation, reward, flags word}.  The step kernel writes whole
-            # rows (one output stream instead of three), the NumPy convenience path ships the array to the host as one
-            # copy, and what step() returns are views of it: obs [n, obs_dim] (row stride obs_dim + 2), reward [n],
-            # terminated / truncated [n] bytes of the flags word
+            # the default outputs.  Up to PACKED_ROWS_MAX_ENVS envs: the columns of ONE [n, obs_dim + 2] float32 array --
+            # "packed rows" (include/copterstep.h, cs_step_io): row i = {observation, reward, flags word}; the step kernel
+            # writes whole rows (one output stream per wavefront instead of three: -0.5 ... -2 % per step while a SIMD
+            # holds one wavefront).  Above: plain obs / reward arrays + the two flags as the columns of one [n,2] byte
+            # array (interleaved flags) -- at >= 262 144 envs the 2 extra bytes per env of a packed row and its ragged
+            # last store cost 0.6 ... 3 % (round 4).  Either way step() returns views, and the NumPy
+            # convenience path ships one array to the host.
             from .sharded import row_views
-            self._rows = torch.zeros((n, self.obs_dim + 2), dtype=torch.float32, device=self.device)
-            self._obs, self._reward, self._term, self._trunc = row_views(self._rows, self.obs_dim)
+            if n <= int(os.environ.get("COPTERSTEP_PACKED_ROWS_MAX_ENVS", PACKED_ROWS_MAX_ENVS)):
+                self._rows = torch.zeros((n, self.obs_dim + 2), dtype=torch.float32, device=self.device)
+                self._obs, self._reward, self._term, self._trunc = row_views(self._rows, self.obs_dim)
+            else:
+                self._rows = None
+                fl = torch.zeros((n, 2), dtype=torch.uint8, device=self.device)
+                self._obs = torch.zeros((n, self.obs_dim), dtype=torch.float32, device=self.device)
+                self._reward = torch.zeros(n, dtype=torch.float32, device=self.device)
+                self._term, self._trunc = fl[:, 0], fl[:, 1]
             self._obs_plain = None          # contiguous [n, obs_dim] scratch for entry points that write plain rows
             self._serve_out = None
             self._final_obs = None
