@@ -613,3 +613,34 @@ def test_the_ctypes_stub_printed_in_integration_md_works_as_written():
     assert done_seen                                               # the step limit (60) was reached
     stub.close()
     env.close()
+
+
+def test_default_output_form_follows_the_batch_size(monkeypatch):
+    """CopterVecEnv's default outputs: packed rows up to PACKED_ROWS_MAX_ENVS envs, plain arrays + interleaved flags
+    above (the threshold is a tuning knob, overridable from the environment); both step identically."""
+    import torch
+    import gym_copter_amd
+    from gym_copter_amd import vecenv
+    small = gym_copter_amd.CopterVecEnv("hover3d", vecenv.PACKED_ROWS_MAX_ENVS, seed=3)
+    big = gym_copter_amd.CopterVecEnv("hover3d", vecenv.PACKED_ROWS_MAX_ENVS + 64, seed=3)
+    assert small._rows is not None and small._obs.stride() == (14, 1)
+    assert big._rows is None and big._obs.is_contiguous() and big._term.stride() == (2,)
+    assert big._trunc.data_ptr() == big._term.data_ptr() + 1
+    monkeypatch.setenv("COPTERSTEP_PACKED_ROWS_MAX_ENVS", "0")
+    plain = gym_copter_amd.CopterVecEnv("hover3d", vecenv.PACKED_ROWS_MAX_ENVS, seed=3)
+    assert plain._rows is None
+    for e in (small, plain):
+        e.reset()
+    g = torch.Generator(device=small.device)
+    g.manual_seed(1)
+    for _ in range(12):
+        a = torch.rand((small.num_envs, 4), generator=g, device=small.device) * 2 - 1
+        r1, r2 = small.step(a), plain.step(a)
+        for k in range(4):
+            assert torch.equal(r1[k], r2[k]), k
+    o1 = small.step(np.zeros((small.num_envs, 4), np.float32))
+    o2 = plain.step(np.zeros((small.num_envs, 4), np.float32))        # NumPy path: gathered into packed rows first
+    for k in range(4):
+        assert np.array_equal(o1[k], o2[k]), k
+    for e in (small, big, plain):
+        e.close()
