@@ -1023,7 +1023,15 @@ struct Policy {
             extra["packed_allgather_note"] = "the default packed all-gather leg did not finish within its deadline: abandoned"
             try:
                 if rank == 0:
-                    os.write(real_stdout, (json.dumps(assemble()) + "\n").encode())
+                    line = None
+                    for _ in range(5):          # (the main thread may be adding a key at this very moment)
+                        try:
+                            line = json.dumps(assemble())
+                            break
+                        except RuntimeError:
+                            time.sleep(0.05)
+                    if line is not None:
+                        os.write(real_stdout, (line + "\n").encode())
             finally:
                 os._exit(0)
         deadline_s = float(os.environ.get("BENCH_GATHER_DEADLINE_S", 150.0))
