@@ -40,14 +40,24 @@ def make_vec(env_id, num_envs=1, **kwargs):
 
 def register_with_gymnasium(namespace="gym_copter_amd"):
     """Register the ids above with Gymnasium when it is importable, as the reference registers 'Lander-v0'
-    (reference gym_copter/__init__.py:9-13): gymnasium.make_vec('gym_copter_amd/Lander-v0', num_envs=N) then
-    builds a CopterVecEnv through `vector_entry_point`.  Returns the ids registered ([] without gymnasium: it
-    is not a dependency, and it is absent from the image this was built in -- untested there)."""
+    (reference gym_copter/__init__.py:9-13: `register(id='Lander-v0', entry_point=..., max_episode_steps=1000)`, reached
+    through gym.make('gym_copter:Lander-v0'), lander.py:80): gymnasium.make_vec('gym_copter_amd/Lander-v0', num_envs=N)
+    then builds a CopterVecEnv through `vector_entry_point` (make_vec calls it as
+    entry(num_envs=N, max_episode_steps=1000, **spec kwargs, **make_vec kwargs)).  Returns the ids registered.
+
+    Gymnasium is not a dependency: without it the result is [] and nothing is logged.  With it, a registration that
+    fails is logged once (logger 'gym_copter_amd') instead of passing silently; `gym_copter_amd.make` works either way."""
+    import logging
+    log = logging.getLogger("gym_copter_amd")
     try:
         from gymnasium.envs.registration import register, registry
-    except Exception:
+    except ImportError:
         return []
-    done = []
+    except Exception as e:       # a Gymnasium that is there but broken: say so
+        log.warning("gym_copter_amd: gymnasium is installed but its registry could not be imported (%r); "
+                    "gymnasium.make_vec ids are not registered, gym_copter_amd.make still works", e)
+        return []
+    done, failed = [], []
     for env_id, spec in _REGISTRY.items():
         full = "%s/%s" % (namespace, env_id)
         if full in registry:
@@ -57,13 +67,23 @@ def register_with_gymnasium(namespace="gym_copter_amd"):
             register(id=full, vector_entry_point="gym_copter_amd:_vector_entry_point",
                      max_episode_steps=spec["max_steps"], kwargs={"copter_id": env_id})
             done.append(full)
-        except Exception:
-            pass
+        except Exception as e:
+            failed.append((full, e))
+    if failed:
+        log.warning("gym_copter_amd: %d of %d ids could not be registered with gymnasium (first: %s: %r); "
+                    "gym_copter_amd.make still works", len(failed), len(_REGISTRY), failed[0][0], failed[0][1])
     return done
 
 
-def _vector_entry_point(copter_id, num_envs=1, **kwargs):
-    kwargs.pop("max_episode_steps", None)
+def _vector_entry_point(copter_id=None, num_envs=1, max_episode_steps=None, **kwargs):
+    """What gymnasium.make_vec calls for the ids registered above.  `max_episode_steps` (the registration's 1000, or
+    the caller's make_vec(..., max_episode_steps=K)) is the env's own step limit `max_steps` (task.py:36, :128-129):
+    the batch env applies the limit itself, as Gymnasium expects of a vector entry point (no TimeLimit wrapper is
+    put around it)."""
+    if copter_id is None:
+        raise TypeError("_vector_entry_point needs copter_id (it is part of the registered kwargs)")
+    if max_episode_steps is not None and "max_steps" not in kwargs:
+        kwargs["max_steps"] = int(max_episode_steps)
     return make(copter_id, num_envs=num_envs, **kwargs)
 
 

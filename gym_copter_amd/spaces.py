@@ -38,3 +38,51 @@ class Box:
 
 def batch_space(space, n):
     return Box(space.low.flat[0], space.high.flat[0], (n,) + space.shape, space.dtype)
+
+
+class _OwnAutoresetMode:
+    """Stand-in for gymnasium.vector.AutoresetMode (same member names and values) for hosts without gymnasium."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __repr__(self):
+        return "<AutoresetMode.%s: %r>" % (self.name, self.value)
+
+
+def gymnasium_api():
+    """-> (VectorEnv base class, Box, batch_space, {mode name: AutoresetMode member}, have_gymnasium).
+
+    With Gymnasium importable these are ITS classes -- gymnasium.vector.VectorEnv as the base of CopterVecEnv,
+    gymnasium.spaces.Box spaces, gymnasium.vector.utils.batch_space and gymnasium.vector.AutoresetMode members for
+    metadata["autoreset_mode"] (what gymnasium.make_vec checks, Gymnasium >= 1.1) -- so that isinstance checks of
+    VectorEnv consumers hold.  Without it (gymnasium is not a dependency): `object`, the minimal Box above and
+    look-alike mode objects with the same names and values."""
+    try:
+        from gymnasium.vector import VectorEnv
+        from gymnasium.spaces import Box as GBox
+        try:
+            from gymnasium.vector.utils import batch_space as gbatch
+        except Exception:      # older layouts
+            gbatch = None
+        try:
+            from gymnasium.vector import AutoresetMode as GMode
+            modes = {"next_step": GMode.NEXT_STEP, "same_step": GMode.SAME_STEP, "disabled": GMode.DISABLED}
+        except Exception:      # Gymnasium < 1.1: no such enum; plain look-alikes
+            modes = None
+
+        def box(low, high, shape, dtype=np.float32):
+            return GBox(low, high, shape=tuple(shape), dtype=dtype)
+
+        def batch(space, n):
+            if gbatch is not None:
+                return gbatch(space, n)
+            return GBox(space.low.flat[0], space.high.flat[0], shape=(n,) + tuple(space.shape), dtype=space.dtype)
+        have = True
+    except ImportError:
+        VectorEnv, box, batch, modes, have = object, Box, batch_space, None, False
+    if modes is None:
+        modes = {"next_step": _OwnAutoresetMode("NEXT_STEP", "NextStep"),
+                 "same_step": _OwnAutoresetMode("SAME_STEP", "SameStep"),
+                 "disabled": _OwnAutoresetMode("DISABLED", "Disabled")}
+    return VectorEnv, box, batch, modes, have

@@ -23,7 +23,12 @@ import os
 import numpy as np
 
 from . import _lib
-from .spaces import Box, batch_space
+from .spaces import gymnasium_api
+
+# With Gymnasium importable CopterVecEnv IS a gymnasium.vector.VectorEnv with gymnasium.spaces.Box spaces and a
+# gymnasium.vector.AutoresetMode in its metadata (what gymnasium.make_vec and VectorEnv consumers check); without it
+# (gymnasium is not a dependency) the same attributes on a plain class (spaces.py).
+_VectorEnvBase, Box, batch_space, _AUTORESET_META, HAVE_GYMNASIUM = gymnasium_api()
 
 _TASKS = {"lander3d": _lib.TASK_LANDER3D, "lander": _lib.TASK_LANDER3D,
           "hover3d": _lib.TASK_HOVER3D, "hover": _lib.TASK_HOVER3D,
@@ -66,8 +71,13 @@ def _torch():
     return torch
 
 
-class CopterVecEnv:
+class CopterVecEnv(_VectorEnvBase):
     FRAMES_PER_SECOND = 100                                    # task.py:25
+    # class-level defaults of the gymnasium.vector.VectorEnv attribute set (instances overwrite them)
+    metadata = {"render_modes": [], "render_fps": 100}         # task.py:27-30 (rendering is out of scope: no modes)
+    render_mode = None
+    spec = None                                                # gymnasium.make_vec assigns env.unwrapped.spec
+    closed = False
 
     def __init__(self, task="lander3d", num_envs=1, device=0, seed=0,
                  autoreset_mode="next_step", substeps=1, state_dtype="float32",
@@ -144,13 +154,25 @@ class CopterVecEnv:
         self.device = torch.device("cuda", int(device))
         first, self.obs_dim, self.action_dim = _TASK_SHAPES[self.task]
         self.STATE_NAMES = STATE_NAMES_12[first:first + self.obs_dim]   # lander.py:30-31
+        # metadata["autoreset_mode"]: a gymnasium.vector.AutoresetMode member (NEXT_STEP / SAME_STEP / DISABLED) when
+        # Gymnasium is importable -- make_vec warns about anything else -- and a look-alike with the same name and
+        # value otherwise; the plain string stays in self.autoreset_mode
         self.metadata = {"render_modes": [], "render_fps": self.FRAMES_PER_SECOND,
-                         "autoreset_mode": autoreset_mode}
+                         "autoreset_mode": _AUTORESET_META[autoreset_mode]}
+        self.render_mode = None
+        self.spec = None
         self.single_observation_space = Box(-np.inf, np.inf, (self.obs_dim,), np.float32)  # task.py:46-49
         self.single_action_space = Box(-1, +1, (self.action_dim,), np.float32)              # task.py:52-55
         self.observation_space = batch_space(self.single_observation_space, self.num_envs)
         self.action_space = batch_space(self.single_action_space, self.num_envs)
         self.closed = False
+        self._fast = self._final_obs = self._done = None
+        self._open_device()
+
+    def _open_device(self):
+        """The device half of construction: the context (cs_create) and the default output buffers."""
+        torch = _torch()
+        lib, cfg = self._lib, self.config
         # cs_create fails loudly when no HIP device is usable (no CPU fallback)
         _lib.check(lib.cs_create(C.byref(cfg), C.byref(self._ctx)))
         od, ad = C.c_int32(), C.c_int32()
