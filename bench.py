@@ -78,8 +78,6 @@ def parse(argv=None):
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--graph-chunk", type=int, default=100)
     p.add_argument("--ring", type=int, default=64, help="resident action batches cycled through")
-    p.add_argument("--prefetch", type=int, default=0,
-                   help="1 = hand the kernel the NEXT action batch of the ring as well (cs_step_io.next_actions_dev)")
     p.add_argument("--produce-actions", action="store_true",
                    help="A/B workload: every step's action batch is WRITTEN by a preceding kernel (a device copy "
                         "from the ring into one buffer) instead of being read from the resident ring")
@@ -100,8 +98,10 @@ def parse(argv=None):
     p.add_argument("--served", type=int, default=500,
                    help="also time served stepping (cs_serve_*) with this many steps per session (0 = skip)")
     p.add_argument("--served-all", action="store_true",
-                   help="also time the plain-rows compatibility form of served stepping (cs_serve_submit + cs_serve_collect "
-                        "per step: the slowest form, ~4 s of run time)")
+                   help="also time the served forms that do not pay against cs_step (DESIGN.md section 8): the closed loop "
+                        "with a policy kernel per step, the same with a persistent policy kernel, and the plain-rows "
+                        "compatibility form (cs_serve_submit + cs_serve_collect per step); the default run keeps "
+                        "served_producers_ahead only")
     p.add_argument("--no-span", action="store_true",
                    help="skip the kernel-only span figure (a child process on the span build, before this one touches the GPU)")
     p.add_argument("--served-graph", type=int, default=-1, help="diagnostic: feeders of the served legs from a hipGraph (1) "
@@ -186,7 +186,7 @@ class Stepper:
     """Runs `count` consecutive env steps, as hipGraph replays of `chunk` captured
     launches plus eager launches for the remainder."""
 
-    def __init__(self, torch, env, actions, use_graph, chunk, post=None, prefetch=True, produce=False):
+    def __init__(self, torch, env, actions, use_graph, chunk, post=None, produce=False):
         self.torch, self.env, self.actions, self.post = torch, env, actions, post
         self.ring = actions.shape[0]
         # produce: the action row is written by a kernel right before the step, as a policy would
@@ -194,7 +194,6 @@ class Stepper:
         self.pos = 0
         self.graph = None
         self.chunk = chunk
-        self.prefetch = prefetch and self.ring > 1 and hasattr(env, "step_prefetch")
         if use_graph:
             s = torch.cuda.Stream(device=env.device)
             s.wait_stream(torch.cuda.current_stream(env.device))
@@ -215,8 +214,6 @@ class Stepper:
         if self.produced is not None:
             self.produced.copy_(self.actions[j % self.ring])
             self.env.step(self.produced)
-        elif self.prefetch:   # the open-loop workload knows the next batch: let the kernel pull it towards its L2
-            self.env.step_prefetch(self.actions[j % self.ring], self.actions[(j + 1) % self.ring])
         else:
             self.env.step(self.actions[j % self.ring])
         if self.post is not None:
@@ -370,9 +367,11 @@ class Timer:
             wall = float(t.item())
         return wall, ev0.elapsed_time(ev1) * 1e-3
 
-    def measure(self, runner, steps, warmup, min_region_s, regions, quantum=1):
+    def measure(self, runner, steps, warmup, min_region_s, regions, quantum=1, sampler=None):
         """-> dict: the median of `regions` timed regions of R * steps steps each (R chosen so that
-        a region holds >= min_region_s of GPU work), and the bare single pass of `steps` steps."""
+        a region holds >= min_region_s of GPU work), the spread over the regions, and the bare single pass of
+        `steps` steps.  sampler (a ClockSampler): clocks / power / temperature of the device before, during and
+        after the timed regions."""
         steps = max(quantum, steps // quantum * quantum)
         if warmup > 0:
             runner.run(max(quantum, warmup // quantum * quantum))
@@ -383,15 +382,24 @@ class Timer:
             e1 = float(t.item())
         reps = max(1, int(min_region_s / max(e1, 1e-9) + 0.999))
         walls, evs = [], []
+        before = sampler.snapshot() if sampler is not None else None
+        if sampler is not None:
+            sampler.start()
         for _ in range(max(1, regions)):
             w, e = self.region(runner, steps * reps)
             walls.append(w)
             evs.append(e)
+        during = sampler.stop() if sampler is not None else None
+        after = sampler.snapshot() if sampler is not None else None
         k = sorted(range(len(walls)), key=lambda i: walls[i])[len(walls) // 2]     # the median region
         total = steps * reps
+        sev = sorted(evs)
         return {"steps": steps, "repeats": reps, "regions": len(walls), "wall_s": walls[k],
                 "s_per_step": walls[k] / total, "launch_s": evs[k] / total,
                 "launch_s_best": min(evs) / total,
+                "launch_us_regions": {"min": sev[0] / total * 1e6, "median": sev[len(sev) // 2] / total * 1e6,
+                                      "max": sev[-1] / total * 1e6, "all": [e / total * 1e6 for e in evs]},
+                "clocks": None if sampler is None else {"before": before, "during": during, "after": after},
                 "single_pass": {"steps": steps, "wall_ms": w1 * 1e3, "ms_per_step": w1 / steps * 1e3,
                                 "note": "one bare pass (the K steps, or one hipGraph of them) incl. graph-launch + "
                                         "synchronisation overhead"}}
@@ -405,6 +413,150 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def cpu_topology():
+    """What this process may actually use of the host's CPUs: the affinity set, the cgroup CPU quota (v2 cpu.max or
+    v1 cfs quota), and how many physical cores / SMT siblings the affinity set spans."""
+    visible = os.cpu_count() or 1
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = list(range(visible))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    cores = set()
+    for c in aff:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            sib = str(c)
+        cores.add(sib)
+    usable = len(aff)
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.999)))
+    return {"cores_visible": visible, "cores_in_affinity_set": len(aff), "cgroup_quota_cores": quota,
+            "cores_usable": usable, "physical_cores_in_set": len(cores),
+            "smt_siblings_in_set": len(cores) < len(aff)}
+
+
+SAMPLER_CHILD = r"""
+import glob, json, os, select, sys, time
+FIELDS = (("sclk_MHz", "freq1_input", 1e-6), ("mclk_MHz", "freq2_input", 1e-6), ("power_W", "power1_input", 1e-6),
+          ("power_W", "power1_average", 1e-6), ("temp_junction_C", "temp2_input", 1e-3),
+          ("temp_memory_C", "temp3_input", 1e-3), ("temp_edge_C", "temp1_input", 1e-3))
+files, node = {}, None
+def snap():
+    out = {}
+    for name, (path, scale) in files.items():
+        try:
+            out[name] = round(float(open(path).read()) * scale, 1)
+        except (OSError, ValueError):
+            pass
+    return out
+def say(x):
+    sys.stdout.write(json.dumps(x) + "\n"); sys.stdout.flush()
+sampling, samples = False, []
+while True:
+    r, _, _ = select.select([sys.stdin], [], [], 0.005 if sampling else None)
+    if r:
+        line = sys.stdin.readline()
+        if not line:
+            break
+        cmd = line.split()
+        if not cmd:
+            continue
+        if cmd[0] == "node":
+            for h in sorted(glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % cmd[1])):
+                node = h
+                for name, fn, scale in FIELDS:
+                    path = os.path.join(h, fn)
+                    if name not in files and os.access(path, os.R_OK):
+                        files[name] = (path, scale)
+                break
+            say({"node": node, "fields": sorted(files)})
+        elif cmd[0] == "snap":
+            say(snap())
+        elif cmd[0] == "start":
+            sampling, samples = True, []
+        elif cmd[0] == "stop":
+            sampling = False
+            out = {"samples": len(samples)}
+            for name in files:
+                v = sorted(x[name] for x in samples if name in x)
+                if v:
+                    out[name] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+            say(out)
+        elif cmd[0] == "quit":
+            break
+    elif sampling:
+        samples.append(snap())
+"""
+
+
+class ClockSampler:
+    """Clocks, power and temperature of ONE device from its sysfs hwmon node: snapshot() once, or start() / stop()
+    around timed regions (one sample every 5 ms; stop() -> min / median / max).  freq1 = sclk, freq2 = mclk, power1 =
+    socket power, temp2 = junction, temp3 = memory.  The reader is a CHILD PROCESS started before this process
+    touches the GPU (plain file reads, no GPU call of its own): a sampling THREAD in this process was measured to
+    cost the timed loop up to 6 % -- it takes the interpreter lock from the thread that replays the hipGraphs
+    (Hover3D 262 144: 7.49 instead of 7.04 us per step, profiles/r05_ab_r4_vs_r5.txt).  sysfs sclk is the firmware's
+    reading; the clock the shader actually runs at under a float64 load is measured in-kernel by cs_clock_probe
+    (MI355X_MICROARCH.md: "sysfs pp_dpm_sclk is not the test")."""
+
+    def __init__(self):
+        self.node, self.fields = None, []
+        try:
+            self.child = subprocess.Popen([sys.executable, "-c", SAMPLER_CHILD], stdin=subprocess.PIPE,
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, bufsize=1)
+        except Exception:
+            self.child = None
+
+    def _ask(self, line, reply=True):
+        if self.child is None or self.child.poll() is not None:
+            return None
+        try:
+            self.child.stdin.write(line + "\n")
+            self.child.stdin.flush()
+            return json.loads(self.child.stdout.readline()) if reply else None
+        except Exception:
+            return None
+
+    def attach(self, pci_address):
+        r = self._ask("node %s" % pci_address) or {}
+        self.node, self.fields = r.get("node"), r.get("fields", [])
+        return bool(self.fields)
+
+    def available(self):
+        return bool(self.fields)
+
+    def snapshot(self):
+        return self._ask("snap") or {}
+
+    def start(self):
+        self._ask("start", reply=False)
+
+    def stop(self):
+        return self._ask("stop") or {}
+
+    def close(self):
+        self._ask("quit", reply=False)
+        try:
+            if self.child is not None:
+                self.child.wait(timeout=2)
+        except Exception:
+            pass
 
 
 def _scalar_port(args):
@@ -446,19 +598,40 @@ def cpu_baseline(task, law, seconds):
     # the 1-core row for both action laws of the headline workloads
     other = "const" if law != "const" else "uniform"
     o_steps, o_dt = _scalar_port((task, other, max(2.0, seconds / 4), 1))
-    procs = os.cpu_count() or 1
+    scalar = steps / dt
+    # All usable cores, one process and one env each.  The pool is sized by what this process may USE -- the affinity
+    # set capped by the cgroup CPU quota -- not by os.cpu_count() (the host's thread count: round 4 started 256
+    # processes on a box that ran ~15 of them at a time).  If the pool still does not scale (a shared host), it is
+    # halved until the aggregate is at least half of pool x one-core rate: `cores` is the pool that scaled.
+    topo = cpu_topology()
     all_cores = None
-    if procs > 1:
+    if topo["cores_usable"] > 1:
         import multiprocessing as mp
         per = max(2.0, seconds / 4)
+        tried = []
         try:
-            with mp.get_context("fork").Pool(procs) as pool:
-                res = pool.map(_scalar_port, [(task, law, per, 100 + i) for i in range(procs)])
-            all_cores = {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env-steps/s",
-                         "cores": procs, "sample": "%d processes x %.1f s, one env each" % (procs, per)}
+            procs = topo["cores_usable"]
+            while True:
+                with mp.get_context("fork").Pool(procs) as pool:
+                    res = pool.map(_scalar_port, [(task, law, per, 100 + i) for i in range(procs)])
+                agg = sum(r[0] for r in res) / max(r[1] for r in res)
+                eff = agg / (scalar * procs)
+                tried.append({"processes": procs, "value": agg, "scaling_efficiency": eff})
+                if eff >= 0.5 or procs <= 2 or len(tried) >= 5:
+                    break
+                procs, per = max(2, procs // 2), 2.0
+            # the pool that scaled (the last one tried) if there is one, else the largest aggregate seen
+            best = tried[-1] if tried[-1]["scaling_efficiency"] >= 0.5 else max(tried, key=lambda t: t["value"])
+            all_cores = {"value": best["value"], "unit": "env-steps/s", "cores": best["processes"],
+                         "per_process_rate": best["value"] / best["processes"],
+                         "scaling_efficiency": best["scaling_efficiency"],
+                         "arithmetic": "scaling_efficiency = value / (one-core value x cores)",
+                         "pools_tried": tried, "largest_aggregate_seen": max(t["value"] for t in tried),
+                         "sample": "%d processes x %.1f s, one env each (pool = usable cores: affinity set %d, cgroup "
+                                   "quota %s, %d visible)" % (best["processes"], per, topo["cores_in_affinity_set"],
+                                                              topo["cgroup_quota_cores"], topo["cores_visible"])}
         except Exception as e:      # a baseline, never a reason to lose the GPU measurement
-            all_cores = {"error": repr(e)}
-    scalar = steps / dt
+            all_cores = {"error": repr(e), "pools_tried": tried}
     nv = 65536
     v = VecOracle(task, nv, store_mode="float32", autoreset=1, seed=1)
     v.reset()
@@ -471,11 +644,11 @@ def cpu_baseline(task, law, seconds):
     vec = nv * k / (time.perf_counter() - t0)
     return {"value": scalar, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "oracle/refcpu.py TaskOracle (scalar NumPy, reference call structure), %s, "
-                      "'%s' actions, %d steps in %.1f s on 1 of %d host cores"
-                      % (task, law, steps, dt, os.cpu_count()),
+                      "'%s' actions, %d steps in %.1f s on 1 of %d usable host cores (%d visible)"
+                      % (task, law, steps, dt, topo["cores_usable"], topo["cores_visible"]),
             "one_core_other_law": {"actions": other, "value": o_steps / o_dt, "unit": "env-steps/s",
                                    "sample": "%d steps in %.1f s" % (o_steps, o_dt)},
-            "all_cores": all_cores, "cpu_model": _cpu_model(),
+            "all_cores": all_cores, "cpu_model": _cpu_model(), "cpu_topology": topo,
             "vectorised_numpy": {"value": vec, "unit": "env-steps/s", "cores": 1,
                                  "sample": "oracle/refvec.py VecOracle, %d envs x %d steps" % (nv, k)}}
 
@@ -512,17 +685,25 @@ def load_stamped(name):
                 "measured by this run" % (name, tj.get("commit"), here))
 
 
-def issue_bound(valu_per_wave_step, n_envs, s_per_step, cus, clock_hz):
+def issue_bound(valu_per_wave_step, n_envs, s_per_step, cus, clock_hz, measured_clock_hz=None):
     """The instruction-issue floor of one step: every SIMD holds ceil(waves / SIMDs) wavefronts, each of which executes
-    `valu_per_wave_step` vector instructions at 4 cycles apiece -> (floor in us, floor / measured = frac)."""
+    `valu_per_wave_step` vector instructions at 4 cycles apiece -> (floor in us, floor / measured = frac).  4 cycles per
+    float64 vector instruction and SIMD is what profiles/r05_ubench_f64.txt measures with proven co-residency (4.19-4.45
+    summed over two or more wavefronts, 4.6-4.9 for a lone one).  `frac` prices the floor at the PEAK engine clock (a
+    roofline is a peak); `frac_at_measured_clock` at the clock this device held under a float64 load in this run
+    (cs_clock_probe), which is what the kernel could have reached here."""
     simds = cus * SIMDS_PER_CU
     waves = (n_envs + LANES_PER_WAVE - 1) // LANES_PER_WAVE
     per_simd = (waves + simds - 1) // simds
     floor_s = per_simd * valu_per_wave_step * ISSUE_CYCLES / clock_hz
-    return {"bound": "valu_f64_issue", "valu_per_wavefront_step": valu_per_wave_step, "wavefronts_per_simd": per_simd,
-            "floor_us": floor_s * 1e6, "achieved_us": s_per_step * 1e6, "frac": floor_s / s_per_step,
-            "ceiling_env_steps_per_s": n_envs / floor_s, "simds": simds, "clock_GHz": clock_hz / 1e9,
-            "arithmetic": "wavefronts_per_simd x valu_per_wavefront_step x 4 cycles / clock = floor; frac = floor / achieved"}
+    out = {"bound": "valu_f64_issue", "valu_per_wavefront_step": valu_per_wave_step, "wavefronts_per_simd": per_simd,
+           "floor_us": floor_s * 1e6, "achieved_us": s_per_step * 1e6, "frac": floor_s / s_per_step,
+           "ceiling_env_steps_per_s": n_envs / floor_s, "simds": simds, "clock_GHz": clock_hz / 1e9,
+           "arithmetic": "wavefronts_per_simd x valu_per_wavefront_step x 4 cycles / clock = floor; frac = floor / achieved"}
+    if measured_clock_hz:
+        out["measured_f64_clock_GHz"] = measured_clock_hz / 1e9
+        out["frac_at_measured_clock"] = out["frac"] * clock_hz / measured_clock_hz
+    return out
 
 
 def kernel_span_child(task, n, law, substeps, timeout=180):
@@ -562,7 +743,7 @@ def roofline_block(task, n, launch_s, state, traffic=None, traffic_source=None):
 
 
 def run_config(torch, timer, gca, a, task, n, law, substeps, device, rank, steps, warmup, ring, min_region_s,
-               regions, use_graph=True, prefetch=True):
+               regions, use_graph=True, sampler=None):
     """One (task, batch, action law) point of the sweep: own env, own action ring, own graph."""
     env = gca.CopterVecEnv(task=task, num_envs=n, device=device.index, seed=1234,
                            autoreset_mode="next_step", state_dtype=a.state, substeps=substeps,
@@ -570,8 +751,8 @@ def run_config(torch, timer, gca, a, task, n, law, substeps, device, rank, steps
     actions = make_actions(torch, law, ring, n, device, 1234 + rank)
     env.reset()
     chunk = graph_chunk_for(steps, a.graph_chunk)
-    st = Stepper(torch, env, actions, use_graph, chunk, prefetch=prefetch)
-    m = timer.measure(st, steps, warmup, min_region_s, regions, quantum=chunk if use_graph else 1)
+    st = Stepper(torch, env, actions, use_graph, chunk)
+    m = timer.measure(st, steps, warmup, min_region_s, regions, quantum=chunk if use_graph else 1, sampler=sampler)
     env.close()
     del st, actions, env
     torch.cuda.empty_cache()
@@ -607,6 +788,9 @@ def main(argv=None):
     if rank == 0 and world == 1 and not a.no_span and not a.no_graph and a.state == "float32" and not a.produce_actions:
         # the kernel-only figure of the headline: a child on the span build, before this process touches the GPU
         span = kernel_span_child(a.task, a.envs, a.actions, a.substeps)
+
+    # the clock / power / temperature reader: a child process, started before this one touches the GPU
+    sampler_proc = ClockSampler() if rank == 0 and world == 1 else None
 
     import torch
     dist = None
@@ -657,18 +841,34 @@ def main(argv=None):
                            substeps=a.substeps, env_id_base=rank * n)
     actions = make_actions(torch, a.actions, a.ring, n, device, 1234 + rank)
     env.reset()
+    # clocks / power / temperature of THIS device beside the timings (sysfs hwmon of the device's PCI address), and the
+    # shader clock it holds under a float64 vector load (cs_clock_probe) -- what the issue bounds are ALSO priced at
+    sampler = None
+    try:
+        if sampler_proc is not None and sampler_proc.attach(env.pci_address()):
+            sampler = sampler_proc
+    except Exception:
+        sampler = None
+    f64_clock = {}
+    try:
+        for w in (1, 4):
+            f64_clock[w] = env.clock_probe(w)
+    except Exception as e:
+        f64_clock = {"error": repr(e)}
     # streams for the served legs, created BEFORE any hipGraph is captured: on MI355X / ROCm 7 a stream created once
     # graphs have been instantiated is served several times more slowly by the hardware scheduler (DESIGN.md section 8;
     # the env kernel's own stream is created with the context for the same reason)
     served_side = [torch.cuda.Stream(device=device) for _ in (0, 1)] if a.served > 0 else None
     use_graph = not a.no_graph
     chunk = graph_chunk_for(a.steps, a.graph_chunk)
-    stepper = Stepper(torch, env, actions, use_graph, chunk, prefetch=bool(a.prefetch), produce=a.produce_actions)
-    m = timer.measure(stepper, a.steps, a.warmup, min_region_s, a.regions, quantum=chunk if use_graph else 1)
+    stepper = Stepper(torch, env, actions, use_graph, chunk, produce=a.produce_actions)
+    m = timer.measure(stepper, a.steps, a.warmup, min_region_s, a.regions, quantum=chunk if use_graph else 1,
+                      sampler=sampler)
     total_envs = n * world
     value = total_envs / m["s_per_step"]
 
     extra = {}
+    state = {"deadline_hit": False}      # (set by the deadline of the default N > 1 gather leg)
 
     def assemble():
         """The ONE JSON line from what has been measured so far (also called by the deadline of the default N > 1
@@ -711,13 +911,25 @@ def main(argv=None):
                                                               if use_graph else "eager launches"),
                        "envs_per_gpu": n, "total_envs": total_envs, "task": a.task,
                        "actions": a.actions, "state_words": a.state, "substeps": a.substeps,
-                       "action_ring": a.ring, "next_action_prefetch": bool(a.prefetch),
+                       "action_ring": a.ring,
                        "actions_produced_by_a_preceding_kernel": bool(a.produce_actions),
                        "parallelism": "env-shard x%d" % world},
             "roofline": roofline_block(a.task, n, m["launch_s"], a.state, traffic, tsrc),
         }
         rf = out["roofline"]
         rf["resident"] = "infinity_cache" if n <= 1048576 else "hbm"
+        lr = m["launch_us_regions"]
+        rf["launch_us_min_median_max"] = [lr["min"], lr["median"], lr["max"]]
+        # clocks / power / temperature of the device around and during the headline's timed regions (sysfs hwmon), and
+        # the shader clock it holds under a float64 vector load with 1 and 4 wavefronts per SIMD (cs_clock_probe)
+        out["clocks"] = {"headline": m.get("clocks"),
+                         "f64_load_clock_GHz": ({str(k): v / 1e9 for k, v in f64_clock.items()}
+                                                if "error" not in f64_clock else f64_clock),
+                         "peak_engine_clock_GHz": clock_hz / 1e9,
+                         "source": (sampler.node if sampler is not None else "no readable hwmon node for this device"),
+                         "note": "sclk_MHz is the firmware's sysfs reading; f64_load_clock_GHz is delta s_memtime / delta "
+                                 "s_memrealtime inside a float64 FMA kernel, by wavefronts per SIMD"}
+        out["status"] = "degraded" if state["deadline_hit"] else "ok"
         # the kernel alone, without the dependent-launch gap that `frac` contains: the span build in a child process
         if span is not None and "kernel_span_ns" in span:
             ks = span["kernel_span_ns"]["median"] * 1e-9
@@ -735,7 +947,7 @@ def main(argv=None):
         key = "%s_%d%s" % (a.task, n, "_substeps%d" % a.substeps if a.substeps > 1 else "")
         v = pmc.get("valu_per_wavefront", {}).get(key) if a.state == "float32" else None
         if v:
-            rf["issue"] = dict(issue_bound(v, n, m["launch_s"], cus, clock_hz), source=pmc_src)
+            rf["issue"] = dict(issue_bound(v, n, m["launch_s"], cus, clock_hz, f64_clock.get(1 if n <= 65536 else 4)), source=pmc_src)
         out.update(extra)
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -751,6 +963,11 @@ def main(argv=None):
                                      for e in extra.get("sweep", []) if "resident" in e},
                   "config5": [pick(b, "bound", "frac") for b in extra.get("config5", {}).get("bounds", [])],
                   "config5_launch_us": extra.get("config5", {}).get("launch_us"),
+                  "sweep_4m_launch_us_min_median_max": {
+                      "%s_%d_%s" % (e.get("task"), e.get("envs", 0), e.get("actions")): [round(x, 2) for x in e["launch_us_min_median_max"]]
+                      for e in extra.get("sweep", []) if e.get("envs", 0) >= 4194304 and "launch_us_min_median_max" in e},
+                  "f64_load_clock_GHz": {str(k): round(v / 1e9, 3) for k, v in f64_clock.items()} if "error" not in f64_clock else None,
+                  "status": "degraded" if state["deadline_hit"] else "ok",
                   "k_step_us": {k: round(extra[k]["us_per_step"], 3) for k in ("step_many", "rollout_pid", "rollout_random", "rollout_policy_linear")
                                 if "us_per_step" in extra.get(k, {})},
                   "k_step_issue_frac": {k: round(extra[k]["roofline"]["frac"], 3)
@@ -783,11 +1000,11 @@ def main(argv=None):
                 bind()
             mode = "graph"
             try:
-                st = Stepper(torch, env, actions, use_graph, chunk, post=post, prefetch=bool(a.prefetch))
+                st = Stepper(torch, env, actions, use_graph, chunk, post=post)
             except Exception as e:      # capture of the collective refused: time it eagerly instead
                 torch.cuda.synchronize()
                 mode = "eager (capture failed: %s)" % type(e).__name__
-                st = Stepper(torch, env, actions, False, chunk, post=post, prefetch=bool(a.prefetch))
+                st = Stepper(torch, env, actions, False, chunk, post=post)
             g = timer.measure(st, a.steps, min(a.warmup, 50), min_region_s, a.regions,
                               quantum=chunk if mode == "graph" else 1)
             return g, mode
@@ -846,7 +1063,7 @@ def main(argv=None):
         # these kernels keep the env in registers: what bounds them is float64 instruction issue, not memory
         v = pmc.get("valu_per_wavefront_step", {}).get(name) if (a.task, n, a.state) == ("lander3d", 65536, "float32") else None
         if v:
-            extra[name]["roofline"] = dict(issue_bound(v, n, g["launch_s"], cus, clock_hz), source=pmc_src)
+            extra[name]["roofline"] = dict(issue_bound(v, n, g["launch_s"], cus, clock_hz, f64_clock.get(1)), source=pmc_src)
         else:
             extra[name]["roofline"] = {"bound": "valu_f64_issue", "frac": None, "source": pmc_src}
 
@@ -943,7 +1160,7 @@ struct Policy {
                 except Exception:
                     pass
 
-        if a.task in ("lander3d", "hover3d"):
+        if a.served_all and a.task in ("lander3d", "hover3d"):
             served_leg("served_closed_loop", lambda s: env.serve_policy_pid(s), 2, wire + 256.0,
                        "closed loop with the policy as its OWN kernel per step (cs_serve_policy_pid: outputs of step "
                        "s-1 -> PID heuristic -> actions of step s) against the persistent env kernel: one launch per "
@@ -1012,13 +1229,15 @@ struct Policy {
     if a.pid > 0 and world == 1 and not any(k.startswith("ROCPROF") for k in os.environ) \
             and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
         fused_policy_leg()
-    state = {"deadline_hit": False}      # (set by the deadline of the default N > 1 gather leg)
     if (world > 1 or a.default_gather_leg) and dist is not None and not a.gather:
         import threading
 
         def give_up():
-            # the leg did not come back: the line goes out without it (rank 0), every rank leaves
+            # the leg did not come back: the line goes out without it (rank 0) with "status": "degraded" (a hung
+            # collective must not read as a clean run), every rank says so on stderr and leaves
             state["deadline_hit"] = True
+            print("bench.py: rank %d: the packed all-gather leg did not return within its deadline -- status degraded"
+                  % rank, file=sys.stderr, flush=True)
             extra["value_with_packed_allgather"] = None
             extra["packed_allgather_note"] = "the default packed all-gather leg did not finish within its deadline: abandoned"
             try:
@@ -1061,48 +1280,62 @@ struct Policy {
                   ("lander3d", 1048576, "uniform", 8),
                   ("hover3d", 1048576, "uniform", 8), ("lander3d", 4194304, "uniform", 4),
                   ("hover3d", 4194304, "uniform", 4)]
+        tile_bytes = 5632 if a.state != "float64" else 10752     # copterstep_internal.h: make_layout (4 groups + FE + RET + EPH)
 
         def resident(task, nn, ring):
-            """Where a step's working set lives between launches: the state tiles (5 376 B per 64 envs in the float32
-            modes), the action ring and the output buffers against the 256 MiB Infinity Cache.  A point that fits is
-            served from that cache (its `frac` is algorithmic bytes over time against the HBM peak, as the contract
-            defines it, but the bytes do not come from HBM); only the others are HBM-resident."""
-            tile = 5376 if a.state != "float64" else 10496
+            """Where a step's working set lives between launches: the state tiles (5 632 B per 64 envs in the float32
+            modes, 4 KiB of it touched per step), the action ring and the output buffers against the 256 MiB Infinity
+            Cache.  A point that fits is served from that cache (its `frac` is algorithmic bytes over time against the
+            HBM peak, as the contract defines it, but the bytes do not come from HBM); only the others are HBM-resident."""
             obs = 12 if task == "hover3d" else 10
-            ws = (nn + 63) // 64 * tile + ring * nn * 16 + nn * (4 * obs + 4 + 2)
-            tiles = (nn + 63) // 64 * tile
+            ws = (nn + 63) // 64 * tile_bytes + ring * nn * 16 + nn * (4 * obs + 4 + 2)
+            tiles = (nn + 63) // 64 * tile_bytes
             where = ("infinity_cache" if ws <= INFINITY_CACHE_BYTES else
                      "hbm" if tiles > INFINITY_CACHE_BYTES else "state in the infinity cache, action ring + outputs streamed from / to hbm")
             return where, ws
+
+        def spread(g):
+            """min / median / max of the launch time over the timed regions, as roofline fractions too."""
+            return g["launch_us_regions"]
         for task, nn, law, ring in points:
             if (task, nn, law) == (a.task, n, a.actions):
                 continue
             try:
+                # the HBM-resident points vary run to run and box to box by more than a layout change is worth
+                # (VERDICT round 4, weak #4): seven regions each, min / median / max and the clocks beside them
+                nreg = 7 if nn >= 4194304 else 3
                 g = run_config(torch, timer, gca, a, task, nn, law, 1, device, rank, 100, 100, ring,
-                               min_region_s, 3, prefetch=bool(a.prefetch))
+                               min_region_s, nreg, sampler=sampler)
                 r = roofline_block(task, nn, g["launch_s"], a.state)
                 where, ws = resident(task, nn, ring)
+                lr = spread(g)
+                algo = ALGO_BYTES[task] * nn / 1e3 / HBM_PEAK_GBPS       # us at the roof
                 sweep.append({"task": task, "envs": nn, "actions": law, "ring": ring,
                               "value": nn / g["s_per_step"], "unit": "env-steps/s",
                               "ms_per_step": g["s_per_step"] * 1e3, "launch_us": r["launch_us"],
                               "achieved_GBps": r["achieved"], "frac": r["frac"], "repeats": g["repeats"],
+                              "regions": g["regions"],
+                              "launch_us_min_median_max": [lr["min"], lr["median"], lr["max"]],
+                              "frac_min_median_max": [algo / lr["max"], algo / lr["median"], algo / lr["min"]],
+                              "clocks": g["clocks"],
                               "resident": where, "working_set_bytes": ws,
                               "config": "BASELINE configs[2]" if (task, nn, law) == ("hover3d", 262144, "uniform") else None})
             except Exception as e:          # a sweep point never costs the headline
                 sweep.append({"task": task, "envs": nn, "actions": law, "error": repr(e)})
                 torch.cuda.empty_cache()
-        extra["sweep"] = sweep
-        # BASELINE configs[4]: dt = 1e-3, 10 Dynamics.setMotors calls per env step -- both bounds
-        try:
+
+        def config5_point(nn, ring, nreg):
+            """BASELINE configs[4] (dt = 1e-3, 10 Dynamics.setMotors calls per env step) at `nn` envs with its three
+            bounds: HBM, float64 vector ALU (flops executed, by PMC) and float64 instruction issue."""
             nsub = 10
-            g = run_config(torch, timer, gca, a, "lander3d", 65536, "near_hover", nsub, device, rank, 100, 100,
-                           a.ring, min_region_s, 3, prefetch=bool(a.prefetch))
-            r = roofline_block("lander3d", 65536, g["launch_s"], a.state)
-            key = "lander3d_65536_substeps10"
+            g = run_config(torch, timer, gca, a, "lander3d", nn, "near_hover", nsub, device, rank, 100, 100,
+                           ring, min_region_s, nreg, sampler=sampler)
+            r = roofline_block("lander3d", nn, g["launch_s"], a.state)
+            key = "lander3d_%d_substeps10" % nn
             bounds = [{"bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"]}]
             flop = pmc.get("f64_flops_per_env_step", {}).get(key) if a.state == "float32" else None
             if flop:
-                tf = flop * 65536 / g["launch_s"] / 1e12
+                tf = flop * nn / g["launch_s"] / 1e12
                 bounds.append({"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / F64_VALU_PEAK_TFLOPS, "flop_per_env_step": flop,
                                "note": "float64 vector ALU (no MFMA on this path).  flop_per_env_step is EXECUTED float64 "
@@ -1112,14 +1345,90 @@ struct Policy {
                 bounds.append({"bound": "valu_f64", "frac": None, "source": pmc_src})
             v = pmc.get("valu_per_wavefront", {}).get(key) if a.state == "float32" else None
             if v:
-                bounds.append(dict(issue_bound(v, 65536, g["launch_s"], cus, clock_hz), source=pmc_src))
-            extra["config5"] = {
-                "workload": "lander3d, 65536 envs, near_hover actions, dt=0.001 x 10 substeps (BASELINE configs[4])",
-                "value": 65536 / g["s_per_step"], "unit": "env-steps/s", "ms_per_step": g["s_per_step"] * 1e3,
-                "launch_us": r["launch_us"], "repeats": g["repeats"], "resident": "infinity_cache", "bounds": bounds}
+                w = 1 if nn <= 65536 else 4
+                bounds.append(dict(issue_bound(v, nn, g["launch_s"], cus, clock_hz, f64_clock.get(w)), source=pmc_src))
+            else:
+                bounds.append({"bound": "valu_f64_issue", "frac": None, "source": pmc_src})
+            lr = g["launch_us_regions"]
+            return {"workload": "lander3d, %d envs, near_hover actions, dt=0.001 x 10 substeps (BASELINE configs[4]%s)"
+                                % (nn, "" if nn == 65536 else " at a batch that gives every SIMD many wavefronts"),
+                    "task": "lander3d", "envs": nn, "actions": "near_hover", "substeps": nsub,
+                    "value": nn / g["s_per_step"], "unit": "env-steps/s", "ms_per_step": g["s_per_step"] * 1e3,
+                    "launch_us": r["launch_us"], "repeats": g["repeats"], "regions": g["regions"],
+                    "launch_us_min_median_max": [lr["min"], lr["median"], lr["max"]], "clocks": g["clocks"],
+                    "frac": r["frac"], "resident": resident("lander3d", nn, ring)[0], "bounds": bounds}
+        try:
+            extra["config5"] = config5_point(65536, a.ring, 3)
         except Exception as e:
             extra["config5"] = {"error": repr(e)}
             torch.cuda.empty_cache()
+        # ... and where an instruction-issue bound is a bound: 16 wavefronts per SIMD (VERDICT round 4 #1b)
+        try:
+            c5 = config5_point(1048576, 8, 3)
+            c5["actions"] = "near_hover_substeps10"
+            sweep.append(c5)
+        except Exception as e:
+            sweep.append({"task": "lander3d", "envs": 1048576, "actions": "near_hover_substeps10", "error": repr(e)})
+            torch.cuda.empty_cache()
+
+        # the K-step kernels with MANY wavefronts per SIMD (4 194 304 envs = 64 per SIMD): here their float64
+        # instruction-issue bound binds.  Counts by PMC at THIS size (above 65 536 envs the observation rows go
+        # through the LDS transpose: a different instantiation from the 65 536-env legs above).
+        def k_step_large(name, nn, k, make_call, bytes_step):
+            envL = gca.CopterVecEnv(task="lander3d", num_envs=nn, device=local, seed=1234, autoreset_mode="next_step",
+                                    state_dtype=a.state, env_id_base=rank * nn)
+            try:
+                envL.reset()
+                call = make_call(envL)
+
+                class Runner:
+                    def run(self, count):
+                        for _ in range(count // k):
+                            call()
+                g = timer.measure(Runner(), 2 * k, 2 * k, min_region_s, 5, quantum=k, sampler=sampler)
+                lr = g["launch_us_regions"]
+                e = {"leg": name, "task": "lander3d", "envs": nn, "actions": name, "steps_per_launch": k,
+                     "value": nn / g["s_per_step"], "unit": "env-steps/s", "launch_us": g["launch_s"] * 1e6,
+                     "us_per_step": g["launch_s"] * 1e6, "repeats": g["repeats"], "regions": g["regions"],
+                     "launch_us_min_median_max": [lr["min"], lr["median"], lr["max"]], "clocks": g["clocks"],
+                     "algorithmic_bytes_per_env_step": bytes_step,
+                     "achieved_GBps": bytes_step * nn / g["launch_s"] / 1e9,
+                     "hbm_frac_of_its_own_bytes": bytes_step * nn / g["launch_s"] / 1e9 / HBM_PEAK_GBPS,
+                     "resident": "hbm"}
+                v = pmc.get("valu_per_wavefront_step", {}).get("%s_%d" % (name, nn)) if a.state == "float32" else None
+                if v:
+                    e["roofline"] = dict(issue_bound(v, nn, g["launch_s"], cus, clock_hz, f64_clock.get(4)), source=pmc_src)
+                    e["frac"] = e["roofline"]["frac"]
+                    e["bound"] = "valu_f64_issue"
+                else:
+                    e["roofline"] = {"bound": "valu_f64_issue", "frac": None, "source": pmc_src}
+                return e
+            finally:
+                envL.close()
+                del envL
+                torch.cuda.empty_cache()
+        if a.many > 0 and a.state == "float32":
+            nn, k = 4194304, 16
+            try:
+                def mk_many(envL):
+                    block = make_actions(torch, "uniform", k, nn, device, 99)
+                    return lambda: envL.step_many(block)
+                sweep.append(k_step_large("step_many", nn, k, mk_many, 16 + 4 * 10 + 4 + 2 + 136.0 / k))
+            except Exception as e:
+                sweep.append({"leg": "step_many", "envs": nn, "actions": "step_many", "task": "lander3d", "error": repr(e)})
+                torch.cuda.empty_cache()
+        if a.pid > 0 and a.state == "float32":
+            nn, k = 4194304, 16
+            try:
+                def mk_pid(envL):
+                    envL.configure_pid()
+                    envL.reset()
+                    return lambda: envL.rollout_pid(k)
+                sweep.append(k_step_large("rollout_pid", nn, k, mk_pid, 4 * 10 + 4 + 2 + (136.0 + 384.0) / k))
+            except Exception as e:
+                sweep.append({"leg": "rollout_pid", "envs": nn, "actions": "rollout_pid", "task": "lander3d", "error": repr(e)})
+                torch.cuda.empty_cache()
+        extra["sweep"] = sweep
 
     if rank == 0 and use_graph and not a.no_sweep:
         # context for the headline's latency-bound figure: what ONE dependent launch costs on this box when the
@@ -1138,6 +1447,8 @@ struct Policy {
             extra["dependent_launch_floor"] = {"error": repr(e)}
 
     out = assemble()
+    if sampler_proc is not None:
+        sampler_proc.close()
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.close(real_stdout)

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # COPTERSTEP_LIB selects a diagnostic build of the same ABI (e.g. the stamp build); default = product
 LIB_PATH = os.environ.get("COPTERSTEP_LIB", os.path.join(_HERE, "libcopterstep.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 TASK_LANDER3D, TASK_HOVER3D, TASK_LANDER2D, TASK_LANDER1D, TASK_HOVER2D, TASK_HOVER1D = range(6)
 STATE_F32G, STATE_F32_RN, STATE_F64 = 0, 1, 2
 AUTORESET_DISABLED, AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP = 0, 1, 2
@@ -59,8 +59,11 @@ class StepIO(C.Structure):
         ("terminated_dev", C.c_void_p), ("truncated_dev", C.c_void_p),
         ("final_obs_dev", C.c_void_p), ("done_count_dev", C.c_void_p),
         ("done_ids_dev", C.c_void_p), ("done_return_dev", C.c_void_p),
-        ("done_length_dev", C.c_void_p), ("next_actions_dev", C.c_void_p),
+        ("done_length_dev", C.c_void_p), ("output_form", C.c_uint32), ("reserved_", C.c_uint32),
     ]
+
+
+OUTPUT_AUTO, OUTPUT_PLAIN, OUTPUT_PACKED_ROWS = 0, 1, 2     # cs_step_io.output_form
 
 
 # every symbol include/copterstep.h declares: name -> (restype, argtypes)
@@ -115,8 +118,9 @@ SYMBOLS = {
     "cs_reset_pose": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P]),
     "cs_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "cs_step_ex": (C.c_int, [_P, C.POINTER(StepIO), _P]),
-    "cs_step_prefetch": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "cs_step_many": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "cs_clock_probe": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), _P]),
+    "cs_device_pci_address": (C.c_int, [_P, C.c_char_p, C.c_int32]),
     "cs_set_motors": (C.c_int, [_P, _P, _P]),
     "cs_set_perturbation": (C.c_int, [_P, _P, _P, _P]),
     "cs_episode_stats": (C.c_int, [_P, _P, _P]),

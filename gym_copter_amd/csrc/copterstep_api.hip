@@ -4,6 +4,7 @@
 // and its dev_*.h device headers.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -189,7 +190,7 @@ cs::DevConst make_const(const cs_ctx* ctx) {
   c.steps_bits = (uint32_t)cs::steps_bits_for(g.max_steps);
   c.steps_mask = (1u << c.steps_bits) - 1u;
   c.ep_mask = (1u << (cs::kMetaCounterBits - (int)c.steps_bits)) - 1u;
-  c.meta_pad_ = 0;
+  c.ep_bits = (uint32_t)cs::kMetaCounterBits - c.steps_bits;
   cs::trig_constants(c.trig);
   return c;
 }
@@ -253,7 +254,7 @@ bool capturing(hipStream_t s) {
   return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
 
-// "Packed rows" (include/copterstep.h, cs_step_io) are written by cs_step / cs_step_ex / cs_step_prefetch only: the
+// "Packed rows" (include/copterstep.h, cs_step_io) are written by cs_step / cs_step_ex only: the
 // same pointer pattern handed to an entry point whose kernel writes plain arrays would make those arrays overlap.
 int refuse_packed_rows(const cs_ctx* ctx, const char* who, const float* obs, const float* reward, const uint8_t* term,
                        const uint8_t* trunc) {
@@ -445,9 +446,9 @@ int cs_create(const cs_config* cfg, cs_ctx** out) {
   (void)hipMalloc((void**)&s.span, (size_t)cs::kSpanLaunches * s.ntiles * 2 * sizeof(unsigned long long));
   (void)cs_debug_reset_spans(ctx);
 #endif
-#ifdef CS_STAMPS
-  (void)hipMalloc((void**)&s.stamps, (size_t)s.ntiles * 8 * sizeof(unsigned long long));
-  (void)hipMemset(s.stamps, 0, (size_t)s.ntiles * 8 * sizeof(unsigned long long));
+#if defined(CS_STAMPS) || defined(CS_KSTAMPS)
+  (void)hipMalloc((void**)&s.stamps, (size_t)s.ntiles * cs::kStampSlots * sizeof(unsigned long long));
+  (void)hipMemset(s.stamps, 0, (size_t)s.ntiles * cs::kStampSlots * sizeof(unsigned long long));
 #endif
   *out = ctx;
   return CS_OK;
@@ -467,13 +468,14 @@ extern "C" int cs_debug_reset_spans(cs_ctx* ctx) {
 }
 #endif
 
-#ifdef CS_STAMPS
-// diagnostic build only: copy the [ntiles][8] stamp buffer to the host
+#if defined(CS_STAMPS) || defined(CS_KSTAMPS)
+// diagnostic builds only: copy the [ntiles][kStampSlots] stamp buffer to the host
 extern "C" int cs_debug_read_stamps(cs_ctx* ctx, unsigned long long* host, void* stream) {
   (void)hipStreamSynchronize((hipStream_t)stream);
-  return hipMemcpy(host, ctx->st.stamps, (size_t)ctx->st.ntiles * 8 * sizeof(unsigned long long),
+  return hipMemcpy(host, ctx->st.stamps, (size_t)ctx->st.ntiles * cs::kStampSlots * sizeof(unsigned long long),
                    hipMemcpyDeviceToHost) == hipSuccess ? 0 : -4;
 }
+extern "C" int cs_debug_stamp_slots(void) { return (int)cs::kStampSlots; }
 #endif
 
 int cs_destroy(cs_ctx* ctx) {
@@ -568,6 +570,16 @@ int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream) {
     return fail(CS_ERR_ARG, "cs_step: done_return_dev needs cfg.episode_stats = 1");
   if ((io->done_ids_dev || io->done_return_dev || io->done_length_dev) && !io->done_count_dev)
     return fail(CS_ERR_ARG, "cs_step: done_* lists need done_count_dev");
+  if (io->output_form > CS_OUTPUT_PACKED_ROWS || io->reserved_ != 0)
+    return fail(CS_ERR_ARG, "cs_step: unknown cs_step_io.output_form (or reserved_ != 0)");
+  if (io->output_form == CS_OUTPUT_PACKED_ROWS) {
+    const int od = cs::task_obs_dim(ctx->cfg.task);
+    if (!(io->obs_dev != nullptr && io->reward_dev == io->obs_dev + od &&
+          io->terminated_dev == reinterpret_cast<const uint8_t*>(io->obs_dev + od + 1) &&
+          io->truncated_dev == io->terminated_dev + 1))
+      return fail(CS_ERR_ARG, "cs_step: CS_OUTPUT_PACKED_ROWS needs the four outputs to be the columns of one "
+                              "[N, obs_dim + 2] float32 array (include/copterstep.h, cs_step_io)");
+  }
   if (io->done_count_dev != nullptr)
     CS_HIP(hipMemsetAsync(io->done_count_dev, 0, sizeof(int32_t), (hipStream_t)stream));
   const cs::DevConst& c = constants(ctx);
@@ -585,20 +597,6 @@ int cs_step(cs_ctx* ctx, const float* actions_dev, float* obs_dev, float* reward
   cs_step_io io;
   std::memset(&io, 0, sizeof io);
   io.actions_dev = actions_dev;
-  io.obs_dev = obs_dev;
-  io.reward_dev = reward_dev;
-  io.terminated_dev = terminated_dev;
-  io.truncated_dev = truncated_dev;
-  return cs_step_ex(ctx, &io, stream);
-}
-
-int cs_step_prefetch(cs_ctx* ctx, const float* actions_dev, const float* next_actions_dev,
-                     float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
-                     uint8_t* truncated_dev, void* stream) {
-  cs_step_io io;
-  std::memset(&io, 0, sizeof io);
-  io.actions_dev = actions_dev;
-  io.next_actions_dev = next_actions_dev;
   io.obs_dev = obs_dev;
   io.reward_dev = reward_dev;
   io.terminated_dev = terminated_dev;
@@ -754,6 +752,7 @@ int cs_pid_configure(cs_ctx* ctx, const cs_pid_gains* g) {
   p.alt_target = g->alt_target;
   p.alt_windup = g->alt_windup;
   p.hover = g->heuristic == CS_PID_HOVER ? 1 : 0;
+  p.terms = cs::pid_terms_word(p);
   ctx->pid_on = true;
   return CS_OK;
 }
@@ -1191,6 +1190,48 @@ int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* ste
     if (want[k])
       CS_HIP(hipMemcpyAsync(host[k], st.base + st.off[k], st.size[k], hipMemcpyDeviceToHost, (hipStream_t)stream));
   CS_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return CS_OK;
+}
+
+int cs_device_pci_address(const cs_ctx* ctx, char* out, int32_t len) {
+  if (check_ctx(ctx) || out == nullptr || len < 16) return fail(CS_ERR_ARG, "cs_device_pci_address: need a buffer of >= 16 bytes");
+  char buf[64] = {0};
+  CS_HIP(hipDeviceGetPCIBusId(buf, (int)sizeof buf, ctx->cfg.device));
+  for (char* p = buf; *p; ++p)
+    if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');  // sysfs spells addresses in lower case
+  std::snprintf(out, (size_t)len, "%s", buf);
+  return CS_OK;
+}
+
+int cs_clock_probe(cs_ctx* ctx, int32_t waves_per_simd, double* hz_out, void* stream) {
+  if (check_ctx(ctx) || hz_out == nullptr) return fail(CS_ERR_ARG, "cs_clock_probe: null argument");
+  if (waves_per_simd < 1 || waves_per_simd > 8) return fail(CS_ERR_ARG, "cs_clock_probe: waves_per_simd must be in [1, 8]");
+  if (capturing((hipStream_t)stream)) return fail(CS_ERR_ARG, "cs_clock_probe: synchronous, not capturable");
+  DeviceGuard guard_dev(ctx->cfg.device);
+  hipDeviceProp_t prop;
+  CS_HIP(hipGetDeviceProperties(&prop, ctx->cfg.device));
+  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)waves_per_simd;
+  unsigned long long* dev = nullptr;
+  if (hipMalloc((void**)&dev, (size_t)blocks * 16) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(CS_ERR_MEMORY, "cs_clock_probe: device allocation failed");
+  }
+  // 64 v_fma_f64 per iteration per wavefront at >= 4 cycles each: ~0.3 ms per wavefront on its own at 2 GHz
+  const int iters = 2400 / waves_per_simd + 1;
+  hipError_t e = hipSuccess;
+  for (int rep = 0; rep < 2 && e == hipSuccess; ++rep)  // the second launch is the one that counts (clocks ramped)
+    e = cs::launch_clock_probe(dev, blocks, iters, (hipStream_t)stream);
+  std::vector<unsigned long long> host((size_t)blocks * 2);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess) e = hipMemcpy(host.data(), dev, host.size() * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return hip_fail(e, "cs_clock_probe");
+  std::vector<double> hz;
+  for (uint32_t b = 0; b < blocks; ++b)
+    if (host[2 * b + 1] > 1000) hz.push_back((double)host[2 * b] / (double)host[2 * b + 1] * 1e8);
+  if (hz.empty()) return fail(CS_ERR_HIP, "cs_clock_probe: no usable sample");
+  std::nth_element(hz.begin(), hz.begin() + hz.size() / 2, hz.end());
+  *hz_out = hz[hz.size() / 2];
   return CS_OK;
 }
 

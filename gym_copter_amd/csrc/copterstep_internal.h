@@ -31,13 +31,17 @@ namespace cs {
 //                                             Dynamics.perturb); touched only while one is installed.
 //                                             ticks = Dynamics._ticks (only under cs_config.track_time)
 //   RET running episode return (dword row, episode_stats)
+//   EPH high part of the episode counter (dword row; round 5): written when an env's episode number crosses a
+//       multiple of 2^E, read only by envs whose gR says they have one -- never on an ordinary step
 //
 //   gT    = 5 guard bits of each of x, dx, y, dy, z, dz (bit 5j.. = slot j) | flight status (bits 30..31)
-//   gR    = 5 guard bits of each of phi .. dpsi         (bit 5j.. = slot 6+j)
-//   meta  = steps (bits 0..S-1) | episode (bits S..28) | perturbation pending (29) | perturbation is
+//   gR    = 5 guard bits of each of phi .. dpsi         (bit 5j.. = slot 6+j) | bit 31: the episode number has a
+//           high part in the EPH row (kEpisodeFarFlag)
+//   meta  = steps (bits 0..S-1) | episode, low E bits (bits S..28) | perturbation pending (29) | perturbation is
 //           the explicit one of the FE group (30; otherwise it is the Philox draw of this episode) |
 //           reset pending (31, NEXT_STEP auto-reset).  S = bits of 2 * (max_steps + 1): 11 at the default step
-//           limit, which leaves the episode counter 18 bits (see DevConst::steps_bits)
+//           limit, E = 29 - S = 18 (see DevConst::steps_bits).  The episode counter itself is a full 32-bit
+//           number: episode = low E bits | EPH << E.
 //
 // Round 4: an ordinary step reads and writes EXACTLY these four groups -- prev_shaping used to be a row of
 // its own and the episode counter a full word of R2 (190 instead of 198 bytes per env-step now; -3 % per step
@@ -61,7 +65,7 @@ struct Layout {
   uint32_t word;          // bytes per float word (4 or 8)
   bool guard;             // guard bits kept (CS_STATE_F32G)
   uint32_t grp[4];        // offsets of T1, T2, R1, R2 (lane stride 4*word)
-  uint32_t fe, ret;       // FE group (stride 4*word), RET row (stride 4)
+  uint32_t fe, ret, eph;  // FE group (stride 4*word), RET row, EPH row (stride 4)
   uint32_t tile_bytes;
 };
 
@@ -79,6 +83,10 @@ constexpr Layout make_layout(int mode) {
   o += n * 4 * l.word;
   l.ret = o;
   o += n * 4u;
+  l.eph = o;
+#ifndef CS_EXP_TB5376  // (A/B timing build: the round-4 tile stride; the EPH row then aliases the next tile -- never touched in a bench)
+  o += n * 4u;
+#endif
   l.tile_bytes = (o + 255u) & ~255u;
   return l;
 }
@@ -87,7 +95,8 @@ constexpr Layout make_layout(int mode) {
 constexpr uint32_t kMetaPerturbPending = 1u << 29;  // the episode's reset perturbation is not consumed yet
 constexpr uint32_t kMetaExplicitForce = 1u << 30;   // ... and it is the FE group's force, not the Philox draw
 constexpr uint32_t kMetaResetPending = 1u << 31;    // NEXT_STEP: env finished, reset on next step
-constexpr int kMetaCounterBits = 29;                // steps (low) + episode (above it)
+constexpr int kMetaCounterBits = 29;                // steps (low) + the low bits of the episode counter (above it)
+constexpr uint32_t kEpisodeFarFlag = 1u << 31;      // in gR: episode >= 2^E, its high part is in the EPH row
 constexpr int kMetaStepsBitsMax = 21;               // cs_config.max_steps <= 2^20 - 3
 // Bits of the step counter for a step limit: the counter saturates at 2^S - 1.  Upstream's counter never
 // saturates (task.py:130) and an env nobody resets keeps counting past the limit (the golden traces run to 1026
@@ -119,11 +128,12 @@ struct DevConst {
   int32_t max_steps, nsub, autoreset, tl_trunc, stats, status0;
   uint32_t key_force, key_action;  // Philox keys (the counter holds env id + episode number)
   uint32_t id_lo;                  // global id of local env 0
-  // the two counters of the meta word: steps = meta & steps_mask, episode = (meta >> steps_bits) & ep_mask.
-  // The episode counter (episodes started; the Philox counter word of the reset draw and the random policy)
-  // has 29 - steps_bits bits and wraps from ep_mask to 1 (0 = never reset): 18 bits at the default limit of
-  // 1000 steps, i.e. an env's perturbation sequence repeats after 262 143 episodes.
-  uint32_t steps_bits, steps_mask, ep_mask, meta_pad_;
+  // the two counters of the meta word: steps = meta & steps_mask, low episode bits = (meta >> steps_bits) & ep_mask.
+  // The episode counter (episodes started; episode - 1 is the Philox counter word of the reset draw and of the
+  // random policy) is a full 32-bit number (round 5; ABI 4 kept ep_bits = 29 - steps_bits of it and wrapped): its
+  // low ep_bits live in the meta word, the rest in the tile's EPH row, which only an env that has run 2^ep_bits
+  // episodes (262 144 at the default step limit) ever touches.  0 = never reset; 2^32 - 1 wraps to 1.
+  uint32_t steps_bits, steps_mask, ep_mask, ep_bits;
   int32_t gyro;                    // 1 = the rotor-inertia term is live (full-featured kernels only)
   int32_t act_f32;                 // 1 = NumPy's float32 evaluation of the motor model (f32_* below)
   int32_t ticks;                   // 1 = keep Dynamics._ticks per env (cs_config.track_time; full-featured kernels only)
@@ -177,14 +187,26 @@ struct PidConst {
   double descent_kp, descent_kd;
   double alt_kp, alt_ki, alt_kd, alt_target, alt_windup;  // hover heuristic (attic/mars/hover3d.py)
   int32_t hover;                                          // 0 = landing heuristic, 1 = hover heuristic
-  int32_t pad_;
+  // which terms each controller has (`if self.Ki > 0`, `if self.Kd > 0`: pidcontrollers/__init__.py:41, :50), folded
+  // on the host into one word so that the kernels branch on a SCALAR bit test: kPidRateI ... kPidAltD
+  int32_t terms;
 };
+enum { kPidRateI = 1, kPidRateD = 2, kPidPosI = 4, kPidPosD = 8, kPidAltI = 16, kPidAltD = 32 };
+inline int32_t pid_terms_word(const PidConst& p) {
+  return (p.rate_ki > 0.0 ? kPidRateI : 0) | (p.rate_kd > 0.0 ? kPidRateD : 0) | (p.pos_ki > 0.0 ? kPidPosI : 0) |
+         (p.pos_kd > 0.0 ? kPidPosD : 0) | (p.alt_ki > 0.0 ? kPidAltI : 0) | (p.alt_kd > 0.0 ? kPidAltD : 0);
+}
 constexpr int kPidControllers = 6;  // roll rate, pitch rate, roll position, pitch position, yaw rate, altitude
 constexpr int kPidRows = 4 * kPidControllers;
 
 // per-env vehicle / world coefficient columns (cs_set_vehicle_params): rows of DevState::veh
 constexpr int kCoefRows = 11;  // k_thrust, k_roll, k_pitch, k_yaw, G, c_dphi, c_dthe, c_dpsi, two_inv_M, g_phi, g_the
 
+#ifdef CS_KSTAMPS
+constexpr uint32_t kStampSlots = 32;
+#else
+constexpr uint32_t kStampSlots = 8;
+#endif
 constexpr uint32_t kSpanLaunches = 256;
 struct DevState {
   char* tiles;      // ntiles * tile_bytes
@@ -193,8 +215,10 @@ struct DevState {
   // [kCoefRows][veh_stride] float64 rows; nullptr = uniform
   const double* veh;
   uint32_t veh_stride;
-#ifdef CS_STAMPS
-  unsigned long long* stamps;  // diagnostic build: [ntiles][8] shader-clock stamps
+#if defined(CS_STAMPS) || defined(CS_KSTAMPS)
+  // diagnostic builds: [ntiles][kStampSlots] shader-clock stamps (make stamps: phases of step_kernel; make kstamps:
+  // phases of two consecutive loop iterations of the K-step kernels, tools/kstep_stamps.py)
+  unsigned long long* stamps;
 #endif
 #ifdef CS_SPAN
   // diagnostic build (make span): every wavefront of every launch notes the chip-wide 100 MHz clock
@@ -244,6 +268,10 @@ hipError_t launch_set_perturbation(int mode, const DevState& s, const uint8_t* m
 // non-finite state word, as float64.
 hipError_t launch_episode_stats(int mode, const DevConst& c, const DevState& s, double* stats_dev,
                                 hipStream_t stream);
+
+// Diagnostic (cs_clock_probe): `blocks` one-wavefront workgroups of ~iters x 64 independent v_fma_f64; every
+// wavefront writes {delta s_memtime, delta s_memrealtime} to out[2 * block].
+hipError_t launch_clock_probe(unsigned long long* out, uint32_t blocks, int iters, hipStream_t stream);
 
 // served stepping (copterstep_serve.hip; include/copterstep.h: cs_serve_*)
 hipError_t launch_serve(int task, int mode, const DevConst& c, const DevState& s, const cs_serve_view& v,

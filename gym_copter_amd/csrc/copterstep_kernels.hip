@@ -50,13 +50,12 @@ namespace {
 // LEAN = the common configuration (auto-reset DISABLED or NEXT_STEP, no episode statistics,
 // no done list / final_obs, time limit folded into `terminated`, uniform vehicle, float64 motor
 // model, no rotor-inertia term): the optional features are compiled out instead of being skipped
-// by uniform branches.  (cs_step_io.next_actions_dev is accepted and ignored: the kernel-side touch of the
-// next action rows measured +3.5 % per step in round 2 and was removed in round 3.)
+// by uniform branches.
 template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL>
 __device__ __forceinline__ void step_body(
     char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
-    const float* const next_actions_dev, const DevConst& c, const DevState& s_rest, const cs_step_io& io_rest) {
+    const DevConst& c, const DevState& s_rest, const cs_step_io& io_rest) {
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
@@ -66,7 +65,6 @@ __device__ __forceinline__ void step_body(
   io.reward_dev = reward_dev;
   io.terminated_dev = terminated_dev;
   io.truncated_dev = truncated_dev;
-  io.next_actions_dev = next_actions_dev;
   StepOpts o;
   o.stats = !LEAN && c.stats;
   o.trunc = !LEAN && c.tl_trunc;
@@ -75,6 +73,9 @@ __device__ __forceinline__ void step_body(
   o.gyro = !LEAN && c.gyro;
   o.act_f32 = !LEAN && c.act_f32;
   o.ticks = !LEAN && c.ticks;
+#ifdef CS_KSTAMPS
+  o.kst = nullptr;
+#endif
   constexpr int OBS = task_obs_dim(TASK);
   __shared__ __attribute__((aligned(16))) float lds[kBlock * (OBS + 2)];  // (+ 2: packed rows, dev_task.h)
 
@@ -125,7 +126,7 @@ __device__ __forceinline__ void step_body(
   store_env<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
-  if (outputs_are_packed_rows<OBS>(io.obs_dev, io.reward_dev, io.terminated_dev, io.truncated_dev)) {  // uniform
+  if (io.output_form == CS_OUTPUT_PACKED_ROWS) {  // uniform; AUTO was resolved by the launcher (resolve_output_form)
     float row2[OBS + 2];
 #pragma unroll
     for (int k = 0; k < OBS; ++k) row2[k] = out.row[k];
@@ -152,12 +153,11 @@ __device__ __forceinline__ void step_body(
      do not wait for an s_load of the argument block */                                                   \
   char *const tiles, const uint32_t n_envs, const float *const actions_dev, float *const obs_dev,         \
       float *const reward_dev, uint8_t *const terminated_dev, uint8_t *const truncated_dev,               \
-      const float *const next_actions_dev, const DevConst c, const DevState s_rest, const cs_step_io io_rest
+      const DevConst c, const DevState s_rest, const cs_step_io io_rest
 template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL>
 __global__ __launch_bounds__(kBlock) void step_kernel(CS_STEP_ARGS) {
   step_body<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL>(
-      tiles, n_envs, actions_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, next_actions_dev, c, s_rest,
-      io_rest);
+      tiles, n_envs, actions_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, c, s_rest, io_rest);
 }
 
 
@@ -193,6 +193,10 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   park_constants<MODE == CS_STATE_F64>(c);
   constexpr bool kPid = POLICY == kPolicyPid || POLICY == kPolicyPidHover;
   constexpr int NCTL = POLICY == kPolicyPidHover ? kPidControllers : 4;
+  // which terms the controllers have: decided on the kernel ARGUMENTS (scalar registers), before the gains are made
+  // vector-resident -- a test on a parked gain is a per-lane compare and an exec-mask branch (3 scalar instructions
+  // per `if`, eight of them per step), on these a scalar branch
+  const PidTerms pf = pid_terms(pc_arg);
   if constexpr (kPid) park_gains(pc);
   DevState s = s_rest;
   s.tiles = tiles;
@@ -217,6 +221,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     const typename TILE::Group t1 = tile.load_group(0);
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
+  // the on-device random policy keys every step's draw by the whole episode number: fetch its high part (if the env
+  // has one) once, here; next_episode keeps it current through the resets inside the loop
+  if constexpr (POLICY == kPolicyRandom) resolve_episode<MODE>(c, tile, e);
   const bool opt_stats = !LEAN && c.stats;
   e.ep_ret = opt_stats ? tile.load_ret() : 0.f;
   const bool opt_ticks = !LEAN && c.ticks;
@@ -229,9 +236,14 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   o.same_step = !LEAN && c.autoreset == CS_AUTORESET_SAME_STEP;
   o.gyro = !LEAN && c.gyro;
   o.act_f32 = !LEAN && c.act_f32;
+#ifdef CS_KSTAMPS
+  o.kst = nullptr;
+#endif
 
   cs_step_io io;  // no optional outputs in the K-step form
-  io.actions_dev = io.next_actions_dev = nullptr;
+  io.actions_dev = nullptr;
+  io.output_form = CS_OUTPUT_PLAIN;
+  io.reserved_ = 0;
   io.obs_dev = io.reward_dev = io.final_obs_dev = io.done_return_dev = nullptr;
   io.terminated_dev = io.truncated_dev = nullptr;
   io.done_count_dev = io.done_ids_dev = io.done_length_dev = nullptr;
@@ -261,16 +273,29 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     // body then never waits on the memory counter for its action
     asm volatile("" : "+v"(act.x), "+v"(act.y), "+v"(act.z), "+v"(act.w));
   }
+  // Everything loaded so far (the env, the controller state, the first action row) is taken delivery of HERE, once.
+  // Left to the compiler, the wait for each loaded register sits at its first use INSIDE the loop (the PID kernel
+  // had a ladder of twelve, vmcnt(15) ... vmcnt(0), at the top of its loop body), and the memory counter retires
+  // loads and stores in issue order: from the second iteration on those waits sat out the previous step's row
+  // stores -- a whole store round trip per step (round 5, found in the ISA; what the open-loop kernel's action
+  // row had in round 2).
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   for (int k = 0; k < num_steps; ++k) {
+#ifdef CS_KSTAMPS
+    // two consecutive iterations in the middle of the launch: slots [0, 16) and [16, 32) of this tile
+    o.kst = (s.stamps != nullptr && (k == num_steps / 2 || k == num_steps / 2 + 1))
+                ? s.stamps + (size_t)tile_index * kStampSlots + (k == num_steps / 2 ? 0 : 16) : nullptr;
+#endif
+    CS_KSTAMP(CS_KST(o), 0);  // loop top
     // rows of step k (64-bit uniform offsets: K * N can exceed 32 bits)
     const size_t row = (size_t)k * n;
     float4 act_next = act;
     if constexpr (kPid) {
       static_assert(OBS >= 10, "the PID heuristic reads the 3D observation");
-      act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL>(pc, ctl, seen);
+      act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL>(pc, pf, ctl, seen);
       if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
     } else if constexpr (POLICY == kPolicyRandom) {
-      const float4 a = draw_action(c, i, e.episode, (uint32_t)e.steps);
+      const float4 a = draw_action(c, i, full_episode<MODE>(e), (uint32_t)e.steps);
       // the task's own action row (1, 2 or 4 values), then its motor fan-out
       if constexpr (ACT == 4) {
         act = a;
@@ -287,6 +312,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       const int kn = (k + 1 < num_steps) ? k + 1 : k;
       act_next = load_action<TASK>(actions_dev + (size_t)kn * n * ACT, ia);  // prefetch
     }
+    CS_KSTAMP(CS_KST(o), 1);  // policy done (PID heuristic / Philox draw / next row requested)
     StepOut<OBS> out;
     advance<TASK, MODE, OBS, LEAN, ONE_CALL, true>(c, q, o, e, act, io, i, lane, valid, tile, out);
     if constexpr (kPid) {
@@ -303,10 +329,12 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       // while at the top of the next iteration the same wait would also sit out these stores' round trip.
       asm volatile("" : "+v"(act_next.x), "+v"(act_next.y), "+v"(act_next.z), "+v"(act_next.w));
     }
+    CS_KSTAMP(CS_KST(o), 7);  // controller hand-over / action row delivered
     if (valid) {
       if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
       write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
     }
+    CS_KSTAMP(CS_KST(o), 8);  // reward + flag stores issued
     if constexpr (DIRECT_ROWS) {
       // one wavefront per SIMD: instruction issue is the limit, and three row stores per lane cost fewer
       // instructions than the LDS transpose (whose full-line stores win as soon as SIMDs hold two wavefronts)
@@ -317,6 +345,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     } else {
       write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
     }
+    CS_KSTAMP(CS_KST(o), 9);   // observation row stores issued
+    CS_KSTAMP(CS_KST(o), 14);  // (two stamps back to back: what a stamp itself costs)
+    CS_KSTAMP(CS_KST(o), 15);
     act = act_next;
   }
 
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, co
     torque_model(q, mv.x, mv.y, mv.z, mv.w, w);
   }
   double px, py, pz;
-  pending_perturbation<MODE>(c, q, tile, i, e.episode, e.pend, e.expl, px, py, pz);
+  pending_perturbation<MODE>(c, q, tile, i, e.episode, e.ep_far, e.pend, e.expl, px, py, pz);
   uint32_t ticked;
   if (c.gyro) {
     ticked = physics_substeps<FULL, true, false>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
@@ -442,7 +473,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
       fe.v[3] = (T)0;
       tile.store_fe(fe);
     }
-    e.episode = next_episode(c, e.episode);
+    next_episode<MODE>(c, tile, e);
     e.reset_pending = false;
     e.steps = 1;
 #pragma unroll
@@ -523,6 +554,7 @@ __global__ __launch_bounds__(kBlock) void state_gather_kernel(const DevConst c, 
   const typename TILE::Group t2 = tile.load_group(1);
   Env<MODE> e;
   unpack_env<MODE, TILE>(c, tile.load_group(0), t2, tile.load_group(2), tile.load_group(3), e);
+  resolve_episode<MODE>(c, tile, e);
   const uint32_t meta = TILE::int_hi(t2);
   if (a.x) {
 #pragma unroll
@@ -542,14 +574,14 @@ __global__ __launch_bounds__(kBlock) void state_gather_kernel(const DevConst c, 
       f[0] = (double)fe.v[0];
       f[1] = (double)fe.v[1];
       f[2] = (double)fe.v[2];
-    } else if (e.episode != 0u) {
-      draw_force<T>(c, i, e.episode - 1u, f);
+    } else if (full_episode<MODE>(e) != 0u) {
+      draw_force<T>(c, i, full_episode<MODE>(e) - 1u, f);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) a.force[(size_t)j * n + i] = f[j];
   }
   if (a.ret) a.ret[i] = (double)tile.load_ret();
-  if (a.episode) a.episode[i] = e.episode;
+  if (a.episode) a.episode[i] = full_episode<MODE>(e);
   if (a.ticks) a.ticks[i] = c.ticks ? (int32_t)tile.load_ticks() : -1;
 }
 
@@ -592,7 +624,12 @@ __global__ __launch_bounds__(kBlock) void state_scatter_kernel(const DevConst c,
     }
     e.expl = expl;
   }
-  if (a.episode) e.episode = a.episode[i] & c.ep_mask;
+  if (a.episode) {  // the full 32-bit number: low ep_bits to the meta word, the rest to the EPH row
+    const uint32_t full = a.episode[i], hi = full >> c.ep_bits;
+    e.episode = full & c.ep_mask;
+    e.ep_far = hi != 0u ? kEpisodeFarFlag : 0u;
+    tile.store_eph(hi);
+  }
   if (a.ticks && c.ticks) tile.store_ticks((uint32_t)a.ticks[i]);
   if (a.prev) e.prev_sh = (double)(T)a.prev[i];
   store_env<MODE, TILE>(c, tile, e);
@@ -629,7 +666,9 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevConst c,
   const uint32_t meta = TILE::int_hi(t2);
   const double steps = valid ? (double)(meta & c.steps_mask) : 0.0;
   const double air = valid && (TILE::int_lo(t2) >> kStatusShift) == CS_STATUS_AIRBORNE ? 1.0 : 0.0;
-  const double epi = valid ? (double)((meta >> c.steps_bits) & c.ep_mask) : 0.0;
+  uint32_t episode = (meta >> c.steps_bits) & c.ep_mask;
+  if (__builtin_expect((TILE::int_lo(r2) & kEpisodeFarFlag) != 0u, 0)) episode |= tile.load_eph() << c.ep_bits;
+  const double epi = valid ? (double)episode : 0.0;
   const double ret = valid ? (double)tile.load_ret() : 0.0;
   // envs with a non-finite state word: upstream lets NaN / inf propagate silently (task.py:133 just casts);
   // the batch counts them (wave ballot -> one atomic per wavefront)
@@ -654,6 +693,45 @@ __global__ __launch_bounds__(kBlock) void episode_stats_kernel(const DevConst c,
   }
 }
 
+// ---------------------------------------------------------------------------------
+// cs_clock_probe: the shader clock the device holds under a float64 vector load -- what the instruction-issue
+// floors of the K-step kernels are to be priced at on THIS device (profiles/r05_ubench_f64.txt: 1.9-2.05 GHz
+// under such a load against the 2.4 GHz peak).  Eight independent accumulator chains of v_fma_f64 per wavefront,
+// nothing from memory; each wavefront notes its own delta s_memtime (shader clock) / delta s_memrealtime (100 MHz).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void clock_probe_kernel(unsigned long long* __restrict__ out, const int iters,
+                                                             const double seed) {
+  double a[8], acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = seed + 1e-9 * (double)(j + (int)threadIdx.x);
+    acc[j] = 0.5 * j;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): both clock reads have landed
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fma(acc[j], a[j], a[(j + 1) & 7]);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  double sum = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sum += acc[j];
+  if (threadIdx.x == 0) {
+    out[2 * (size_t)blockIdx.x + 0] = (t1 - t0) | (sum == 12345.678 ? 1ull : 0ull);  // (keeps the chains alive)
+    out[2 * (size_t)blockIdx.x + 1] = r1 - r0;
+  }
+}
+
 }  // namespace
 }  // namespace cs
 
@@ -663,16 +741,19 @@ namespace cs {
 namespace {
 
 template <int TASK, int MODE>
-hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io, const Tuning& tune,
+hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io_in, const Tuning& tune,
                   hipStream_t stream) {
   const dim3 grid(grid_for(s.n)), block(kBlock);
+  cs_step_io io = io_in;
+  io.output_form = resolve_output_form<task_obs_dim(TASK)>(io_in.output_form, s.n, io_in.obs_dev, io_in.reward_dev,
+                                                          io_in.terminated_dev, io_in.truncated_dev);
   const bool lean = lean_config(c, s) && io.done_count_dev == nullptr && io.final_obs_dev == nullptr;
   const uint32_t nt_act_max = tune.nt_action_max_envs ? tune.nt_action_max_envs : kNtActionMaxEnvs;
   const uint32_t nt_state_min = tune.nt_state_min_envs ? tune.nt_state_min_envs : kNtStateMinEnvs;
 #define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL)                                                  \
   hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL>), grid, block, 0, \
                      stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,   \
-                     io.truncated_dev, io.next_actions_dev, c, s, io)
+                     io.truncated_dev, c, s, io)
 #define CS_STEP_N(LEAN, STREAM_ACT, STREAM_STATE)       \
   do {                                                  \
     if (c.nsub == 1)                                    \
@@ -815,6 +896,11 @@ hipError_t launch_state_gather(int mode, const DevConst& c, const DevState& s, c
 hipError_t launch_state_scatter(int mode, const DevConst& c, const DevState& s, const StateArrays& a,
                                 hipStream_t stream) {
   CS_MODE_LAUNCH(state_scatter_kernel, c, s, a);
+}
+
+hipError_t launch_clock_probe(unsigned long long* out, uint32_t blocks, int iters, hipStream_t stream) {
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(kBlock), 0, stream, out, iters, 1.0000001);
+  return hipGetLastError();
 }
 
 hipError_t launch_reset(int task, int mode, const DevConst& c, const DevState& s,

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
   StepOpts o;
+#ifdef CS_KSTAMPS
+  o.kst = nullptr;
+#endif
   o.stats = !LEAN && c.stats;
   o.ticks = !LEAN && c.ticks;
   o.trunc = !LEAN && c.tl_trunc;
@@ -77,7 +80,9 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
   e.ep_ret = o.stats ? tile.load_ret() : 0.f;
   e.ticks = o.ticks ? tile.load_ticks() : 0u;
   cs_step_io io;  // no optional outputs in the served form
-  io.actions_dev = io.next_actions_dev = nullptr;
+  io.actions_dev = nullptr;
+  io.output_form = CS_OUTPUT_PLAIN;
+  io.reserved_ = 0;
   io.obs_dev = io.reward_dev = io.final_obs_dev = io.done_return_dev = nullptr;
   io.terminated_dev = io.truncated_dev = nullptr;
   io.done_count_dev = io.done_ids_dev = io.done_length_dev = nullptr;
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v
   constexpr int NCTL = HOVER ? kPidControllers : 4;
   const uint32_t tile = blockIdx.x, lane = threadIdx.x, i = tile * kBlock + lane;
   PidConst pc = pc_arg;
+  const PidTerms pf = pid_terms(pc_arg);  // (on the scalar kernel arguments, before the gains are parked)
   if constexpr (MANY) park_gains(pc);  // (a loop body: gains out of the scalar registers' way, as in the K-step kernels)
   uint32_t w[2 * OP];
   if constexpr (!MANY) {
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void serve_pid_kernel(const cs_serve_view v
     float seen[OBS];
 #pragma unroll
     for (int k = 0; k < OBS; ++k) seen[k] = __uint_as_float(w[k]);
-    const float4 act = pid_policy<OBS, HOVER, NCTL>(pc, ctl, seen);
+    const float4 act = pid_policy<OBS, HOVER, NCTL>(pc, pf, ctl, seen);
     const float a[4] = {act.x, act.y, act.z, act.w};
     if (!cs_serve::put_actions<2>(v, step, tile, lane, a)) break;
   }

@@ -68,11 +68,19 @@ __device__ __forceinline__ void write_flags(uint8_t* terminated, uint8_t* trunca
 // 64 rows as full 16-byte-per-lane stores through the LDS transpose (three 1 KiB stores for Lander3D) instead of
 // observation rows + a 256-byte reward store + a 128-byte flags store, i.e. one output stream instead of three
 // (-1.9 % per step at 65 536 envs, -1.4 % at 262 144: profiles/r04_ab_packed_rows.txt).
+// The form is the caller's to declare (cs_step_io.output_form, ABI 5): CS_OUTPUT_PACKED_ROWS says so outright,
+// CS_OUTPUT_PLAIN never packs, and CS_OUTPUT_AUTO (0: cs_step's four bare pointers) infers it from the pointer
+// pattern ONLY for n > 1 -- with two or more envs four separate arrays cannot have that pattern without overlapping,
+// whereas ONE env's {obs[OBS], reward, terminated, truncated} may be adjacent fields of a caller's struct that has no
+// room for the 4-byte flags word a packed row ends with.  The HOST resolves this (resolve_output_form, called by the
+// launcher): the kernel sees PLAIN or PACKED_ROWS and tests one uniform word instead of comparing four pointers.
 template <int OBS>
-__device__ __forceinline__ bool outputs_are_packed_rows(const float* obs, const float* reward, const uint8_t* term,
-                                                        const uint8_t* trunc) {
-  return obs != nullptr && reward == obs + OBS && term == reinterpret_cast<const uint8_t*>(obs + OBS + 1) &&
-         trunc == term + 1;
+inline uint32_t resolve_output_form(uint32_t form, uint32_t n, const float* obs, const float* reward,
+                                    const uint8_t* term, const uint8_t* trunc) {
+  if (form != CS_OUTPUT_AUTO) return form;
+  const bool pattern = obs != nullptr && reward == obs + OBS &&
+                       term == reinterpret_cast<const uint8_t*>(obs + OBS + 1) && trunc == term + 1;
+  return n > 1u && pattern ? (uint32_t)CS_OUTPUT_PACKED_ROWS : (uint32_t)CS_OUTPUT_PLAIN;
 }
 
 // One env's observation row straight from its lane (the K-step kernels at one wavefront per SIMD, where instruction
@@ -106,7 +114,13 @@ struct Env {
   bool pend;           // this episode's reset perturbation is not yet consumed
   bool expl;           // ... and it is the explicit force of the FE group (else: the Philox draw)
   bool reset_pending;  // NEXT_STEP: finished, resets at the next step
-  uint32_t episode;    // episodes started (DevConst::ep_mask bits, wrapping to 1)
+  // episodes started, a full 32-bit count kept in two places: `episode` = its low DevConst::ep_bits (the meta word),
+  // the rest in the tile's EPH row.  An ordinary step never reads that row: ep_far (= kEpisodeFarFlag or 0, bit 31 of
+  // gR) only says whether there is one, and the two places that need the whole number -- the reset draw (once per
+  // episode, pending_perturbation) and the carry into the high part (next_episode) -- fetch it there, inside their
+  // own rare branches.  ep_hi is the high part already shifted into place, valid only in kernels that resolved it up
+  // front (resolve_episode: the K-step kernels, whose on-device random policy keys every step's draw by the count).
+  uint32_t episode, ep_far, ep_hi;
   uint32_t ticks;      // Dynamics._ticks of this episode (kept only under cs_config.track_time)
   double prev_sh;
   float ep_ret;
@@ -122,7 +136,15 @@ struct StepOut {
 
 struct StepOpts {  // uniform switches (compiled out in LEAN builds)
   bool stats, trunc, done_list, same_step, gyro, act_f32, ticks;
+#ifdef CS_KSTAMPS
+  unsigned long long* kst;  // diagnostic build: this iteration's stamp slots, or nullptr
+#endif
 };
+#ifdef CS_KSTAMPS
+#define CS_KST(o) ((o).kst)
+#else
+#define CS_KST(o) nullptr
+#endif
 
 // the raw groups of one tile <-> Env
 template <int MODE, class TILE>
@@ -131,6 +153,12 @@ __device__ __forceinline__ void unpack_env(const DevConst& c, const typename TIL
                                            const typename TILE::Group& r2, Env<MODE>& e) {
   const uint32_t gT = TILE::int_lo(t2), meta = TILE::int_hi(t2), gR = TILE::int_lo(r2);
   e.episode = (meta >> c.steps_bits) & c.ep_mask;  // one v_bfe_u32 with uniform operands
+#ifdef CS_EXP_NOFAR  // (A/B timing build: the round-4 word handling, no high part)
+  e.ep_far = 0u;
+#else
+  e.ep_far = gR & kEpisodeFarFlag;
+#endif
+  e.ep_hi = 0u;
   e.steps = (int)(meta & c.steps_mask);
   e.prev_sh = (double)TILE::prev_of(r2);
   e.fs = (int)(gT >> kStatusShift);
@@ -154,11 +182,36 @@ __device__ __forceinline__ uint32_t pack_meta(const DevConst& c, int steps, uint
   return ((episode << c.steps_bits) | (uint32_t)steps) | (pend ? kMetaPerturbPending : 0u) |
          (expl ? kMetaExplicitForce : 0u) | (reset_pending ? kMetaResetPending : 0u);
 }
-// The episode counter after one more reset: it wraps from ep_mask to 1 (0 is "never reset"), so the Philox
-// counter word episode - 1 runs through [0, ep_mask).
-__device__ __forceinline__ uint32_t next_episode(const DevConst& c, uint32_t episode) {
-  const uint32_t n = episode + 1u;
-  return n > c.ep_mask ? 1u : n;
+// The whole episode number of an env, for kernels where one more rare branch costs nothing (K-step kernels before
+// their loop, state exchange, statistics): fetches the high part if the env has one.
+template <int MODE, class TILE>
+__device__ __forceinline__ void resolve_episode(const DevConst& c, const TILE& tile, Env<MODE>& e) {
+  if (__builtin_expect(e.ep_far != 0u, 0)) e.ep_hi = tile.load_eph() << c.ep_bits;
+}
+template <int MODE>
+__device__ __forceinline__ uint32_t full_episode(const Env<MODE>& e) {  // (after resolve_episode)
+  return e.episode | e.ep_hi;
+}
+// The episode counter after one more reset: a full 32-bit count (0 is "never reset": 2^32 - 1 is followed by 1), so
+// the Philox counter word episode - 1 runs through [0, 2^32 - 1).  The low ep_bits stay in the env's meta word; when
+// they overflow -- once per 2^ep_bits episodes of ONE env, 262 144 at the default step limit -- the carry goes to the
+// tile's EPH row, inside this rare branch; store_env puts ep_far into gR.
+template <int MODE, class TILE>
+__device__ __forceinline__ void next_episode(const DevConst& c, const TILE& tile, Env<MODE>& e) {
+  uint32_t n = e.episode + 1u;
+#ifdef CS_EXP_NOCARRY  // (A/B timing build: the round-4 wrap)
+  e.episode = n > c.ep_mask ? 1u : n;
+  return;
+#endif
+  if (__builtin_expect(n > c.ep_mask, 0)) {
+    uint32_t hi = e.ep_far != 0u ? tile.load_eph() : 0u;
+    hi = (hi + 1u) & (0xFFFFFFFFu >> c.ep_bits);
+    n = hi == 0u ? 1u : 0u;
+    tile.store_eph(hi);
+    e.ep_far = hi != 0u ? kEpisodeFarFlag : 0u;
+    e.ep_hi = hi << c.ep_bits;
+  }
+  e.episode = n;
 }
 
 template <int MODE, class TILE>
@@ -168,7 +221,7 @@ __device__ __forceinline__ void store_env(const DevConst& c, const TILE& tile, c
   words6<MODE>(e.x, w);
   words6<MODE>(e.x + 6, w + 6);
   const uint32_t gT = pack_guards6<MODE>(e.x) | ((uint32_t)e.fs << kStatusShift);
-  const uint32_t gR = pack_guards6<MODE>(e.x + 6);
+  const uint32_t gR = pack_guards6<MODE>(e.x + 6) | e.ep_far;
   typename TILE::Group t1, t2, r1, r2;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -209,8 +262,8 @@ __device__ __forceinline__ float4 load_action(const float* base, uint32_t env) {
 // the explicit force of the FE group, or this episode's Philox draw, evaluated here, where it is used.
 template <int MODE, class TILE>
 __device__ __forceinline__ void pending_perturbation(const DevConst& c, const Coef& q, const TILE& tile,
-                                                     uint32_t i, uint32_t episode, bool pend, bool expl,
-                                                     double& px, double& py, double& pz) {
+                                                     uint32_t i, uint32_t episode, uint32_t ep_far, bool pend,
+                                                     bool expl, double& px, double& py, double& pz) {
   using T = typename ModeOf<MODE>::T;
   // "none pending" is MINUS zero: a + (-0.0) == a for every a including -0.0, so the general call and the
   // free-flight call (which adds nothing) leave the same bits, also in the sign of a zero velocity -- which call a
@@ -218,6 +271,8 @@ __device__ __forceinline__ void pending_perturbation(const DevConst& c, const Co
   px = py = pz = -0.0;
   if (pend) {
     double f[3];
+    // the draw is keyed by the WHOLE episode number: an env past its 2^ep_bits-th episode has the rest in the EPH row
+    if (__builtin_expect(ep_far != 0u, 0)) episode |= tile.load_eph() << c.ep_bits;
     draw_force<T>(c, i, episode - 1u, f);
     if (__builtin_expect(expl, 0)) {  // an installed force: rare, kept out of the common path
       const Vec4<T> fe = tile.load_fe();
@@ -309,7 +364,8 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
       torque_model(q, a0, a1, a2, a3, w);
     }
     double px, py, pz;
-    pending_perturbation<MODE>(c, q, tile, i, e.episode, e.pend, e.expl, px, py, pz);
+    pending_perturbation<MODE>(c, q, tile, i, e.episode, e.ep_far, e.pend, e.expl, px, py, pz);
+    CS_KSTAMP(CS_KST(o), 2);  // clip + motor model + pending perturbation done
     bool gyro = false;
     if constexpr (!LEAN) gyro = o.gyro;
     uint32_t ticked;
@@ -321,6 +377,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     if constexpr (!LEAN) e.ticks += ticked;
   }
 
+  CS_KSTAMP(CS_KST(o), 3);  // Dynamics.setMotors done
   // ---- round to the stored precision; everything below sees exactly what is stored ----
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
@@ -329,6 +386,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)e.x[k];
   }
 
+  CS_KSTAMP(CS_KST(o), 4);  // stored-word rounding + observation row done
   // ---- reward / termination (task.py:104-130, lander.py:46-74) ----
   if (!resetting) {
     double sh = 0.0;
@@ -344,6 +402,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     e.ep_ret += (float)reward;
   }
   const bool fin = term || trunc;
+  CS_KSTAMP(CS_KST(o), 5);  // shaping potential, reward, termination done
 
   // ---- finished-episode list: wave ballot -> one atomic per wavefront ----
   if (o.done_list) {
@@ -380,7 +439,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
       e.x[k] = (double)w0;
       if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
     }
-    e.episode = next_episode(c, e.episode);
+    next_episode<MODE>(c, tile, e);
     e.fs = c.status0;
     e.pend = true;
     e.expl = false;
@@ -393,6 +452,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
   out.term = term;
   out.trunc = trunc;
   out.did_reset = do_reset;
+  CS_KSTAMP(CS_KST(o), 6);  // masked reset done
 }
 
 }  // namespace

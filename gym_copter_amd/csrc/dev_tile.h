@@ -22,6 +22,24 @@ namespace {
 #define CS_STAMP(slot) ((void)0)
 #endif
 
+// Diagnostic build only (make kstamps): shader-clock stamps at the phase boundaries of ONE loop iteration of a K-step
+// kernel (and the one after it), through a pointer that is null in every other iteration.  The stamp is one asm
+// statement between two scheduling barriers (MI355X guide: s_memtime + its own lgkmcnt(0)); it pins the phases in
+// program order -- the un-instrumented kernel lets the scheduler interleave them -- so read the shares, and the
+// cost of the stamps themselves from the back-to-back pair (slots 14 / 15).
+#ifdef CS_KSTAMPS
+#define CS_KSTAMP(kst, slot)                                                        \
+  do {                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    unsigned long long t_;                                                          \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    if ((kst) != nullptr && threadIdx.x == 0) (kst)[slot] = t_;                     \
+  } while (0)
+#else
+#define CS_KSTAMP(kst, slot) ((void)0)
+#endif
+
 #ifdef CS_SPAN
 #define CS_SPAN_BEGIN() const unsigned long long span_t0_ = __builtin_amdgcn_s_memrealtime()
 #define CS_SPAN_END()                                                                                         \
@@ -145,6 +163,13 @@ struct TileIO {
   __device__ __forceinline__ void store_group(int j, const Group& g) const { st(bg, L.grp[j], g); }
   __device__ __forceinline__ float load_ret() const { return ld<float>(b4, L.ret); }
   __device__ __forceinline__ void store_ret(float v) const { st(b4, L.ret, v); }
+  // EPH row: the episode counter's bits above the meta word's (plain accesses: once per 2^ep_bits episodes of an env)
+  __device__ __forceinline__ uint32_t load_eph() const {
+    return *reinterpret_cast<const uint32_t*>(b4 + ((int)L.eph - kBias));
+  }
+  __device__ __forceinline__ void store_eph(uint32_t hi) const {
+    *reinterpret_cast<uint32_t*>(b4 + ((int)L.eph - kBias)) = hi;
+  }
   // FE group: the EXPLICIT pending force [N] in its first three words (plain accesses: rare); the fourth
   // word is the Dynamics tick counter (cs_config.track_time), so a force is stored as three words
   __device__ __forceinline__ Vec4<T> load_fe() const {

@@ -122,6 +122,10 @@ class ShardedCopterVecEnv:
         if device is None:
             import os
             device = int(os.environ.get("LOCAL_RANK", 0))
+        if gather == "obs":
+            # the observation rows are what the collective ships: a contiguous [n_local, obs_dim] buffer that the
+            # step kernel writes directly (the default packed rows would need a .contiguous() copy every step)
+            env_kwargs.setdefault("contiguous_outputs", True)
         self.local = vecenv.CopterVecEnv(task=task, num_envs=self.n_local, device=device,
                                          env_id_base=self.env_id_base, **env_kwargs)
         self.gather = gather

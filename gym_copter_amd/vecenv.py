@@ -84,7 +84,7 @@ class CopterVecEnv(_VectorEnvBase):
                  time_limit_truncates=False, episode_stats=False, env_id_base=0,
                  max_steps=1000, vehicle_params=None, frames_per_second=None,
                  action_arith="float64", thrust_model="B", rotor_gyro=False, world_params=None,
-                 track_time=False, copy=True, **task_kwargs):
+                 track_time=False, copy=True, contiguous_outputs=False, **task_kwargs):
         # the constructor's keywords as given: what pickling reproduces (__reduce__ below), as the reference's
         # EzPickle does for its envs (task.py:23, :40)
         self._ctor_kwargs = dict(task=task, num_envs=num_envs, device=device, seed=seed, autoreset_mode=autoreset_mode,
@@ -94,7 +94,8 @@ class CopterVecEnv(_VectorEnvBase):
                                  frames_per_second=frames_per_second, action_arith=action_arith,
                                  thrust_model=thrust_model, rotor_gyro=rotor_gyro,
                                  world_params=None if world_params is None else dict(world_params),
-                                 track_time=track_time, copy=copy, **task_kwargs)
+                                 track_time=track_time, copy=copy, contiguous_outputs=contiguous_outputs,
+                                 **task_kwargs)
         lib = _lib.load()
         torch = _torch()
         if task not in _TASKS:
@@ -151,6 +152,11 @@ class CopterVecEnv(_VectorEnvBase):
         self.episode_stats = bool(episode_stats)
         self.track_time = bool(track_time)
         self.copy = bool(copy)              # as gymnasium.vector.SyncVectorEnv(copy=True): NumPy returns are the caller's
+        # Default outputs (see _open_device): up to PACKED_ROWS_MAX_ENVS envs step() / reset() return STRIDED views --
+        # the columns of one [n, obs_dim + 2] array (obs has row stride obs_dim + 2: obs.view(-1) raises, use
+        # .reshape / .contiguous()).  contiguous_outputs=True allocates four plain contiguous arrays at every size
+        # instead (+0.5 ... 2 % per step below 131 072 envs; what gather="obs" sharding and obs.view(...) callers want).
+        self.contiguous_outputs = bool(contiguous_outputs)
         self.device = torch.device("cuda", int(device))
         first, self.obs_dim, self.action_dim = _TASK_SHAPES[self.task]
         self.STATE_NAMES = STATE_NAMES_12[first:first + self.obs_dim]   # lander.py:30-31
@@ -189,12 +195,19 @@ class CopterVecEnv(_VectorEnvBase):
             # last store cost 0.6 ... 3 % (round 4).  Either way step() returns views, and the NumPy
             # convenience path ships one array to the host.
             from .sharded import row_views
-            if n <= int(os.environ.get("COPTERSTEP_PACKED_ROWS_MAX_ENVS", PACKED_ROWS_MAX_ENVS)):
+            self._flags2 = None
+            if self.contiguous_outputs:
+                self._rows = None
+                self._obs = torch.zeros((n, self.obs_dim), dtype=torch.float32, device=self.device)
+                self._reward = torch.zeros(n, dtype=torch.float32, device=self.device)
+                self._term = torch.zeros(n, dtype=torch.uint8, device=self.device)
+                self._trunc = torch.zeros(n, dtype=torch.uint8, device=self.device)
+            elif 1 < n <= int(os.environ.get("COPTERSTEP_PACKED_ROWS_MAX_ENVS", PACKED_ROWS_MAX_ENVS)):
                 self._rows = torch.zeros((n, self.obs_dim + 2), dtype=torch.float32, device=self.device)
                 self._obs, self._reward, self._term, self._trunc = row_views(self._rows, self.obs_dim)
             else:
                 self._rows = None
-                fl = torch.zeros((n, 2), dtype=torch.uint8, device=self.device)
+                fl = self._flags2 = torch.zeros((n, 2), dtype=torch.uint8, device=self.device)
                 self._obs = torch.zeros((n, self.obs_dim), dtype=torch.float32, device=self.device)
                 self._reward = torch.zeros(n, dtype=torch.float32, device=self.device)
                 self._term, self._trunc = fl[:, 0], fl[:, 1]
@@ -232,7 +245,7 @@ class CopterVecEnv(_VectorEnvBase):
             if not (interleaved or (terminated.is_contiguous() and truncated.is_contiguous())):
                 raise ValueError("bind_outputs: terminated / truncated must be contiguous uint8 (%d,) tensors, or the two "
                                  "columns of one (%d, 2) uint8 tensor" % (n, n))
-        self._rows = None                    # (the default packed array is no longer what step() writes)
+        self._rows = self._flags2 = None     # (the default arrays are no longer what step() writes)
         self._obs, self._reward, self._term, self._trunc = obs, reward, terminated, truncated
         self._cache_outputs()
 
@@ -242,6 +255,12 @@ class CopterVecEnv(_VectorEnvBase):
         torch = _torch()
         self._out_ptrs = tuple(C.c_void_p(t.data_ptr())
                                for t in (self._obs, self._reward, self._term, self._trunc))
+        # cs_step_io.output_form (ABI 5): this wrapper knows what it allocated / was bound to, and says so where it
+        # passes a cs_step_io; the bare-pointer cs_step infers the same (packed rows only for num_envs > 1, and
+        # bind_outputs / the default allocation never use them for one env)
+        n, od = self.num_envs, self.obs_dim
+        self._output_form = (_lib.OUTPUT_PACKED_ROWS if (n > 1 and self._reward.data_ptr() == self._obs.data_ptr() + 4 * od
+                                                        and self._obs.stride(0) == od + 2) else _lib.OUTPUT_PLAIN)
         self._term_b, self._trunc_b = self._term.view(torch.bool), self._trunc.view(torch.bool)
         self._dev_index = self.device.index
         # raw current-stream / current-device queries (no Stream object, no lazy-init check); fall back
@@ -441,6 +460,7 @@ class CopterVecEnv(_VectorEnvBase):
                     C.c_void_p(self._trunc.data_ptr()), self._stream()))
             else:
                 io = _lib.StepIO()
+                io.output_form = self._output_form
                 io.actions_dev = a.data_ptr()
                 io.obs_dev = self._obs.data_ptr()
                 io.reward_dev = self._reward.data_ptr()
@@ -467,15 +487,47 @@ class CopterVecEnv(_VectorEnvBase):
         return self._obs, self._reward, term, trunc, infos
 
     def _outputs_to_numpy(self):
-        """The NumPy convenience path: obs, reward and both flags cross PCIe as ONE device-to-host copy (the packed
-        rows) and the arrays returned are views of that host array (obs has row stride obs_dim + 2).  copy=True (the default, as gymnasium.vector.SyncVectorEnv):
-        a fresh buffer every step -- the arrays are the caller's to keep.  copy=False: two PINNED buffers
-        alternate (no staging copy, no allocation), so what a step returned stays valid only until the step
-        after the next one."""
+        """The NumPy convenience path.  Packed rows (the default up to PACKED_ROWS_MAX_ENVS envs): obs, reward and both
+        flags cross PCIe as ONE device-to-host copy and the arrays returned are views of that host array (obs has row
+        stride obs_dim + 2).  Plain default arrays (larger batches, contiguous_outputs=True): one copy per array
+        straight from the buffers the kernel wrote -- obs, reward and the [n,2] flags array (or the two flag arrays);
+        no device-side repacking.  Caller-bound outputs of any other shape are gathered into packed rows first.
+        copy=True (the default, as gymnasium.vector.SyncVectorEnv): fresh host buffers every step -- the arrays are
+        the caller's to keep.  copy=False: two sets of PINNED buffers alternate (no staging copy, no allocation), so
+        what a step returned stays valid only until the step after the next one."""
         torch = _torch()
         n, od = self.num_envs, self.obs_dim
         rows = self._rows
-        if rows is None:                    # outputs re-bound by the caller: gather them into packed rows first
+        plain = None
+        if rows is None:
+            if self._obs.is_contiguous() and self._reward.is_contiguous():
+                if self._flags2 is not None:
+                    plain = (self._obs, self._reward, self._flags2)
+                elif self._term.is_contiguous() and self._trunc.is_contiguous():
+                    plain = (self._obs, self._reward, self._term, self._trunc)
+        if plain is not None:
+            def host_like(t):
+                return torch.empty(t.shape, dtype=t.dtype)
+            if self.copy:
+                hosts = [host_like(t) for t in plain]
+            else:
+                sets = getattr(self, "_plain_host", None)
+                if sets is None or len(sets[0]) != len(plain):
+                    sets = self._plain_host = [[host_like(t).pin_memory() for t in plain] for _ in (0, 1)]
+                    self._pack_turn = 0
+                hosts = sets[self._pack_turn]
+                self._pack_turn ^= 1
+            for h, t in zip(hosts[:-1], plain[:-1]):
+                h.copy_(t, non_blocking=not self.copy)      # (pinned destinations: asynchronous, ordered on the stream)
+            hosts[-1].copy_(plain[-1])                      # the last one blocks: all of them have landed
+            if not self.copy:
+                torch.cuda.current_stream(self.device).synchronize()
+            hn = [h.numpy() for h in hosts]
+            if len(hn) == 3:
+                fb = hn[2].view(np.bool_)
+                return hn[0], hn[1], fb[:, 0], fb[:, 1]
+            return hn[0], hn[1], hn[2].view(np.bool_), hn[3].view(np.bool_)
+        if rows is None:                    # outputs re-bound by the caller in another shape: gather them into packed rows
             from .sharded import row_views
             rows = getattr(self, "_rows_tmp", None)
             if rows is None:
@@ -498,28 +550,6 @@ class CopterVecEnv(_VectorEnvBase):
         h = host.numpy()                                   # (shares the tensor's memory and keeps it alive)
         hb = h.view(np.bool_)                              # [n, 4 * (od + 2)]: the flag bytes are 0 / 1
         return h[:, :od], h[:, od], hb[:, 4 * (od + 1)], hb[:, 4 * (od + 1) + 1]
-
-    def step_prefetch(self, actions, next_actions):
-        """step(actions) for open-loop callers that already hold the NEXT action batch as a device
-        tensor (recorded or pre-generated actions): the kernel also touches `next_actions`' cache lines
-        so that the next launch finds them close by (cs_step_io.next_actions_dev).  Same results as
-        step(); device float32 tensors only."""
-        self._check_open()
-        torch = _torch()
-        shape = (self.num_envs, self.action_dim)
-        for t in (actions, next_actions):
-            if (not isinstance(t, torch.Tensor) or tuple(t.shape) != shape or t.dtype != torch.float32
-                    or t.device != self.device or not t.is_contiguous()):
-                raise ValueError("step_prefetch needs contiguous float32 %s tensors on %s" % (shape, self.device))
-        if self._final_obs is not None or self._done is not None:
-            raise RuntimeError("step_prefetch serves the default outputs only")
-        po, pr, pt, pu = self._out_ptrs
-        with torch.cuda.device(self.device):
-            _lib.check(self._lib.cs_step_prefetch(self._ctx, C.c_void_p(actions.data_ptr()),
-                                                  C.c_void_p(next_actions.data_ptr()), po, pr, pt, pu,
-                                                  self._stream()))
-        self._keep = (actions, next_actions)
-        return self._obs, self._reward, self._term_b, self._trunc_b, {}
 
     def step_many(self, actions):
         """K steps in ONE kernel launch for resident action batches: actions [K,N,4] ->
@@ -751,6 +781,22 @@ class CopterVecEnv(_VectorEnvBase):
         torch = _torch()
         with torch.cuda.device(self.device):
             _lib.check(self._lib.cs_pid_set_state(self._ctx, st.ctypes.data_as(C.c_void_p), self._stream()))
+
+    def clock_probe(self, waves_per_simd=4):
+        """The shader clock (Hz) this device holds under a float64 vector load (cs_clock_probe: one ~0.3 ms kernel,
+        synchronous): what the instruction-issue bounds of the K-step kernels are priced at by bench.py."""
+        self._check_open()
+        hz = C.c_double()
+        with _torch().cuda.device(self.device):
+            _lib.check(self._lib.cs_clock_probe(self._ctx, int(waves_per_simd), C.byref(hz), self._stream()))
+        return hz.value
+
+    def pci_address(self):
+        """'dddd:bb:dd.f' of this env's device (cs_device_pci_address): its sysfs node is /sys/bus/pci/devices/<it>."""
+        self._check_open()
+        buf = C.create_string_buffer(32)
+        _lib.check(self._lib.cs_device_pci_address(self._ctx, buf, 32))
+        return buf.value.decode()
 
     def close(self):                                            # task.py:139-143
         if not self.closed and self._ctx:

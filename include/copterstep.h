@@ -14,8 +14,7 @@
  *                                                               dynamics/__init__.py:71-76, vehicles/dji_phantom.py:9-26
  *   cs_seed                  _Task.seed                         envs/task.py:71-75
  *   cs_reset                 Lander.reset -> _Task._reset       envs/lander.py:35-37, envs/task.py:145-202
- *   cs_step / cs_step_ex / cs_step_prefetch
- *                            _Task.step + Lander._get_reward    envs/task.py:77-137, envs/lander.py:39-74
+ *   cs_step / cs_step_ex     _Task.step + Lander._get_reward    envs/task.py:77-137, envs/lander.py:39-74
  *                            (+ attic hover.py:18-21, hover3d.py:32-37 for CS_TASK_HOVER3D)
  *                            which calls Dynamics.setMotors     dynamics/__init__.py:114-197,249-302
  *   cs_step_many             K x _Task.step in one launch       envs/task.py:77-137 (lander.py:40-65 loop)
@@ -61,12 +60,16 @@ extern "C" {
 #endif
 
 /* ABI history.  3: next_actions_dev ignored; Philox perturbations restored as draws by cs_set_state.
- * 4: output forms of cs_step_io (interleaved flags in every stepping entry point, packed rows in cs_step / cs_step_ex /
- *    cs_step_prefetch); cs_get_launch_view checks view->struct_size; cs_set_last_error; the step counter saturates at
- *    2^S - 1 with S = bits(2 * (max_steps + 1)) (2047 at the default limit of 1000) and the episode counter has
- *    29 - S bits, wrapping from its maximum to 1 (18 bits / 262 143 episodes per env at the default limit): it is the
- *    Philox counter word of the reset draw and the random policy, and what cs_get_state / cs_episode_stats report. */
-#define CS_ABI_VERSION 4
+ * 4: output forms of cs_step_io (interleaved flags in every stepping entry point, packed rows in cs_step / cs_step_ex);
+ *    cs_get_launch_view checks view->struct_size; cs_set_last_error; the step counter saturates at 2^S - 1 with
+ *    S = bits(2 * (max_steps + 1)) (2047 at the default limit of 1000).
+ * 5: the episode counter -- the Philox counter word of the reset draw and of the random policy, what cs_get_state
+ *    reports and cs_episode_stats sums -- is a full 32-bit count again (ABI 4 kept 29 - S bits of it and wrapped after
+ *    262 143 episodes per env at the default limit; below that number ABI 5 draws exactly what ABI 4 drew), and
+ *    cs_set_state takes any uint32; cs_step_io.output_form declares the output form (packed rows are no longer
+ *    inferred for a single env); cs_step_prefetch and cs_step_io.next_actions_dev (accepted and ignored since ABI 3)
+ *    are gone; cs_clock_probe. */
+#define CS_ABI_VERSION 5
 
 typedef enum cs_status {
   CS_OK = 0,
@@ -138,7 +141,9 @@ typedef struct cs_config {
   int32_t time_limit_truncates; /* 0 = upstream (step limit folded into `terminated`) */
   int32_t episode_stats;    /* 1 = keep per-env episode return on device */
   int32_t device;           /* HIP device ordinal */
-  int32_t max_steps;        /* task.py:35; at most 2^20 - 3 */
+  int32_t max_steps;        /* task.py:35; at most 2^20 - 3.  The step counter of an env that nobody resets saturates at
+                               2^S - 1, S = bits(2 * (max_steps + 1)) (upstream's never does, task.py:130).  The episode
+                               counter is a full 32-bit count whatever the limit (ABI 5). */
   int64_t num_envs;         /* environments held by this context (this shard) */
   int64_t env_id_base;      /* global id of local env 0: keys the RNG so that a batch
                                sharded over several contexts/GPUs is shard-invariant */
@@ -180,12 +185,15 @@ typedef struct cs_step_io {
                                 kernels write each env's pair with one 2-byte store -- a wavefront then emits one
                                 full 128-byte line instead of two half lines.  Any other pair of pointers: two
                                 plain [N] arrays, as before.
-                                PACKED ROWS (ABI 4; cs_step / cs_step_ex / cs_step_prefetch): reward_dev == obs_dev +
+                                PACKED ROWS (ABI 4; cs_step / cs_step_ex): reward_dev == obs_dev +
                                 obs_dim, terminated_dev == (uint8_t*)(obs_dev + obs_dim + 1) and truncated_dev ==
                                 terminated_dev + 1 declare all four outputs the columns of ONE [N, obs_dim + 2] float32
                                 array: row i = {observation, reward, flags word (byte 0 terminated, byte 1 truncated,
-                                bytes 2-3 zero)}, written as whole rows -- one output stream instead of three.  The
-                                K-step, rollout and cs_serve_collect entry points refuse that pattern (CS_ERR_ARG). */
+                                bytes 2-3 zero)}, written as whole rows -- one output stream instead of three.  Note the
+                                footprint: a packed row ENDS with a 4-byte flags word, two bytes past truncated_dev[i].
+                                With output_form = CS_OUTPUT_AUTO the pattern is recognised for num_envs > 1 only (see
+                                output_form).  The K-step, rollout and cs_serve_collect entry points refuse that pattern
+                                (CS_ERR_ARG). */
   float* final_obs_dev;      /* [N,obs_dim]; SAME_STEP only: pre-reset observation of
                                 envs that finished this step (other rows untouched) */
   /* done-mask compaction (wave ballot): ids of the envs that finished this step,
@@ -195,12 +203,17 @@ typedef struct cs_step_io {
   int32_t* done_ids_dev;     /* [N] local env index */
   float* done_return_dev;    /* [N] (needs cfg.episode_stats) */
   int32_t* done_length_dev;  /* [N] */
-  /* Optional hint for open-loop workloads (recorded / pre-generated action batches, the "resident
-     ring" of the benchmark): the action batch the NEXT step will be given, [N,A] like actions_dev.
-     Nothing is computed from it and results do not depend on it.  Accepted and IGNORED since ABI 3: the
-     kernel-side touch of those rows measured +3.5 % per step on MI355X. */
-  const float* next_actions_dev;
+  /* ABI 5: how the four output pointers are to be read (CS_OUTPUT_*).  CS_OUTPUT_AUTO (0, what cs_step's bare
+     pointers get): interleaved flags whenever truncated_dev == terminated_dev + 1 (for one env that IS two adjacent
+     bytes, so nothing can go wrong); packed rows when the pointers have that pattern AND num_envs > 1 -- four
+     separate arrays of two or more envs cannot have it without overlapping, but ONE env's {obs, reward, terminated,
+     truncated} may be adjacent fields of a caller's struct with no room for the flags word's last two bytes.
+     CS_OUTPUT_PLAIN: never packed rows (the flags may still be interleaved).  CS_OUTPUT_PACKED_ROWS: packed rows,
+     any num_envs; CS_ERR_ARG unless the pointers have the pattern. */
+  uint32_t output_form;
+  uint32_t reserved_;        /* 0 */
 } cs_step_io;
+enum { CS_OUTPUT_AUTO = 0, CS_OUTPUT_PLAIN = 1, CS_OUTPUT_PACKED_ROWS = 2 };
 
 int cs_version(void);
 const char* cs_last_error(void);
@@ -244,10 +257,6 @@ int cs_reset_pose(cs_ctx* ctx, const uint8_t* mask_dev, const float* pose_dev, i
 int cs_step(cs_ctx* ctx, const float* actions_dev, float* obs_dev, float* reward_dev,
             uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
 int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream);
-/* cs_step with cs_step_io.next_actions_dev (see there): identical results, one more pointer. */
-int cs_step_prefetch(cs_ctx* ctx, const float* actions_dev, const float* next_actions_dev,
-                     float* obs_dev, float* reward_dev, uint8_t* terminated_dev,
-                     uint8_t* truncated_dev, void* stream);
 
 /* K consecutive steps in ONE launch for action batches that are already resident (open
  * loop: recorded or random actions, shooting-style planners).  actions_dev [K,N,4];
@@ -463,6 +472,17 @@ int cs_comm_destroy(cs_comm* comm);
 /* recv_dev [world_size * bytes] <- every rank's send_dev [bytes], in rank order */
 int cs_allgather(cs_comm* comm, const void* send_dev, void* recv_dev, int64_t bytes, void* stream);
 
+/* Diagnostic, no upstream counterpart: the shader clock this device holds under a float64 vector load.  Runs (and
+ * waits for) one ~0.3 ms kernel of dependent-free v_fma_f64 on every SIMD and reports delta s_memtime / delta
+ * s_memrealtime x 100 MHz, median over wavefronts, in Hz -- the clock the instruction-issue bounds of the K-step
+ * kernels should be priced at on THIS device (it is typically below the peak engine clock; bench.py reports both).
+ * waves_per_simd in [1, 8] wavefronts of the load per SIMD.  Synchronises `stream`. */
+int cs_clock_probe(cs_ctx* ctx, int32_t waves_per_simd, double* hz_out, void* stream);
+/* The PCI address of the context's device as "dddd:bb:dd.f" (NUL-terminated, len >= 16): lets a host find the
+ * device's sysfs node (/sys/bus/pci/devices/<address>/hwmon/...: clocks, power, temperature) without guessing
+ * which of a node's GPUs this process was given. */
+int cs_device_pci_address(const cs_ctx* ctx, char* out, int32_t len);
+
 /* Physics only: `substeps` x Dynamics.setMotors(motors[i]) on every env, raw motor
  * values (no clipping, no task logic). */
 int cs_set_motors(cs_ctx* ctx, const float* motors_dev, void* stream);
@@ -487,8 +507,8 @@ int cs_export_state(cs_ctx* ctx, float* x_dev, uint8_t* status_dev, int32_t* ste
  * flags_host it installs one only where bit2 is set and leaves the other envs on their Philox draw,
  * so that cs_set_state(everything cs_get_state returned) is a faithful restore (pending draws keep
  * following cs_seed);
- * prev_shaping NaN = upstream's None; episode_host [N] = episodes started so far per env
- * (the Philox counter word of the next reset draw); ticks_host [N] = Dynamics._ticks
+ * prev_shaping NaN = upstream's None; episode_host [N] = episodes started so far per env, a full uint32
+ * (episode - 1 is the Philox counter word of the episode's reset draw); ticks_host [N] = Dynamics._ticks
  * (cfg.track_time; -1 / ignored without it). */
 int cs_get_state(cs_ctx* ctx, double* x_host, uint8_t* status_host, int32_t* steps_host,
                  double* prev_shaping_host, double* force_xyz_host, uint8_t* flags_host,

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
   StepOpts o;
+#ifdef CS_KSTAMPS
+  o.kst = nullptr;
+#endif
   o.stats = !LEAN && c.stats;
   o.ticks = !LEAN && c.ticks;
   o.trunc = !LEAN && c.tl_trunc;
@@ -104,7 +107,9 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
   e.ep_ret = o.stats ? tile.load_ret() : 0.f;
   e.ticks = o.ticks ? tile.load_ticks() : 0u;
   cs_step_io io;  /* no optional outputs in the K-step forms */
-  io.actions_dev = io.next_actions_dev = nullptr;
+  io.actions_dev = nullptr;
+  io.output_form = CS_OUTPUT_PLAIN;
+  io.reserved_ = 0;
   io.obs_dev = io.reward_dev = io.final_obs_dev = io.done_return_dev = nullptr;
   io.terminated_dev = io.truncated_dev = nullptr;
   io.done_count_dev = io.done_ids_dev = io.done_length_dev = nullptr;
@@ -119,7 +124,17 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
 #pragma unroll
   for (int j = 0; j < OBS; ++j) seen[j] = (float)e.x[FIRST + j];
   bool fresh = false;
+  /* Everything loaded so far (the env, the policy's own state and weights) is taken delivery of HERE, once.  Left to
+     the compiler, the wait for each loaded register sits at its first use INSIDE the loop, and the memory counter
+     retires loads and stores in issue order: from the second iteration on such a wait sits out the previous step's
+     row stores -- a whole store round trip per step (round 5: -13 % per step for a 44-weight linear law). */
+  __builtin_amdgcn_s_waitcnt(0x0F70);  /* vmcnt(0) */
   for (int k = 0; k < num_steps; ++k) {
+#ifdef CS_KSTAMPS  /* diagnostic build (make kstamps; tools/kstep_stamps.py): phase stamps of two iterations */
+    o.kst = (s.stamps != nullptr && (k == num_steps / 2 || k == num_steps / 2 + 1))
+                ? s.stamps + (size_t)tile_index * kStampSlots + (k == num_steps / 2 ? 0 : 16) : nullptr;
+#endif
+    CS_KSTAMP(CS_KST(o), 0);
     const size_t row = (size_t)k * n;  /* 64-bit uniform offsets: K * N can exceed 32 bits */
     float a[ACT];
     policy(seen, i, k, fresh, a);
@@ -134,11 +149,13 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
       act = make_float4(a[0], a[0], a[0], a[0]);
       if (actions_dev != nullptr && valid) *at32<float>(actions_dev + row, ia << 2) = a[0];
     }
+    CS_KSTAMP(CS_KST(o), 1);
     StepOut<OBS> out;
     advance<TASK, MODE, OBS, LEAN, ONE_CALL, true>(c, q, o, e, act, io, i, lane, valid, tile, out);
 #pragma unroll
     for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
     fresh = out.did_reset;
+    CS_KSTAMP(CS_KST(o), 7);
     if (valid) {
       if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
       write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
@@ -150,6 +167,9 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     } else {
       write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
     }
+    CS_KSTAMP(CS_KST(o), 9);
+    CS_KSTAMP(CS_KST(o), 14);
+    CS_KSTAMP(CS_KST(o), 15);
   }
   policy.store(i, valid);
 

@@ -151,16 +151,12 @@ class VecOracle:
         self.time_limit_truncates = bool(time_limit_truncates)
         self.dt = 1. / (tp.frames_per_second * self.substeps)
         self.max_angle = np.radians(tp.max_angle)
-        # episodes started (the Philox counter word is episode - 1).  The device keeps the step counter and this
-        # counter in one 29-bit field of its meta word (copterstep_internal.h): the step counter gets the bits
-        # 2 * (max_steps + 1) needs and saturates at steps_cap (upstream's never does: task.py:130), the episode
-        # counter the rest and wraps from ep_mask to 1
+        # episodes started: a plain 32-bit count (the Philox counter word of an episode's draws is episode - 1; 0 =
+        # never reset, so 2^32 - 1 is followed by 1).  The step counter below is upstream's (task.py:130): it never
+        # saturates.  The device's storage limits (its step counter saturates at 2^S - 1: copterstep_internal.h) are NOT
+        # restated here -- a test that runs an env past them applies the documented cap in its comparison
+        # (tests/gpu_util.py: device_steps_cap).
         self.episode = np.zeros(self.n, dtype=np.uint32)
-        sbits = 1
-        while (1 << sbits) - 1 < 2 * (tp.max_steps + 1):
-            sbits += 1
-        self.steps_cap = (1 << sbits) - 1
-        self.ep_mask = (1 << (29 - sbits)) - 1
         n = self.n
         self.x = np.zeros((12, n), dtype=xdtype)          # struct-of-arrays state
         self.status = np.full(n, LANDED, dtype=np.uint8)
@@ -277,7 +273,7 @@ class VecOracle:
             self.x[:, m] = self._round(x0)
         self.status[m] = np.where(self.x[4, m].astype(np.float64) < 0, AIRBORNE, LANDED)
         nxt = self.episode[m].astype(np.int64) + 1
-        self.episode[m] = np.where(nxt > self.ep_mask, 1, nxt).astype(np.uint32)
+        self.episode[m] = np.where(nxt > 0xFFFFFFFF, 1, nxt).astype(np.uint32)
         if not perturb:
             f = np.zeros((3, int(np.sum(m))))
         elif forces is None:
@@ -385,7 +381,7 @@ class VecOracle:
         else:
             tr = np.zeros(n, dtype=bool)
             done |= limit
-        self.steps[live] = np.minimum(self.steps[live] + 1, self.steps_cap)
+        self.steps[live] = self.steps[live] + 1
 
         reward[live] = r[live]
         term[live] = done[live]

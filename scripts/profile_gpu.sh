@@ -64,6 +64,17 @@ step pmc_flops
 FL="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"
 $T rocprofv3 --pmc $FL -d $OUT/fl_c5 --output-format csv -- $LIGHT --no-graph --steps 200 --warmup 50 --regions 1 --min-region-ms 1 --ring 4 --envs 65536 --substeps 10 --actions near_hover > $OUT/fl_c5.log 2>&1
 $T rocprofv3 --pmc $FL -d $OUT/fl --output-format csv -- $SQB > $OUT/fl.log 2>&1
+step pmc_large
+# 3c. round 5: the sizes where an instruction-issue bound binds (many wavefronts per SIMD) -- executed instructions AND
+#     float64 flops of configs[4] at 1 048 576 envs, and of the K-step kernels at 4 194 304 envs (above 65 536 envs their
+#     observation rows go through the LDS transpose: a different instantiation from the 65 536-env legs); SQ_WAIT /
+#     SQ_WAVE_CYCLES in a second pass.  tools/kstep_probe.py = one leg and nothing else (eager launches).
+$T rocprofv3 --pmc $FL -d $OUT/fl_c5_1m --output-format csv -- $LIGHT --no-graph --steps 60 --warmup 20 --regions 1 --min-region-ms 1 --ring 4 --envs 1048576 --substeps 10 --actions near_hover > $OUT/fl_c5_1m.log 2>&1
+$T rocprofv3 --pmc $SQ2 -d $OUT/sq2_c5_1m --output-format csv -- $LIGHT --no-graph --steps 60 --warmup 20 --regions 1 --min-region-ms 1 --ring 4 --envs 1048576 --substeps 10 --actions near_hover > $OUT/sq2_c5_1m.log 2>&1
+for leg in many pid; do
+  $T rocprofv3 --pmc $SQ1 -d $OUT/sq1_${leg}_4m --output-format csv -- python3 $R/tools/kstep_probe.py $leg 4194304 16 3 > $OUT/sq1_${leg}_4m.log 2>&1
+  $T rocprofv3 --pmc $SQ2 -d $OUT/sq2_${leg}_4m --output-format csv -- python3 $R/tools/kstep_probe.py $leg 4194304 16 3 > $OUT/sq2_${leg}_4m.log 2>&1
+done
 step spans
 # 4. the kernel's own duration per launch, un-profiled: first wavefront start -> last wavefront end on the
 #    100 MHz clock in the span build (tools/kernel_span.py; phases not serialised)

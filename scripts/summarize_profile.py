@@ -161,7 +161,8 @@ for tag, kern, label in (("", "step_kernel<0, 0, true", "headline: Lander3D 65 5
 
 # ---- 4b. float64 arithmetic executed, by PMC (what bench.py prices config 5's float64-ALU bound with) --------------
 counts = {"valu_per_wavefront": {}, "f64_flops_per_env_step": {}, "valu_per_wavefront_step": {}}
-for key, sub, kern in (("lander3d_65536_substeps10", "fl_c5", "step_kernel<0, 0, true"), ("lander3d_65536", "fl", "step_kernel<0, 0, true")):
+for key, sub, kern in (("lander3d_65536_substeps10", "fl_c5", "step_kernel<0, 0, true"), ("lander3d_65536", "fl", "step_kernel<0, 0, true"),
+                       ("lander3d_1048576_substeps10", "fl_c5_1m", "step_kernel<0, 0, true")):
     c = counters(sub, kern)
     if c.get("SQ_WAVES"):
         w = c["SQ_WAVES"]
@@ -195,12 +196,36 @@ for name, label, k, leg in (("step_many_kernel<0, 0, true, 0,", "open loop", 64,
         counts["valu_per_wavefront_step"][leg] = per["SQ_INSTS_VALU"]
         print("%-22s (%3d steps/launch): " % (label, k) +
               "  ".join("%s %.1f" % (c.replace("SQ_INSTS_", "").replace("SQ_", ""), v) for c, v in per.items()))
+# round 5: the K-step kernels at 4 194 304 envs (64 wavefronts per SIMD; LDS-transpose instantiation), tools/kstep_probe.py
+for name, label, k, leg, subs in (("step_many_kernel<0, 0, true, 0,", "open loop, 4 M envs", 16, "step_many_4194304", ("sq1_many_4m", "sq2_many_4m")),
+                                  ("step_many_kernel<0, 0, true, 1,", "PID policy, 4 M envs", 16, "rollout_pid_4194304", ("sq1_pid_4m", "sq2_pid_4m"))):
+    m = {}
+    for sub in subs:
+        m.update(counters(sub, name))
+    if m.get("SQ_WAVES"):
+        per = {c: m[c] / m["SQ_WAVES"] / k for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD",
+                                                    "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                                                    "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU") if c in m}
+        res["pmc_k_step"][name + " @4M"] = per
+        counts["valu_per_wavefront_step"][leg] = per["SQ_INSTS_VALU"]
+        print("%-22s (%3d steps/launch): " % (label, k) +
+              "  ".join("%s %.1f" % (c.replace("SQ_INSTS_", "").replace("SQ_", ""), v) for c, v in per.items()))
+c5m = counters("sq2_c5_1m", "step_kernel<0, 0, true")
+if c5m:
+    res["pmc_c5_1m"] = c5m
+    if c5m.get("SQ_WAVE_CYCLES"):
+        print("configs[4] at 1 048 576 envs: SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f, SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = %.3f, "
+              "SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = %.3f" % (c5m.get("SQ_WAIT_ANY", 0) / c5m["SQ_WAVE_CYCLES"],
+                                                              c5m.get("SQ_WAIT_INST_ANY", 0) / c5m["SQ_WAVE_CYCLES"],
+                                                              c5m.get("SQ_ACTIVE_INST_VALU", 0) / max(c5m.get("SQ_BUSY_CYCLES", 1), 1)))
 res["pmc_counts"] = counts
 print()
 print("== issue floors from the counts above: wavefronts per SIMD x vector instructions x 4 cycles / 2.4 GHz (1 024 SIMDs) ==")
 for leg, v in counts["valu_per_wavefront_step"].items():
-    print("%-24s %6.1f VALU per wavefront and env-step -> floor %.3f us per step at 65 536 envs, ceiling %.1f G env-steps/s"
-          % (leg, v, v * 4 / 2.4e9 * 1e6, 65536 / (v * 4 / 2.4e9) / 1e9))
+    nn = int(leg.rsplit("_", 1)[1]) if leg.rsplit("_", 1)[-1].isdigit() else 65536
+    per_simd = -(-(nn // 64) // 1024)
+    print("%-24s %6.1f VALU per wavefront and env-step -> floor %.3f us per step at %d envs (%d wavefronts per SIMD), ceiling %.1f G env-steps/s"
+          % (leg, v, per_simd * v * 4 / 2.4e9 * 1e6, nn, per_simd, nn / (per_simd * v * 4 / 2.4e9) / 1e9))
 for key, v in counts["valu_per_wavefront"].items():
     n = int(key.split("_")[1])
     per_simd = -(-(n // 64) // 1024)

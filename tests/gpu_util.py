@@ -146,3 +146,22 @@ def run_with_rccl(cmd, env, timeout, cwd=None):
         print("note: ProcessGroupNCCL watchdog abort in the child (rc %d); retrying once" % p.returncode)
         p, _ = once()
     return p
+
+
+def device_steps_cap(max_steps):
+    """The device's step counter saturates at 2^S - 1, S = bits of 2 * (max_steps + 1) (copterstep_internal.h:
+    steps_bits_for; include/copterstep.h, cs_config.max_steps) -- 2047 at the default limit of 1000.  Upstream's never
+    does (task.py:130) and neither does the oracle's: a test that runs an env nobody resets past the cap compares
+    np.minimum(oracle.steps, device_steps_cap(max_steps))."""
+    s = 1
+    while (1 << s) - 1 < 2 * (max_steps + 1):
+        s += 1
+    return (1 << s) - 1
+
+
+def device_episode_bits(max_steps):
+    """Bits of the episode counter that live in the device's meta word (29 - S); the rest is in the tile's EPH row."""
+    s = 1
+    while (1 << s) - 1 < 2 * (max_steps + 1):
+        s += 1
+    return 29 - s

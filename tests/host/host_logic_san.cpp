@@ -31,6 +31,7 @@ hipError_t launch_serve_submit(const cs_serve_view&, uint32_t, const float*, hip
 hipError_t launch_serve_collect(const cs_serve_view&, int, float*, float*, uint8_t*, uint8_t*, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_serve_pid(const cs_serve_view&, uint32_t, uint32_t, const PidConst&, double*, uint32_t, hipStream_t) { return hipErrorUnknown; }
 hipError_t launch_serve_stop(uint32_t*, hipStream_t) { return hipErrorUnknown; }
+hipError_t launch_clock_probe(unsigned long long*, uint32_t, int, hipStream_t) { return hipErrorUnknown; }
 }  // namespace cs
 
 #define REQUIRE(cond)                                                        \
@@ -83,7 +84,7 @@ int main() {
       REQUIRE(std::isnan(c.reset_shaping) == !cs::task_is_lander(task));
       REQUIRE(c.gyro == 0 && c.act_f32 == 0 && c.key_force != c.key_action);
       // the two counters of the meta word at the default step limit (1000): 11 + 18 of its 29 counter bits
-      REQUIRE(c.steps_bits == 11 && c.steps_mask == 2047 && c.ep_mask == (1u << 18) - 1);
+      REQUIRE(c.steps_bits == 11 && c.steps_mask == 2047 && c.ep_mask == (1u << 18) - 1 && c.ep_bits == 18);
       REQUIRE(c.f32_pi == 3.14159274101257324f && c.f32_LB == (float)(0.35 * 5e-3));
       fake.cfg.thrust_model = CS_THRUST_LIFT;
       fake.cfg.rotor_gyro = 1;

@@ -102,6 +102,37 @@ def replay_policy(env, cache_dir):
 
 @pytest.mark.parametrize("seed", range(64))
 def test_random_configuration_and_stepping_forms_vs_oracle(seed, tmp_path_factory):
+    run_case(seed, tmp_path_factory)
+
+
+# The two seeds of the 400-seed sweep that do NOT pass (see the header): chaos after a one-unit rounding difference, not a
+# bug.  Kept as strict expected failures -- a change that makes one of them pass (or fail in another way: the second
+# test pins HOW they fail) is a change in the device's rounding behaviour and must be noticed.
+CHAOTIC = [(181, 2.7e-8), (360, 2.0e-7)]
+
+
+@pytest.mark.xfail(strict=True, reason="known chaotic divergence after a one-unit difference of the stored format "
+                                       "(auto-reset off, tumbling envs): tools/fuzz_sweep.py, rounds 3-5")
+@pytest.mark.parametrize("seed,grown", CHAOTIC)
+def test_known_chaotic_seeds_still_diverge(seed, grown, tmp_path_factory):
+    run_case(seed, tmp_path_factory)
+
+
+@pytest.mark.parametrize("seed,grown", CHAOTIC)
+def test_known_chaotic_seeds_diverge_the_way_they_were_recorded(seed, grown, tmp_path_factory):
+    """What the failure IS: a state (or float32 row) error just above the same-mode tolerance -- recorded 2.7e-8 /
+    2.0e-7 -- and nothing discrete (flags, status, counters stay equal up to that point)."""
+    import re
+    with pytest.raises(AssertionError) as ei:
+        run_case(seed, tmp_path_factory)
+    msg = str(ei.value)
+    m = re.search(r"(?:state|obs) err ([0-9.]+e[+-][0-9]+)", msg)
+    assert m is not None, "seed %d fails in a NEW way (not a state / observation tolerance): %s" % (seed, msg[:300])
+    err = float(m.group(1))
+    assert grown / 5 <= err <= grown * 5, "seed %d: recorded growth %.1e, now %.3e" % (seed, grown, err)
+
+
+def run_case(seed, tmp_path_factory):
     import torch
     cfg, kw, law, rng = draw_case(seed)
     track = bool(rng.integers(0, 2))

@@ -128,21 +128,28 @@ def test_served_collect_writes_interleaved_flags():
 # the meta word's two counters (copterstep_internal.h): episode wraps, steps saturate
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("max_steps,sbits", [(1000, 11), (5, 4), (3000, 13)])
-def test_episode_counter_wraps_and_step_counter_saturates_like_the_oracle(max_steps, sbits):
-    """The episode counter has 29 - S bits and wraps from its maximum to 1 (the Philox counter word episode - 1
-    runs through [0, max)); the step counter has S bits and saturates.  Both against the oracle, which restates
-    the same rule, across a wrap: forces drawn on the device = the oracle's draw for the wrapped number."""
+def test_episode_counter_is_a_full_32_bit_count_and_the_step_counter_saturates(max_steps, sbits):
+    """ABI 5: the episode counter is a full 32-bit count -- its low 29 - S bits in the meta word, the rest in the
+    tile's EPH row (ABI 4 wrapped it at 2^(29-S) - 1: the perturbation and random-action streams of an env repeated
+    after that many episodes).  Envs parked just below 2^(29-S), just below 2^(30-S), just below 2^32 and at small
+    numbers are flown across those boundaries under auto-reset: episode numbers, the Philox forces drawn for them and
+    the `episodes started` statistic against the oracle's plain count.  The step counter still has S bits and
+    saturates (upstream's and the oracle's never do: the documented cap is applied here, in the comparison)."""
     import torch
+    from gpu_util import device_steps_cap, device_episode_bits
     n = 300
     env, orc = make_pair("lander3d", n, "float32", "next_step", seed=21, max_steps=max_steps)
-    ep_mask = (1 << (29 - sbits)) - 1
-    assert orc.ep_mask == ep_mask and orc.steps_cap == (1 << sbits) - 1
+    ebits = device_episode_bits(max_steps)
+    assert ebits == 29 - sbits and device_steps_cap(max_steps) == (1 << sbits) - 1
+    ep_mask = (1 << ebits) - 1
     env.reset()
     orc.reset()
-    # park the counters just below the wrap (a few envs at other values)
-    ep = np.full(n, ep_mask - 1, np.uint32)
+    ep = np.full(n, ep_mask - 1, np.uint32)                # crosses into the EPH row within a few resets
     ep[::7] = ep_mask
     ep[1::7] = 5
+    ep[2::7] = 2 * (ep_mask + 1) - 2                       # already has a high part; crosses the next multiple
+    ep[3::7] = 0xFFFFFFFE                                  # the 32-bit wrap: ... 2^32 - 1, then 1
+    ep[4::7] = 0x9E3779B9                                  # an arbitrary large number
     env.set_state(episode=ep)
     orc.episode[:] = ep
     # (the reset's perturbation is still pending: the device draws it where it is consumed, under the episode number
@@ -151,7 +158,6 @@ def test_episode_counter_wraps_and_step_counter_saturates_like_the_oracle(max_st
     orc.force[:] = refvec.draw_forces(orc.seed, orc.env_ids, ep - np.uint32(1), orc.tp.initial_random_force).astype(orc.T)
     assert np.array_equal(env.get_state(only=("episode",))["episode"], ep)
     rng = np.random.default_rng(2)
-    wrapped = False
     for t in range(60):
         a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
         got, want, _ = step_both(env, orc, a)
@@ -159,22 +165,29 @@ def test_episode_counter_wraps_and_step_counter_saturates_like_the_oracle(max_st
         st = env.get_state()
         assert np.array_equal(st["episode"], orc.episode), t
         assert np.array_equal(st["force"].astype(np.float32), orc.force.astype(np.float32)), t
-        wrapped |= bool(np.any(orc.episode < 5))
-    assert wrapped and orc.episode.max() <= ep_mask and orc.episode.min() >= 1
+    e0, e1 = ep.astype(np.int64), orc.episode.astype(np.int64)
+    assert np.any((e0 <= ep_mask) & (e1 > ep_mask)), "no env crossed 2^%d" % ebits
+    assert np.any((e0 < 2 * (ep_mask + 1)) & (e0 > ep_mask) & (e1 >= 2 * (ep_mask + 1))), "no env crossed 2^%d" % (ebits + 1)
+    assert np.any((e0 > 0xFFFFFF00) & (e1 < 100) & (e1 >= 1)), "no env wrapped from 2^32 - 1 to 1"
     assert_state_close(env, orc, MODE_TOL["float32"])
-    assert float(to_np(env.batch_stats())[4]) == float(orc.episode.sum())
+    assert float(to_np(env.batch_stats())[4]) == float(orc.episode.astype(np.float64).sum())
+    # a checkpoint round trip keeps the full numbers (ABI 4 masked them silently)
+    snap = env.get_state()
+    env.set_state(**{k: v for k, v in snap.items()})
+    assert np.array_equal(env.get_state(only=("episode",))["episode"], orc.episode)
     env.close()
     # saturation: nobody resets these envs
     env, orc = make_pair("hover3d", 64, "float32", "disabled", seed=2, max_steps=max_steps)
     env.reset()
     orc.reset()
-    cap = (1 << sbits) - 1
+    cap = device_steps_cap(max_steps)
     env.set_state(steps=np.full(64, cap - 2, np.int32))
     orc.steps[:] = cap - 2
     hover = np.full((64, 4), 0.0165, np.float32)
     for t in range(5):
         step_both(env, orc, hover)
-    assert np.array_equal(env.get_state()["steps"], orc.steps) and int(orc.steps.max()) == cap
+    assert int(orc.steps.max()) == cap + 3                  # the oracle counts on, as upstream does (task.py:130)
+    assert np.array_equal(env.get_state()["steps"], np.minimum(orc.steps, cap))
     with pytest.raises(Exception, match="steps out of range"):
         env.set_state(steps=np.full(64, cap + 1, np.int32))
     env.close()
@@ -548,16 +561,19 @@ def test_bench_line_carries_span_issue_bounds_and_residency(tmp_path):
     assert d["summary"]["sweep_resident"]["lander3d_4194304_uniform"] == "hbm"
 
 
-def test_episode_counter_wraps_naturally_under_the_on_device_random_policy():
-    """No parked counters: a step limit of 100 000 leaves the episode counter 11 bits (it wraps at 2 047), and under
-    the on-device random policy (episodes of ~7 steps) nearly every env wraps within 18 400 steps.  cs_rollout_random in
-    launches of 400 steps against the oracle driven by the oracle's own draw of the same actions (keyed by seed, env
-    id, EPISODE and step: a wrong wrap changes every action after it), every step's flags and the state after every
-    launch; the random policy's and the reset perturbation's Philox counters both run through the wrap."""
+def test_episode_counter_outgrows_the_meta_word_naturally_under_the_on_device_random_policy():
+    """No parked counters: a step limit of 100 000 leaves the episode counter 11 bits in the meta word, and under
+    the on-device random policy (episodes of ~7 steps) nearly every env passes episode 2 047 within 18 400 steps -- from
+    there its number continues in the tile's EPH row (ABI 4 wrapped to 1 here).  cs_rollout_random in launches of 400
+    steps against the oracle driven by the oracle's own draw of the same actions (keyed by seed, env id, EPISODE and
+    step: a wrong episode number changes every action after it), every step's flags and the state after every launch;
+    the random policy's and the reset perturbation's Philox counters both run through the boundary, inside the K-step
+    kernel."""
     from oracle.refvec import draw_actions
     n, K, launches = 192, 400, 46
     env, orc = make_pair("lander3d", n, "float32", "next_step", seed=99, env_id_base=4096, max_steps=100000)
-    assert orc.ep_mask == 2047
+    from gpu_util import device_episode_bits
+    assert device_episode_bits(100000) == 11
     env.reset()
     orc.reset()
     ids = np.arange(4096, 4096 + n)
@@ -570,11 +586,11 @@ def test_episode_counter_wraps_naturally_under_the_on_device_random_policy():
             assert np.array_equal(a, act_k[k]), (launch, k)
             _, _, t, tr = orc.step(a.astype(np.float64))
             assert np.array_equal(term_k[k], t) and np.array_equal(trunc_k[k], tr), (launch, k)
-            wrapped |= orc.episode < before
+            wrapped |= (before <= 2047) & (orc.episode > 2047)
         st = env.get_state()
         assert np.array_equal(st["episode"], orc.episode) and np.array_equal(st["steps"], orc.steps), launch
         assert_state_close(env, orc, 2e-6, ctx="launch %d" % launch)
-    assert wrapped.mean() > 0.9 and orc.episode.max() <= 2047 and orc.episode.min() >= 1
+    assert wrapped.mean() > 0.9 and orc.episode.max() > 2047 and orc.episode.min() >= 1
     env.close()
 
 

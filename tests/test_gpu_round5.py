@@ -1,0 +1,218 @@
+"""-m gpu tests added in round 5 (ABI 5): the declared output form (cs_step_io.output_form), contiguous default outputs
+and the NumPy paths that ship them, the diagnostics bench.py prices its bounds with (cs_clock_probe,
+cs_device_pci_address), and the bench line's new blocks (clocks, region spreads, truthful CPU cores, the sweep points
+where an instruction-issue bound binds)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from gpu_util import have_gpu, make_pair, to_np
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------
+# cs_step_io.output_form (include/copterstep.h): packed rows are declared, or inferred for num_envs > 1 only
+# ---------------------------------------------------------------------------------------
+def _raw_env(n, task="lander3d"):
+    import gym_copter_amd
+    env = gym_copter_amd.CopterVecEnv(task, n, seed=5, autoreset_mode="next_step", max_steps=7)
+    env.reset()
+    return env
+
+
+def test_one_envs_adjacent_outputs_are_not_taken_for_a_packed_row():
+    """ONE env whose {obs[10], reward, terminated, truncated} are adjacent fields of a caller's struct (exactly the
+    pointer pattern of a packed row) followed by bytes that are NOT the caller's to lose: cs_step (output_form AUTO)
+    writes the two flags and nothing after them (ABI 4 wrote a 4-byte flags word there).  CS_OUTPUT_PACKED_ROWS makes
+    the same call write the whole word; a pattern that does not hold, and an unknown form, are refused."""
+    import torch
+    from gym_copter_amd import _lib
+    env = _raw_env(1)
+    lib, od = env._lib, env.obs_dim
+    buf = torch.full((64,), 0xA5, dtype=torch.uint8, device=env.device)        # 48-byte "struct" + canary bytes
+    base = buf.data_ptr()
+    assert base % 16 == 0
+    obs_p, rew_p = C.c_void_p(base), C.c_void_p(base + 4 * od)
+    term_p, trunc_p = C.c_void_p(base + 4 * (od + 1)), C.c_void_p(base + 4 * (od + 1) + 1)
+    act = torch.full((1, 4), 0.0166, device=env.device)
+    _lib.check(lib.cs_step(env._ctx, C.c_void_p(act.data_ptr()), obs_p, rew_p, term_p, trunc_p, env._stream()))
+    torch.cuda.synchronize()
+    h = buf.cpu().numpy()
+    f = 4 * (od + 1)
+    assert h[f] in (0, 1) and h[f + 1] in (0, 1), "the two flags were not written"
+    assert h[f + 2] == 0xA5 and h[f + 3] == 0xA5, "cs_step wrote past truncated[0] for a single env (inferred packed rows)"
+    assert np.all(h[f + 4:] == 0xA5)
+    obs = np.frombuffer(h[:4 * od].tobytes(), np.float32)
+    assert abs(obs[4] + 10.0) < 0.1                                            # z of a Lander just off its reset altitude
+    # declared: the whole 4-byte flags word belongs to the row
+    io = _lib.StepIO()
+    io.actions_dev, io.obs_dev, io.reward_dev = act.data_ptr(), base, base + 4 * od
+    io.terminated_dev, io.truncated_dev = base + f, base + f + 1
+    io.output_form = _lib.OUTPUT_PACKED_ROWS
+    _lib.check(lib.cs_step_ex(env._ctx, C.byref(io), env._stream()))
+    torch.cuda.synchronize()
+    h = buf.cpu().numpy()
+    assert h[f + 2] == 0 and h[f + 3] == 0 and np.all(h[f + 4:] == 0xA5)
+    # ... and refused where the pointers are not the columns of one array, or the form is unknown
+    io.reward_dev = base + 4 * od + 4
+    assert lib.cs_step_ex(env._ctx, C.byref(io), env._stream()) == _lib.ERR_ARG
+    assert b"CS_OUTPUT_PACKED_ROWS" in lib.cs_last_error()
+    io.reward_dev, io.output_form = base + 4 * od, 7
+    assert lib.cs_step_ex(env._ctx, C.byref(io), env._stream()) == _lib.ERR_ARG
+    io.output_form, io.reserved_ = _lib.OUTPUT_AUTO, 1
+    assert lib.cs_step_ex(env._ctx, C.byref(io), env._stream()) == _lib.ERR_ARG
+    env.close()
+
+
+def test_output_form_auto_still_recognises_packed_rows_of_a_batch():
+    """num_envs > 1: AUTO recognises the packed pattern through cs_step_ex as ABI 4 did (whole rows, the flags word's
+    bytes 2-3 zero), equal to the wrapper's own packed rows; the wrapper declares the form it allocated, and never
+    allocates packed rows for a single env."""
+    import torch
+    from gym_copter_amd import _lib
+    n = 130
+    env, twin = _raw_env(n), _raw_env(n)
+    lib, od = env._lib, env.obs_dim
+    rows = torch.full((n, od + 2), float("nan"), device=env.device)
+    base = rows.data_ptr()
+    act = torch.full((n, 4), 0.0166, device=env.device)
+    io = _lib.StepIO()
+    io.actions_dev, io.obs_dev, io.reward_dev = act.data_ptr(), base, base + 4 * od
+    io.terminated_dev, io.truncated_dev = base + 4 * (od + 1), base + 4 * (od + 1) + 1
+    io.output_form = _lib.OUTPUT_AUTO
+    _lib.check(lib.cs_step_ex(env._ctx, C.byref(io), env._stream()))
+    got = rows.clone()
+    o, r, t, u, _ = twin.step(act)                                    # the wrapper's own packed rows
+    assert torch.equal(got[:, :od], o) and torch.equal(got[:, od], r)
+    fw = got.view(torch.uint8).view(n, -1)[:, 4 * (od + 1):]
+    assert torch.equal(fw[:, 0].bool(), t) and torch.equal(fw[:, 1].bool(), u) and int(fw[:, 2:].sum()) == 0
+    # the wrapper declares what it allocated
+    assert twin._output_form == _lib.OUTPUT_PACKED_ROWS
+    one = _raw_env(1)
+    assert one._output_form == _lib.OUTPUT_PLAIN and one._rows is None      # a single env never gets packed rows
+    for e in (env, twin, one):
+        e.close()
+
+
+# ---------------------------------------------------------------------------------------
+# contiguous default outputs, and the NumPy convenience path of every default form
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 300, 131072 + 64])
+def test_contiguous_outputs_and_numpy_returns_agree_with_the_default_form(n):
+    """contiguous_outputs=True: four plain contiguous arrays at every size (obs.view(-1) works), same results as the
+    default form; the NumPy path ships each default form without repacking on the device (one copy for packed rows,
+    one per array for plain arrays) and returns the same values; copy=False alternates two pinned buffer sets."""
+    import torch
+    import gym_copter_amd
+    kw = dict(task="hover3d", num_envs=n, seed=9, autoreset_mode="next_step", max_steps=11)
+    d_env = gym_copter_amd.CopterVecEnv(**kw)
+    c_env = gym_copter_amd.CopterVecEnv(contiguous_outputs=True, **kw)
+    p_env = gym_copter_amd.CopterVecEnv(contiguous_outputs=True, copy=False, **kw)
+    assert c_env._obs.is_contiguous() and c_env._reward.is_contiguous() and c_env._term.is_contiguous()
+    assert c_env._rows is None and c_env._flags2 is None
+    for e in (d_env, c_env, p_env):
+        e.reset()
+    g = torch.Generator(device=d_env.device)
+    g.manual_seed(4)
+    for t in range(6):
+        a = torch.rand((n, 4), generator=g, device=d_env.device) * 2 - 1
+        rd, rc = d_env.step(a), c_env.step(a)
+        p_env.step(a)
+        assert rc[0].view(-1).shape == (n * 12,)                          # a contiguous observation array
+        for k in range(4):
+            assert torch.equal(rd[k], rc[k]), (t, k)
+    a_np = np.full((n, 4), 0.0166, np.float32)
+    nd, nc = d_env.step(a_np), c_env.step(a_np)
+    for k in range(4):
+        assert isinstance(nc[k], np.ndarray) and np.array_equal(nd[k], nc[k]), k
+    assert nc[0].flags["C_CONTIGUOUS"] and nc[2].dtype == np.bool_
+    first = p_env.step(a_np)
+    keep = [x.copy() for x in first[:4]]
+    second = p_env.step(a_np)
+    assert second[0] is not first[0] and not np.shares_memory(second[0], first[0])
+    for k in range(4):
+        assert np.array_equal(first[k], keep[k]), "copy=False: the previous step's arrays must survive ONE more step"
+    for e in (d_env, c_env, p_env):
+        e.close()
+
+
+def test_sharded_gather_obs_ships_the_buffer_the_kernel_wrote():
+    """ShardedCopterVecEnv(gather="obs"): the local env is built with contiguous outputs, so the observation rows the
+    collective ships ARE what the step kernel wrote (the packed default needed a .contiguous() copy per
+    step)."""
+    from gym_copter_amd.sharded import ShardedCopterVecEnv
+    env = ShardedCopterVecEnv(task="lander3d", total_envs=640, gather="obs", device=0, seed=2)
+    assert env.local.contiguous_outputs and env.local._obs.is_contiguous()
+    obs, _ = env.reset()
+    assert obs.is_contiguous() and obs.data_ptr() == env.local._obs.data_ptr()
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# diagnostics behind bench.py's bounds
+# ---------------------------------------------------------------------------------------
+def test_clock_probe_and_pci_address():
+    env, _ = make_pair("lander3d", 64)
+    addr = env.pci_address()
+    assert re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-7]", addr), addr
+    assert os.path.isdir("/sys/bus/pci/devices/%s" % addr)
+    hz1, hz4 = env.clock_probe(1), env.clock_probe(4)
+    assert 0.8e9 < hz4 <= hz1 * 1.1 and hz1 < 2.6e9, (hz1, hz4)     # at or below the 2.4 GHz peak engine clock
+    with pytest.raises(Exception):
+        env.clock_probe(0)
+    env.close()
+
+
+def _bench(args, tmp_path, timeout=900):
+    out = tmp_path / "line.json"
+    with open(out, "w") as f:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=f, stderr=subprocess.PIPE,
+                           text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = open(out).read().strip().splitlines()
+    assert len(lines) == 1, "stdout must carry ONE line"
+    return json.loads(lines[0])
+
+
+def test_bench_line_round5_blocks(tmp_path):
+    """The driver-form line: status, clocks (sysfs + in-kernel), region spreads on the HBM-resident points, the sweep
+    points where an instruction-issue bound binds (config 5 at 1 M envs, the K-step kernels at 4 M envs), a CPU
+    baseline whose all-core row names the cores it could use, and only the served leg that pays."""
+    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "4"], tmp_path)
+    assert d["status"] == "ok" and d["summary"]["status"] == "ok"
+    ck = d["clocks"]
+    assert 0.8 < ck["f64_load_clock_GHz"]["4"] <= 2.6 and ck["peak_engine_clock_GHz"] > 2.0
+    if ck["headline"] is not None:                       # a readable hwmon node: before / during / after
+        assert ck["headline"]["during"]["samples"] >= 3 and ck["headline"]["during"]["sclk_MHz"]["max"] > 500
+    lo, med, hi = d["roofline"]["launch_us_min_median_max"]
+    assert lo <= med <= hi and hi < 1.2 * lo
+    sweep = {(e["task"], e["envs"], e["actions"]): e for e in d["sweep"]}
+    for key in (("lander3d", 4194304, "uniform"), ("hover3d", 4194304, "uniform")):
+        e = sweep[key]
+        assert e["regions"] >= 5 and len(e["launch_us_min_median_max"]) == 3 and e["resident"] == "hbm"
+        assert e["frac_min_median_max"][0] <= e["frac"] + 1e-9 <= e["frac_min_median_max"][2] + 2e-9
+    c5 = sweep[("lander3d", 1048576, "near_hover_substeps10")]
+    assert c5["substeps"] == 10 and {b["bound"] for b in c5["bounds"]} == {"hbm", "valu_f64", "valu_f64_issue"}
+    for leg in ("step_many", "rollout_pid"):
+        e = sweep[("lander3d", 4194304, leg)]
+        assert e["steps_per_launch"] == 16 and e["roofline"]["bound"] == "valu_f64_issue"
+        if e["roofline"].get("frac") is not None:         # the PMC stamp matches this tree's kernels
+            r = e["roofline"]
+            assert r["wavefronts_per_simd"] == 64 and 0.3 < r["frac"] < 1.0 and r["frac"] < r["frac_at_measured_clock"] < 1.05
+    cpu = d["cpu_baseline"]
+    topo, allc = cpu["cpu_topology"], cpu["all_cores"]
+    assert topo["cores_usable"] <= topo["cores_in_affinity_set"] <= topo["cores_visible"]
+    if allc is not None and "value" in allc:
+        assert allc["cores"] <= topo["cores_usable"]
+        assert abs(allc["scaling_efficiency"] - allc["value"] / (cpu["value"] * allc["cores"])) < 0.15 * allc["scaling_efficiency"] + 1e-9
+        assert 0.4 < allc["scaling_efficiency"] < 1.3, allc
+    assert "served_producers_ahead" in d and "served_closed_loop" not in d and "served_closed_loop_persistent_policy" not in d
+    assert "next_action_prefetch" not in d["config"]
