@@ -102,6 +102,8 @@ def parse(argv=None):
                         "with a policy kernel per step, the same with a persistent policy kernel, and the plain-rows "
                         "compatibility form (cs_serve_submit + cs_serve_collect per step); the default run keeps "
                         "served_producers_ahead only")
+    p.add_argument("--no-clock-sampling", action="store_true",
+                   help="do not read the device's hwmon sensors (sclk / power / temperature) around the timed regions")
     p.add_argument("--no-span", action="store_true",
                    help="skip the kernel-only span figure (a child process on the span build, before this one touches the GPU)")
     p.add_argument("--served-graph", type=int, default=-1, help="diagnostic: feeders of the served legs from a hipGraph (1) "
@@ -790,7 +792,7 @@ def main(argv=None):
         span = kernel_span_child(a.task, a.envs, a.actions, a.substeps)
 
     # the clock / power / temperature reader: a child process, started before this one touches the GPU
-    sampler_proc = ClockSampler() if rank == 0 and world == 1 else None
+    sampler_proc = ClockSampler() if rank == 0 and world == 1 and not a.no_clock_sampling else None
 
     import torch
     dist = None

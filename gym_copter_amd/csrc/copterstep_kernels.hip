@@ -53,8 +53,8 @@ namespace {
 // by uniform branches.
 template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL>
 __device__ __forceinline__ void step_body(
-    char* const tiles, const uint32_t n_envs, const float* const actions_dev, float* const obs_dev,
-    float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
+    char* const tiles, const uint32_t n_envs, const uint32_t output_form, const float* const actions_dev,
+    float* const obs_dev, float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
     const DevConst& c, const DevState& s_rest, const cs_step_io& io_rest) {
   DevState s = s_rest;
   s.tiles = tiles;
@@ -65,6 +65,7 @@ __device__ __forceinline__ void step_body(
   io.reward_dev = reward_dev;
   io.terminated_dev = terminated_dev;
   io.truncated_dev = truncated_dev;
+  io.output_form = output_form;
   StepOpts o;
   o.stats = !LEAN && c.stats;
   o.trunc = !LEAN && c.tl_trunc;
@@ -126,7 +127,7 @@ __device__ __forceinline__ void step_body(
   store_env<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
-  if (io.output_form == CS_OUTPUT_PACKED_ROWS) {  // uniform; AUTO was resolved by the launcher (resolve_output_form)
+  if (io.output_form == CS_OUTPUT_PACKED_ROWS) {  // uniform and preloaded; AUTO was resolved by the launcher
     float row2[OBS + 2];
 #pragma unroll
     for (int k = 0; k < OBS; ++k) row2[k] = out.row[k];
@@ -141,6 +142,7 @@ __device__ __forceinline__ void step_body(
     write_rows<OBS>(io.obs_dev, lds, lane, env0, n, valid, out.row);
   }
   CS_STAMP(6);
+  finish_carry<MODE, TILE>(c, tile, e);  // (rare; behind every store of the step)
 #ifdef CS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -149,15 +151,19 @@ __device__ __forceinline__ void step_body(
 }
 
 #define CS_STEP_ARGS                                                                                      \
-  /* leading scalar arguments: preloaded into SGPRs with the wave (kernarg preload), so the first loads  \
-     do not wait for an s_load of the argument block */                                                   \
-  char *const tiles, const uint32_t n_envs, const float *const actions_dev, float *const obs_dev,         \
-      float *const reward_dev, uint8_t *const terminated_dev, uint8_t *const truncated_dev,               \
-      const DevConst c, const DevState s_rest, const cs_step_io io_rest
+  /* leading scalar arguments: preloaded into SGPRs with the wave (kernarg preload, 16 dwords), so the    \
+     first loads do not wait for an s_load of the argument block -- and neither does the choice of the    \
+     output form at the end (round 5: read from the tail of the block it cost Hover3D 262 144 2.4 %).      \
+     kernarg_pad keeps DevConst on a 64-byte boundary of the block, where round 4 had it: at 0x38 the     \
+     same kernel was 3.9 % slower at that point (profiles/r05_ab_argument_block.txt) */                   \
+  char *const tiles, const uint32_t n_envs, const uint32_t output_form, const float *const actions_dev,  \
+      float *const obs_dev, float *const reward_dev, uint8_t *const terminated_dev,                       \
+      uint8_t *const truncated_dev, const uint64_t kernarg_pad, const DevConst c, const DevState s_rest,  \
+      const cs_step_io io_rest
 template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL>
 __global__ __launch_bounds__(kBlock) void step_kernel(CS_STEP_ARGS) {
   step_body<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL>(
-      tiles, n_envs, actions_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, c, s_rest, io_rest);
+      tiles, n_envs, output_form, actions_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, c, s_rest, io_rest);
 }
 
 
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   }
 
   store_env<MODE, TILE>(c, tile, e);
+  finish_carry<MODE, TILE>(c, tile, e);
   if (opt_stats) tile.store_ret(e.ep_ret);
   if (opt_ticks) tile.store_ticks(e.ticks);
   if constexpr (kPid) {
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
       fe.v[3] = (T)0;
       tile.store_fe(fe);
     }
-    next_episode<MODE>(c, tile, e);
+    next_episode<MODE>(e);
     e.reset_pending = false;
     e.steps = 1;
 #pragma unroll
@@ -501,6 +508,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
       }
     }
     store_env<MODE, TILE>(c, tile, e);
+    finish_carry<MODE, TILE>(c, tile, e);
     tile.store_ret(0.f);
     if (c.ticks) tile.store_ticks(0u);  // a new Dynamics object (task.py:161)
   }
@@ -752,8 +760,8 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io_in,
   const uint32_t nt_state_min = tune.nt_state_min_envs ? tune.nt_state_min_envs : kNtStateMinEnvs;
 #define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL)                                                  \
   hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL>), grid, block, 0, \
-                     stream, s.tiles, s.n, io.actions_dev, io.obs_dev, io.reward_dev, io.terminated_dev,   \
-                     io.truncated_dev, c, s, io)
+                     stream, s.tiles, s.n, io.output_form, io.actions_dev, io.obs_dev, io.reward_dev,      \
+                     io.terminated_dev, io.truncated_dev, (uint64_t)0, c, s, io)
 #define CS_STEP_N(LEAN, STREAM_ACT, STREAM_STATE)       \
   do {                                                  \
     if (c.nsub == 1)                                    \

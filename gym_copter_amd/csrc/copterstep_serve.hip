@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
   }
 
   store_env<MODE, TILE>(c, tile, e);
+  finish_carry<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
   if (lane == 0) {

@@ -114,12 +114,14 @@ struct Env {
   bool pend;           // this episode's reset perturbation is not yet consumed
   bool expl;           // ... and it is the explicit force of the FE group (else: the Philox draw)
   bool reset_pending;  // NEXT_STEP: finished, resets at the next step
-  // episodes started, a full 32-bit count kept in two places: `episode` = its low DevConst::ep_bits (the meta word),
-  // the rest in the tile's EPH row.  An ordinary step never reads that row: ep_far (= kEpisodeFarFlag or 0, bit 31 of
-  // gR) only says whether there is one, and the two places that need the whole number -- the reset draw (once per
-  // episode, pending_perturbation) and the carry into the high part (next_episode) -- fetch it there, inside their
-  // own rare branches.  ep_hi is the high part already shifted into place, valid only in kernels that resolved it up
-  // front (resolve_episode: the K-step kernels, whose on-device random policy keys every step's draw by the count).
+  // episodes started, a full 32-bit count kept in two places: its low DevConst::ep_bits in the meta word, the rest in
+  // the tile's EPH row.  An ordinary step never reads that row: ep_far (= kEpisodeFarFlag or 0, bit 31 of gR) only
+  // says whether there is one.  `episode` holds the low part PLUS whatever this launch's resets have added to it
+  // (next_episode is a plain increment, so it may exceed ep_mask until finish_carry() moves the overflow into the
+  // EPH row, after the launch's last store).  The whole number -- full_episode() -- is needed by the reset draw (once
+  // per episode: pending_perturbation fetches the high part there, inside its own rare branch) and by the on-device
+  // random policy (every step: the K-step kernels fetch it once up front, resolve_episode -> ep_hi, already shifted
+  // into place).
   uint32_t episode, ep_far, ep_hi;
   uint32_t ticks;      // Dynamics._ticks of this episode (kept only under cs_config.track_time)
   double prev_sh;
@@ -188,30 +190,23 @@ template <int MODE, class TILE>
 __device__ __forceinline__ void resolve_episode(const DevConst& c, const TILE& tile, Env<MODE>& e) {
   if (__builtin_expect(e.ep_far != 0u, 0)) e.ep_hi = tile.load_eph() << c.ep_bits;
 }
+// high part (shifted) + low part with its pending overflow.  0 is "never reset" and is skipped when the count wraps
+// (2^32 - 1 is followed by 1): a carry out of the 32-bit sum adds one.
+__device__ __forceinline__ uint32_t whole_episode(uint32_t hi_shifted, uint32_t low) {
+  const uint32_t v = hi_shifted + low;
+  return v + (v < hi_shifted ? 1u : 0u);
+}
 template <int MODE>
 __device__ __forceinline__ uint32_t full_episode(const Env<MODE>& e) {  // (after resolve_episode)
-  return e.episode | e.ep_hi;
+  return whole_episode(e.ep_hi, e.episode);
 }
-// The episode counter after one more reset: a full 32-bit count (0 is "never reset": 2^32 - 1 is followed by 1), so
-// the Philox counter word episode - 1 runs through [0, 2^32 - 1).  The low ep_bits stay in the env's meta word; when
-// they overflow -- once per 2^ep_bits episodes of ONE env, 262 144 at the default step limit -- the carry goes to the
-// tile's EPH row, inside this rare branch; store_env puts ep_far into gR.
-template <int MODE, class TILE>
-__device__ __forceinline__ void next_episode(const DevConst& c, const TILE& tile, Env<MODE>& e) {
-  uint32_t n = e.episode + 1u;
-#ifdef CS_EXP_NOCARRY  // (A/B timing build: the round-4 wrap)
-  e.episode = n > c.ep_mask ? 1u : n;
-  return;
-#endif
-  if (__builtin_expect(n > c.ep_mask, 0)) {
-    uint32_t hi = e.ep_far != 0u ? tile.load_eph() : 0u;
-    hi = (hi + 1u) & (0xFFFFFFFFu >> c.ep_bits);
-    n = hi == 0u ? 1u : 0u;
-    tile.store_eph(hi);
-    e.ep_far = hi != 0u ? kEpisodeFarFlag : 0u;
-    e.ep_hi = hi << c.ep_bits;
-  }
-  e.episode = n;
+
+// One more reset: a plain increment of the low part (the Philox counter word of the new episode's draws is
+// full_episode() - 1).  The overflow of the low ep_bits -- once per 2^ep_bits episodes of ONE env, 262 144 at the
+// default step limit -- stays in the register until finish_carry().
+template <int MODE>
+__device__ __forceinline__ void next_episode(Env<MODE>& e) {
+  e.episode += 1u;
 }
 
 template <int MODE, class TILE>
@@ -221,7 +216,10 @@ __device__ __forceinline__ void store_env(const DevConst& c, const TILE& tile, c
   words6<MODE>(e.x, w);
   words6<MODE>(e.x + 6, w + 6);
   const uint32_t gT = pack_guards6<MODE>(e.x) | ((uint32_t)e.fs << kStatusShift);
-  const uint32_t gR = pack_guards6<MODE>(e.x + 6) | e.ep_far;
+  // (the far flag also for a carry that finish_carry() is about to move into the EPH row: 0 - over has bit 31 set for
+  // every over in [1, 2^31])
+  const uint32_t over = e.episode >> c.ep_bits;
+  const uint32_t gR = pack_guards6<MODE>(e.x + 6) | ((e.ep_far | (0u - over)) & kEpisodeFarFlag);
   typename TILE::Group t1, t2, r1, r2;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -232,12 +230,31 @@ __device__ __forceinline__ void store_env(const DevConst& c, const TILE& tile, c
   t2.v[1] = as_bits(w[5]);
   r2.v[0] = as_bits(w[10]);
   r2.v[1] = as_bits(w[11]);
-  TILE::set_t2(t2, gT, pack_meta(c, e.steps, e.episode, e.pend, e.expl, e.reset_pending));
+  TILE::set_t2(t2, gT, pack_meta(c, e.steps, e.episode & c.ep_mask, e.pend, e.expl, e.reset_pending));
   TILE::set_r2(r2, gR, (T)e.prev_sh);
   tile.store_group(0, t1);
   tile.store_group(1, t2);
   tile.store_group(2, r1);
   tile.store_group(3, r2);
+}
+
+// After the launch's last store_env: move what this launch's resets carried out of the low ep_bits into the tile's
+// EPH row (rare: see Env).  Wrapping past 2^32 - 1 skips 0 (0 = never reset): the stored number is then rewritten.
+template <int MODE, class TILE>
+__device__ __forceinline__ void finish_carry(const DevConst& c, const TILE& tile, Env<MODE>& e) {
+  const uint32_t over = e.episode >> c.ep_bits;
+  if (__builtin_expect(over != 0u, 0)) {
+    const uint32_t hi_mask = 0xFFFFFFFFu >> c.ep_bits;
+    const uint32_t hi = (e.ep_far != 0u ? tile.load_eph() : 0u) + over;
+    tile.store_eph(hi & hi_mask);
+    e.episode &= c.ep_mask;
+    e.ep_far = (hi & hi_mask) != 0u ? kEpisodeFarFlag : 0u;
+    e.ep_hi = (hi & hi_mask) << c.ep_bits;
+    if (hi > hi_mask) {  // wrapped past 2^32 - 1: one more (0 is skipped), and the groups again with the new number
+      e.episode += 1u;
+      store_env<MODE, TILE>(c, tile, e);
+    }
+  }
 }
 
 // One action row -> the four motor demands: _get_motors (lander.py:95-97 for the 3D tasks; the
@@ -272,7 +289,7 @@ __device__ __forceinline__ void pending_perturbation(const DevConst& c, const Co
   if (pend) {
     double f[3];
     // the draw is keyed by the WHOLE episode number: an env past its 2^ep_bits-th episode has the rest in the EPH row
-    if (__builtin_expect(ep_far != 0u, 0)) episode |= tile.load_eph() << c.ep_bits;
+    if (__builtin_expect(ep_far != 0u, 0)) episode = whole_episode(tile.load_eph() << c.ep_bits, episode);
     draw_force<T>(c, i, episode - 1u, f);
     if (__builtin_expect(expl, 0)) {  // an installed force: rare, kept out of the common path
       const Vec4<T> fe = tile.load_fe();
@@ -439,7 +456,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
       e.x[k] = (double)w0;
       if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
     }
-    next_episode<MODE>(c, tile, e);
+    next_episode<MODE>(e);
     e.fs = c.status0;
     e.pend = true;
     e.expl = false;

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
   policy.store(i, valid);
 
   store_env<MODE, TILE>(c, tile, e);
+  finish_carry<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
 }

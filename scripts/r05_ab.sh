@@ -10,6 +10,6 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 B=gym_copter_amd/csrc/build
-timeout 2400 python3 tools/ab_cfg.py --libs base=gym_copter_amd/libcopterstep.so tb5376=$B/libcopterstep_tb5376.so nocarry=$B/libcopterstep_nocarry.so r4like=$B/libcopterstep_r4like.so r4all=$B/libcopterstep_r4all.so \
-  --cfgs "262144 uniform 1 hover3d" "65536 uniform 1" "262144 uniform 1" "1048576 uniform 1 hover3d" --reps 3 > $OUT/ab_round5_additions.txt 2>&1
+timeout 2400 python3 tools/ab_cfg.py --libs base=gym_copter_amd/libcopterstep.so r4all=$B/libcopterstep_r4all.so r4pad=$B/libcopterstep_r4pad.so r4padptr=$B/libcopterstep_r4padptr.so \
+  --cfgs "262144 uniform 1 hover3d" "65536 uniform 1" "65536 near_hover 10" --reps 3 > $OUT/ab_round5_additions.txt 2>&1
 cat $OUT/ab_round5_additions.txt
