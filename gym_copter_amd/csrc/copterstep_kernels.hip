@@ -194,6 +194,10 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // and fetches back with v_readlane in every iteration.  Vector registers are plentiful at
   // this occupancy, so the constants used deep inside the step (sin/cos coefficients,
   // controller gains, reward constants) are made vector-resident up front instead.
+  // (The DIRECT_ROWS instantiations are the ones for <= 65 536 envs -- one wavefront per SIMD, where registers are free.
+  // The others run with as many wavefronts per SIMD as their registers allow, and there a parked constant costs
+  // occupancy: the PID kernel at 254 registers held ONE wavefront per SIMD at 4 M envs.  They leave the constants where
+  // the compiler puts them.)
   DevConst c = c_arg;
   PidConst pc = pc_arg;
   park_constants<MODE == CS_STATE_F64>(c);
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // vector-resident -- a test on a parked gain is a per-lane compare and an exec-mask branch (3 scalar instructions
   // per `if`, eight of them per step), on these a scalar branch
   const PidTerms pf = pid_terms(pc_arg);
-  if constexpr (kPid) park_gains(pc);
+  if constexpr (kPid && DIRECT_ROWS) park_gains(pc);
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     float4 act_next = act;
     if constexpr (kPid) {
       static_assert(OBS >= 10, "the PID heuristic reads the 3D observation");
-      act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL>(pc, pf, ctl, seen);
+      act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL, DIRECT_ROWS>(pc, pf, ctl, seen);
       if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
     } else if constexpr (POLICY == kPolicyRandom) {
       const float4 a = draw_action(c, i, full_episode<MODE>(e), (uint32_t)e.steps);
