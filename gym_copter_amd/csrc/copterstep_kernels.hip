@@ -231,9 +231,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     const typename TILE::Group t1 = tile.load_group(0);
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
-  // the on-device random policy keys every step's draw by the whole episode number: fetch its high part (if the env
-  // has one) once, here; next_episode keeps it current through the resets inside the loop
-  if constexpr (POLICY == kPolicyRandom) resolve_episode<MODE>(c, tile, e);
+  // the reset draws inside the loop (and every step's draw of the on-device random policy) are keyed by the whole
+  // episode number: fetch its high part (if the env has one) once, here -- no branch for it inside the loop
+  resolve_episode<MODE>(c, tile, e);
   const bool opt_stats = !LEAN && c.stats;
   e.ep_ret = opt_stats ? tile.load_ret() : 0.f;
   const bool opt_ticks = !LEAN && c.ticks;
@@ -289,7 +289,9 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // loads and stores in issue order: from the second iteration on those waits sat out the previous step's row
   // stores -- a whole store round trip per step (round 5, found in the ISA; what the open-loop kernel's action
   // row had in round 2).
+#ifndef CS_EXP_NOPREWAIT  // (A/B timing build)
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
   for (int k = 0; k < num_steps; ++k) {
 #ifdef CS_KSTAMPS
     // two consecutive iterations in the middle of the launch: slots [0, 16) and [16, 32) of this tile
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL, DIRECT_ROWS>(pc, pf, ctl, seen);
       if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
     } else if constexpr (POLICY == kPolicyRandom) {
-      const float4 a = draw_action(c, i, full_episode<MODE>(e), (uint32_t)e.steps);
+      const float4 a = draw_action(c, i, e.episode, (uint32_t)e.steps);
       // the task's own action row (1, 2 or 4 values), then its motor fan-out
       if constexpr (ACT == 4) {
         act = a;
@@ -361,8 +363,8 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     act = act_next;
   }
 
+  split_episode<MODE>(c, tile, e);
   store_env<MODE, TILE>(c, tile, e);
-  finish_carry<MODE, TILE>(c, tile, e);
   if (opt_stats) tile.store_ret(e.ep_ret);
   if (opt_ticks) tile.store_ticks(e.ticks);
   if constexpr (kPid) {
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
       fe.v[3] = (T)0;
       tile.store_fe(fe);
     }
-    next_episode<MODE>(e);
+    next_episode<MODE, false>(e);
     e.reset_pending = false;
     e.steps = 1;
 #pragma unroll
@@ -586,14 +588,14 @@ __global__ __launch_bounds__(kBlock) void state_gather_kernel(const DevConst c, 
       f[0] = (double)fe.v[0];
       f[1] = (double)fe.v[1];
       f[2] = (double)fe.v[2];
-    } else if (full_episode<MODE>(e) != 0u) {
-      draw_force<T>(c, i, full_episode<MODE>(e) - 1u, f);
+    } else if (e.episode != 0u) {  // (the whole number: resolve_episode above)
+      draw_force<T>(c, i, e.episode - 1u, f);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) a.force[(size_t)j * n + i] = f[j];
   }
   if (a.ret) a.ret[i] = (double)tile.load_ret();
-  if (a.episode) a.episode[i] = full_episode<MODE>(e);
+  if (a.episode) a.episode[i] = e.episode;
   if (a.ticks) a.ticks[i] = c.ticks ? (int32_t)tile.load_ticks() : -1;
 }
 

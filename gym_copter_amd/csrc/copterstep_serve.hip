@@ -66,6 +66,7 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
     const typename TILE::Group t1 = tile.load_group(0);
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
+  resolve_episode<MODE>(c, tile, e);  /* the reset draws inside the loop are keyed by the whole episode number */
   StepOpts o;
 #ifdef CS_KSTAMPS
   o.kst = nullptr;
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
     done = step + 1u;
   }
 
+  split_episode<MODE>(c, tile, e);
   store_env<MODE, TILE>(c, tile, e);
-  finish_carry<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
   if (lane == 0) {

@@ -115,13 +115,14 @@ struct Env {
   bool expl;           // ... and it is the explicit force of the FE group (else: the Philox draw)
   bool reset_pending;  // NEXT_STEP: finished, resets at the next step
   // episodes started, a full 32-bit count kept in two places: its low DevConst::ep_bits in the meta word, the rest in
-  // the tile's EPH row.  An ordinary step never reads that row: ep_far (= kEpisodeFarFlag or 0, bit 31 of gR) only
-  // says whether there is one.  `episode` holds the low part PLUS whatever this launch's resets have added to it
-  // (next_episode is a plain increment, so it may exceed ep_mask until finish_carry() moves the overflow into the
-  // EPH row, after the launch's last store).  The whole number -- full_episode() -- is needed by the reset draw (once
-  // per episode: pending_perturbation fetches the high part there, inside its own rare branch) and by the on-device
-  // random policy (every step: the K-step kernels fetch it once up front, resolve_episode -> ep_hi, already shifted
-  // into place).
+  // the tile's EPH row, which an ordinary step never reads: ep_far (= kEpisodeFarFlag or 0, bit 31 of gR) only says
+  // whether there is a high part.  Two regimes:
+  //  * one launch per step (step_kernel, reset_kernel): `episode` = the low part plus whatever this launch's reset added
+  //    (next_episode is a plain increment; finish_carry() moves an overflow into the EPH row after the last store).  The
+  //    reset draw -- once per episode -- fetches the high part where it draws, inside its own rare branch.
+  //  * K steps per launch (and the state exchange / statistics kernels): resolve_episode() fetches the high part ONCE,
+  //    before the loop, and `episode` is the WHOLE number from then on (ep_hi remembers what the row holds);
+  //    split_episode() undoes that before store_env.  Nothing of this is inside the loop.
   uint32_t episode, ep_far, ep_hi;
   uint32_t ticks;      // Dynamics._ticks of this episode (kept only under cs_config.track_time)
   double prev_sh;
@@ -184,29 +185,42 @@ __device__ __forceinline__ uint32_t pack_meta(const DevConst& c, int steps, uint
   return ((episode << c.steps_bits) | (uint32_t)steps) | (pend ? kMetaPerturbPending : 0u) |
          (expl ? kMetaExplicitForce : 0u) | (reset_pending ? kMetaResetPending : 0u);
 }
-// The whole episode number of an env, for kernels where one more rare branch costs nothing (K-step kernels before
-// their loop, state exchange, statistics): fetches the high part if the env has one.
-template <int MODE, class TILE>
-__device__ __forceinline__ void resolve_episode(const DevConst& c, const TILE& tile, Env<MODE>& e) {
-  if (__builtin_expect(e.ep_far != 0u, 0)) e.ep_hi = tile.load_eph() << c.ep_bits;
-}
 // high part (shifted) + low part with its pending overflow.  0 is "never reset" and is skipped when the count wraps
 // (2^32 - 1 is followed by 1): a carry out of the 32-bit sum adds one.
 __device__ __forceinline__ uint32_t whole_episode(uint32_t hi_shifted, uint32_t low) {
   const uint32_t v = hi_shifted + low;
   return v + (v < hi_shifted ? 1u : 0u);
 }
-template <int MODE>
-__device__ __forceinline__ uint32_t full_episode(const Env<MODE>& e) {  // (after resolve_episode)
-  return whole_episode(e.ep_hi, e.episode);
+// K-step kernels, state exchange, statistics: the whole episode number into e.episode, once (fetches the high part if
+// the env has one; e.ep_hi = what the EPH row holds).
+template <int MODE, class TILE>
+__device__ __forceinline__ void resolve_episode(const DevConst& c, const TILE& tile, Env<MODE>& e) {
+  e.ep_hi = 0u;
+  if (__builtin_expect(e.ep_far != 0u, 0)) e.ep_hi = tile.load_eph();
+  e.episode |= e.ep_hi << c.ep_bits;
+}
+// ... and back, before store_env: low part, far flag, and the EPH row if the high part changed (rare).
+template <int MODE, class TILE>
+__device__ __forceinline__ void split_episode(const DevConst& c, const TILE& tile, Env<MODE>& e) {
+  const uint32_t hi = e.episode >> c.ep_bits;
+  if (__builtin_expect(hi != e.ep_hi, 0)) tile.store_eph(hi);
+  e.ep_hi = hi;
+  e.ep_far = hi != 0u ? kEpisodeFarFlag : 0u;
+  e.episode &= c.ep_mask;
 }
 
-// One more reset: a plain increment of the low part (the Philox counter word of the new episode's draws is
-// full_episode() - 1).  The overflow of the low ep_bits -- once per 2^ep_bits episodes of ONE env, 262 144 at the
-// default step limit -- stays in the register until finish_carry().
-template <int MODE>
+// One more reset (the Philox counter word of the new episode's draws is the whole number - 1).  WHOLE (resolved
+// kernels): the 32-bit count itself, 2^32 - 1 followed by 1.  Otherwise a plain increment of the low part: its overflow
+// -- once per 2^ep_bits episodes of ONE env, 262 144 at the default step limit -- stays in the register until
+// finish_carry().
+template <int MODE, bool WHOLE>
 __device__ __forceinline__ void next_episode(Env<MODE>& e) {
-  e.episode += 1u;
+  const uint32_t n = e.episode + 1u;
+  if constexpr (WHOLE) {
+    e.episode = n == 0u ? 1u : n;
+  } else {
+    e.episode = n;
+  }
 }
 
 template <int MODE, class TILE>
@@ -277,7 +291,10 @@ __device__ __forceinline__ float4 load_action(const float* base, uint32_t env) {
 
 // The pending reset perturbation of an env in its doubled form 2*F/M (dynamics :263-271 + :183):
 // the explicit force of the FE group, or this episode's Philox draw, evaluated here, where it is used.
-template <int MODE, class TILE>
+// RESOLVED: `episode` is the whole number already (resolve_episode: the K-step kernels, before their loop) -- nothing to
+// fetch and no branch here (the exec-mask branch of the lazy form cost the K-step kernels 1.5-3 % per step).  Otherwise
+// `episode` is the low part, `ep_far` the far flag, and the high part is fetched here, inside this already-rare path.
+template <int MODE, bool RESOLVED = false, class TILE>
 __device__ __forceinline__ void pending_perturbation(const DevConst& c, const Coef& q, const TILE& tile,
                                                      uint32_t i, uint32_t episode, uint32_t ep_far, bool pend,
                                                      bool expl, double& px, double& py, double& pz) {
@@ -289,7 +306,9 @@ __device__ __forceinline__ void pending_perturbation(const DevConst& c, const Co
   if (pend) {
     double f[3];
     // the draw is keyed by the WHOLE episode number: an env past its 2^ep_bits-th episode has the rest in the EPH row
-    if (__builtin_expect(ep_far != 0u, 0)) episode = whole_episode(tile.load_eph() << c.ep_bits, episode);
+    if constexpr (!RESOLVED) {
+      if (__builtin_expect(ep_far != 0u, 0)) episode = whole_episode(tile.load_eph() << c.ep_bits, episode);
+    }
     draw_force<T>(c, i, episode - 1u, f);
     if (__builtin_expect(expl, 0)) {  // an installed force: rare, kept out of the common path
       const Vec4<T> fe = tile.load_fe();
@@ -381,7 +400,8 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
       torque_model(q, a0, a1, a2, a3, w);
     }
     double px, py, pz;
-    pending_perturbation<MODE>(c, q, tile, i, e.episode, e.ep_far, e.pend, e.expl, px, py, pz);
+    pending_perturbation<MODE, IN_LOOP>(c, q, tile, i, e.episode, e.ep_far, e.pend, e.expl, px, py,
+                                        pz);  // (IN_LOOP kernels hold the whole episode number: resolve_episode)
     CS_KSTAMP(CS_KST(o), 2);  // clip + motor model + pending perturbation done
     bool gyro = false;
     if constexpr (!LEAN) gyro = o.gyro;
@@ -456,7 +476,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
       e.x[k] = (double)w0;
       if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
     }
-    next_episode<MODE>(e);
+    next_episode<MODE, IN_LOOP>(e);
     e.fs = c.status0;
     e.pend = true;
     e.expl = false;

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     const typename TILE::Group t1 = tile.load_group(0);
     unpack_env<MODE, TILE>(c, t1, t2, r1, r2, e);
   }
+  resolve_episode<MODE>(c, tile, e);  /* the reset draws inside the loop are keyed by the whole episode number */
   StepOpts o;
 #ifdef CS_KSTAMPS
   o.kst = nullptr;
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
   }
   policy.store(i, valid);
 
+  split_episode<MODE>(c, tile, e);
   store_env<MODE, TILE>(c, tile, e);
-  finish_carry<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
 }
