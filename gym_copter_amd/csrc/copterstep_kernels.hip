@@ -181,7 +181,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(CS_STEP_ARGS) {
 // zeroed whenever its env starts a new episode.
 // (the hover heuristic is its own instantiation: its six controllers cost 16 more VGPRs, which
 // would take the landing-heuristic kernel from four to three wavefronts per SIMD)
-enum { kPolicyNone = 0, kPolicyPid = 1, kPolicyRandom = 2, kPolicyPidHover = 3 };
+// kPolicyPidUpstream: the landing heuristic with the terms of upstream's own gains compiled in (dev_pid.h: FIXED_I / FIXED_D)
+enum { kPolicyNone = 0, kPolicyPid = 1, kPolicyRandom = 2, kPolicyPidHover = 3, kPolicyPidUpstream = 4 };
+constexpr int kPidUpstreamTerms = kPidRateD | kPidPosI | kPidPosD;  // attic/mars/lander3d.py:32-36: rate 1/0/1, position 1e-5/0.1/4
 
 template <int TASK, int MODE, bool LEAN, int POLICY, bool ONE_CALL, bool DIRECT_ROWS>
 __global__ __launch_bounds__(kBlock) void step_many_kernel(
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   DevConst c = c_arg;
   PidConst pc = pc_arg;
   park_constants<MODE == CS_STATE_F64>(c);
-  constexpr bool kPid = POLICY == kPolicyPid || POLICY == kPolicyPidHover;
+  constexpr bool kPid = POLICY == kPolicyPid || POLICY == kPolicyPidHover || POLICY == kPolicyPidUpstream;
   constexpr int NCTL = POLICY == kPolicyPidHover ? kPidControllers : 4;
   // which terms the controllers have: decided on the kernel ARGUMENTS (scalar registers), before the gains are made
   // vector-resident -- a test on a parked gain is a per-lane compare and an exec-mask branch (3 scalar instructions
@@ -304,7 +306,8 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     float4 act_next = act;
     if constexpr (kPid) {
       static_assert(OBS >= 10, "the PID heuristic reads the 3D observation");
-      act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL, DIRECT_ROWS>(pc, pf, ctl, seen);
+      act = pid_policy<OBS, POLICY == kPolicyPidHover, NCTL, DIRECT_ROWS,
+                       POLICY == kPolicyPidUpstream ? kPidUpstreamTerms : -1>(pc, pf, ctl, seen);
       if (actions_dev != nullptr && valid) *at32<float4>(actions_dev + row * 4, ia << 4) = act;
     } else if constexpr (POLICY == kPolicyRandom) {
       const float4 a = draw_action(c, i, e.episode, (uint32_t)e.steps);
@@ -831,6 +834,10 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
         } else {
           return hipErrorInvalidValue;
         }
+      } else if (lean && is_tuned(TASK, MODE) && c.nsub == 1 && s.n <= direct_max &&
+                 (pc.terms & (kPidRateI | kPidRateD | kPidPosI | kPidPosD)) == kPidUpstreamTerms) {
+        // upstream's own gains at <= 65 536 envs: the instantiation with their terms compiled in
+        if constexpr (is_tuned(TASK, MODE)) CS_MANY_N(true, kPolicyPidUpstream, true, true);
       } else if (lean) {
         CS_MANY(true, kPolicyPid);
       } else {

@@ -58,12 +58,34 @@ __device__ __forceinline__ double bit_keep(uint32_t m, double a) {
 // wavefronts fill the latency and what counts is the number of vector instructions issued -- the always-evaluated
 // form executes ~35 more per step (upstream's rate controllers have no integral term) and was 9-14 % slower at 1 M - 4 M
 // envs.
-template <bool BRANCHLESS>
+//
+// FIXED_I / FIXED_D (-1 = decided at run time by the masks; 0 / 1 = compiled in): the landing heuristic under
+// UPSTREAM'S OWN gains (attic/mars/lander3d.py:32-36: rate controllers P + D, position controllers P + I + D) has its
+// own instantiation of the K-step kernel at <= 65 536 envs, without masks and without the rate controllers' unused
+// integral term: ~55 vector instructions fewer per step than the mask form (kPolicyPidUpstream, launch_step_many).
+template <bool BRANCHLESS, int FIXED_I = -1, int FIXED_D = -1>
 __device__ __forceinline__ double pid_compute(PidCtl& s, double kp, double ki, double kd, uint32_t has_i,
                                               uint32_t has_d, double windup, double target, double actual) {
   const double error = target - actual;
   double acc = error * kp;
-  if constexpr (BRANCHLESS) {
+  if constexpr (FIXED_I >= 0 && FIXED_D >= 0) {
+    if constexpr (FIXED_I == 1) {
+      const double v = s.err_i + error;
+      s.err_i = v < -windup ? -windup : (v > windup ? windup : v);
+      acc = acc + s.err_i * ki;
+    } else {
+      acc = acc + 0.0;  // (iterm = 0: the sum upstream forms, :48 -- keeps -0.0 + 0.0 = +0.0)
+    }
+    double dterm = 0.0;
+    if constexpr (FIXED_D == 1) {
+      const double de = error - s.last;
+      dterm = ((s.d1 + s.d2) + de) * kd;
+      s.d2 = s.d1;
+      s.d1 = de;
+      s.last = error;
+    }
+    return acc + dterm;
+  } else if constexpr (BRANCHLESS) {
     // integral term
     const double v = s.err_i + error;
     const double vi = v < -windup ? -windup : (v > windup ? windup : v);
@@ -97,32 +119,34 @@ __device__ __forceinline__ double pid_compute(PidCtl& s, double kp, double ki, d
 }
 
 // AngularVelocityPidController.getDemand (:135-146): a wild rate restarts the controller
-template <bool BRANCHLESS>
+template <bool BRANCHLESS, int TERMS = -1>
 __device__ __forceinline__ double pid_rate(const PidConst& p, const PidTerms& f, PidCtl& s, double w) {
   if (fabs(w) > p.rate_big) {
     s.err_i = 0.0;
     s.last = 0.0;
   }
-  return pid_compute<BRANCHLESS>(s, p.rate_kp, p.rate_ki, p.rate_kd, f.rate_i, f.rate_d, p.rate_windup, 0.0, w);
+  return pid_compute<BRANCHLESS, TERMS < 0 ? -1 : (TERMS & kPidRateI) != 0, TERMS < 0 ? -1 : (TERMS & kPidRateD) != 0>(
+      s, p.rate_kp, p.rate_ki, p.rate_kd, f.rate_i, f.rate_d, p.rate_windup, 0.0, w);
 }
 
 // PositionHoldPidController.getDemand (:94-108): unit-gain position loop -> velocity loop
-template <bool BRANCHLESS>
+template <bool BRANCHLESS, int TERMS = -1>
 __device__ __forceinline__ double pid_pos(const PidConst& p, const PidTerms& f, PidCtl& s, double x, double dx) {
   const double target_velocity = (p.pos_target - x) * 1.0;
-  return pid_compute<BRANCHLESS>(s, p.pos_kp, p.pos_ki, p.pos_kd, f.pos_i, f.pos_d, p.pos_windup, target_velocity, dx);
+  return pid_compute<BRANCHLESS, TERMS < 0 ? -1 : (TERMS & kPidPosI) != 0, TERMS < 0 ? -1 : (TERMS & kPidPosD) != 0>(
+      s, p.pos_kp, p.pos_ki, p.pos_kd, f.pos_i, f.pos_d, p.pos_windup, target_velocity, dx);
 }
 
 // heuristic + mixer: the landing heuristic (attic/mars/lander3d.py:64-87) or, on the 12-slot
 // observation, the hover heuristic (attic/mars/hover3d.py:65-92: a yaw-rate controller and the
 // altitude-hold controller of attic/mars/hover.py:23 instead of the descent law)
-template <int OBS, bool HOVER, int NCTL, bool BRANCHLESS = true>
+template <int OBS, bool HOVER, int NCTL, bool BRANCHLESS = true, int TERMS = -1>
 __device__ __forceinline__ float4 pid_policy(const PidConst& p, const PidTerms& f, PidCtl (&ctl)[NCTL],
                                              const float (&obs)[OBS]) {
   const double x = obs[0], dx = obs[1], y = obs[2], dy = obs[3], z = obs[4], dz = obs[5];
   const double dphi = obs[7], dtheta = obs[9];
-  const double r = pid_rate<BRANCHLESS>(p, f, ctl[0], dphi) + pid_pos<BRANCHLESS>(p, f, ctl[2], y, dy);
-  const double q = pid_rate<BRANCHLESS>(p, f, ctl[1], -dtheta) + pid_pos<BRANCHLESS>(p, f, ctl[3], x, dx);
+  const double r = pid_rate<BRANCHLESS, TERMS>(p, f, ctl[0], dphi) + pid_pos<BRANCHLESS, TERMS>(p, f, ctl[2], y, dy);
+  const double q = pid_rate<BRANCHLESS, TERMS>(p, f, ctl[1], -dtheta) + pid_pos<BRANCHLESS, TERMS>(p, f, ctl[3], x, dx);
   if constexpr (HOVER) {
     static_assert(OBS >= 12 && NCTL == kPidControllers, "the hover heuristic reads dpsi and has six controllers");
     {

@@ -183,7 +183,10 @@ for key, tag in (("lander3d_65536", ""), ("lander3d_65536_substeps10", "_c5"), (
 print("== PMC, K-step kernels: per wavefront and env-step ==")
 res["pmc_k_step"] = {}
 for name, label, k, leg in (("step_many_kernel<0, 0, true, 0,", "open loop", 64, "step_many"),
-                            ("step_many_kernel<0, 0, true, 1,", "PID policy", 100, "rollout_pid"),
+                            # (round 5: under upstream's gains the lean <= 65 536-env launch is the instantiation with the PID terms
+                            #  compiled in, POLICY = 4; other gain sets run POLICY = 1)
+                            ("step_many_kernel<0, 0, true, 4,", "PID policy (upstream's terms compiled in)", 100, "rollout_pid"),
+                            ("step_many_kernel<0, 0, true, 1,", "PID policy (generic)", 100, "rollout_pid"),
                             ("step_many_kernel<0, 0, true, 2,", "random policy", 100, "rollout_random"),
                             ("rollout_custom_kernel<0, 0, true,", "caller's linear policy", 100, "rollout_policy_linear")):
     m = {}
@@ -193,8 +196,8 @@ for name, label, k, leg in (("step_many_kernel<0, 0, true, 0,", "open loop", 64,
         per = {c: m[c] / m["SQ_WAVES"] / k for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD",
                                                     "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES") if c in m}
         res["pmc_k_step"][name] = per
-        counts["valu_per_wavefront_step"][leg] = per["SQ_INSTS_VALU"]
-        print("%-22s (%3d steps/launch): " % (label, k) +
+        counts["valu_per_wavefront_step"].setdefault(leg, per["SQ_INSTS_VALU"])
+        print("%-42s (%3d steps/launch): " % (label, k) +
               "  ".join("%s %.1f" % (c.replace("SQ_INSTS_", "").replace("SQ_", ""), v) for c, v in per.items()))
 # round 5: the K-step kernels at 4 194 304 envs (64 wavefronts per SIMD; LDS-transpose instantiation), tools/kstep_probe.py
 for name, label, k, leg, subs in (("step_many_kernel<0, 0, true, 0,", "open loop, 4 M envs", 16, "step_many_4194304", ("sq1_many_4m", "sq2_many_4m")),

@@ -216,3 +216,31 @@ def test_bench_line_round5_blocks(tmp_path):
         assert 0.4 < allc["scaling_efficiency"] < 1.3, allc
     assert "served_producers_ahead" in d and "served_closed_loop" not in d and "served_closed_loop_persistent_policy" not in d
     assert "next_action_prefetch" not in d["config"]
+
+
+def test_rollout_pid_with_upstreams_gains_compiled_in_equals_the_generic_kernel():
+    """Under upstream's own gains a lean Lander3D env of <= 65 536 envs runs the K-step kernel whose PID terms are
+    compiled in (kPolicyPidUpstream: no masks, no integral term in the rate controllers); a twin with episode statistics
+    on runs the generic, mask-driven kernel (full-featured instantiation).  Same actions, outputs, env state and
+    controller state, bit for bit, across auto-resets; and a gain set with another term pattern takes the generic path
+    on the lean env too (it must still agree with ITS twin)."""
+    import torch
+    for gains in ({}, dict(rate_ki=0.05, pos_kd=0.0)):
+        n, K = 3000, 60
+        lean, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=5)
+        full, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=5, episode_stats=True)
+        for e in (lean, full):
+            e.configure_pid(**gains)
+            e.reset()
+        for chunk in range(3):
+            a = lean.rollout_pid(K, return_actions=True)
+            b = full.rollout_pid(K, return_actions=True)
+            for k in range(5):
+                assert torch.equal(a[k], b[k]), (gains, chunk, k)
+        sa, sb = lean.get_state(), full.get_state()
+        for key in sa:
+            assert np.array_equal(sa[key], sb[key], equal_nan=True), (gains, key)
+        assert np.array_equal(lean.pid_get_state(), full.pid_get_state()), gains
+        assert int(sa["episode"].max()) > 1                      # episodes ended and restarted inside the launches
+        lean.close()
+        full.close()
