@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
     }
     CS_KSTAMP(CS_KST(o), 1);  // policy done (PID heuristic / Philox draw / next row requested)
     StepOut<OBS> out;
-    advance<TASK, MODE, OBS, LEAN, ONE_CALL, true>(c, q, o, e, act, io, i, lane, valid, tile, out);
+    advance<TASK, MODE, OBS, LEAN, ONE_CALL, true, !kPid>(c, q, o, e, act, io, i, lane, valid, tile, out);
     if constexpr (kPid) {
 #pragma unroll
       for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];

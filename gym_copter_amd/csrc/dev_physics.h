@@ -152,13 +152,31 @@ __device__ __forceinline__ void euler_rotation(const Coef& q, const Wrench& w, d
 // (px,py,pz) = 2*force/M, the pending reset perturbation in its doubled form (upstream
 // adds it inside the derivative, :263-271, and again at :183), zero when none is
 // pending.  Returns what the call did.
-template <bool FULL, bool GYRO, bool IN_LOOP = false>
+template <bool FULL, bool GYRO, bool IN_LOOP = false, bool TRIG3 = false>
 __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, const Wrench& w,
                                             double (&x)[12], int& fs, double px, double py,
                                             double pz) {
   Trig t;
-  sincos_roll_pitch<FULL, IN_LOOP>(c, x[6], x[8], t);
-  sincos_yaw<FULL, IN_LOOP>(c, x[10], t);
+  if constexpr (TRIG3) {
+    // K-step loops (one wavefront per SIMD at <= 65 536 envs: dependent float64 latency is what a step costs there):
+    // when all three angles of the whole wavefront are in the reduction-free range -- the usual case -- the three
+    // polynomial kernels run in ONE basic block, six independent Horner chains for the scheduler to interleave, behind
+    // one uniform test instead of two (roll + pitch, then yaw: four chains, then two on their own).  Otherwise the
+    // two-stage form below.  Same operations on the same values either way.  (TRIG3 is off in the PID kernels: with
+    // the controllers' sixteen state words live across the step, six interleaved chains cost them 1 % instead of
+    // saving 1-2 %: interleaved A/B, round 5.)
+    if (__builtin_expect(__all(fabs(x[6]) < 0.785 && fabs(x[8]) < 0.785 && fabs(x[10]) < 0.785), 1)) {
+      sincos_kernel<FULL>(c.trig, x[6], t.sph, t.cph);
+      sincos_kernel<FULL>(c.trig, x[8], t.sth, t.cth);
+      sincos_kernel<FULL>(c.trig, x[10], t.sps, t.cps);
+    } else {
+      sincos_roll_pitch<FULL, IN_LOOP>(c, x[6], x[8], t);
+      sincos_yaw<FULL, IN_LOOP>(c, x[10], t);
+    }
+  } else {
+    sincos_roll_pitch<FULL, IN_LOOP>(c, x[6], x[8], t);
+    sincos_yaw<FULL, IN_LOOP>(c, x[10], t);
+  }
   double ax, ay, netz;
   thrust_ned(q, w.bz, t, ax, ay, netz);
   const CallPlan p = plan_call(c, fs, netz, x[4], x[5], x[3], x[6]);
@@ -233,12 +251,12 @@ __device__ __forceinline__ bool flight_assured(const Coef& q, const Wrench& w, i
 // qualifies (the usual case of an integration-bound workload: BASELINE configs[4] flies near hover): with no
 // test at all when flight_assured() vouches for all of them, else tested call by call.
 // Returns the calls that ticked (Dynamics._ticks, :197: every call but a ground-contact freeze).
-template <bool FULL, bool GYRO, bool ONE_CALL, bool IN_LOOP = false>
+template <bool FULL, bool GYRO, bool ONE_CALL, bool IN_LOOP = false, bool TRIG3 = false>
 __device__ __forceinline__ uint32_t physics_substeps(const DevConst& c, const Coef& q, const Wrench& w,
                                                      double (&x)[12], int& fs, bool& pend, double px,
                                                      double py, double pz) {
   if constexpr (ONE_CALL) {  // upstream's own configuration (substeps = 1): no loop
-    const int what = physics_call<FULL, GYRO, IN_LOOP>(c, q, w, x, fs, px, py, pz);
+    const int what = physics_call<FULL, GYRO, IN_LOOP, TRIG3>(c, q, w, x, fs, px, py, pz);
     pend = pend && what == kCallFroze;
     return what == kCallFroze ? 0u : 1u;
   }

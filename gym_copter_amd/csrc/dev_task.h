@@ -373,7 +373,7 @@ __device__ __forceinline__ bool test_tilt(const DevConst& c, double phi, double 
 // substeps -> stored-word rounding -> reward / termination -> optional done list and
 // final_obs -> masked auto-reset (task.py:145-197).  Shared by the one-step and the
 // K-step kernels, so both advance an env bit-identically.
-template <int TASK, int MODE, int OBS, bool LEAN, bool ONE_CALL, bool IN_LOOP, class TILE>
+template <int TASK, int MODE, int OBS, bool LEAN, bool ONE_CALL, bool IN_LOOP, bool TRIG3 = false, class TILE>
 __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const StepOpts& o,
                                         Env<MODE>& e, const float4 act, const cs_step_io& io, uint32_t i,
                                         int lane, bool valid, const TILE& tile,
@@ -409,7 +409,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     if (gyro) {
       ticked = physics_substeps<FULL, true, false, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
     } else {
-      ticked = physics_substeps<FULL, false, ONE_CALL, IN_LOOP>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
+      ticked = physics_substeps<FULL, false, ONE_CALL, IN_LOOP, TRIG3>(c, q, w, e.x, e.fs, e.pend, px, py, pz);
     }
     if constexpr (!LEAN) e.ticks += ticked;
   }

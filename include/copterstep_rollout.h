@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     }
     CS_KSTAMP(CS_KST(o), 1);
     StepOut<OBS> out;
-    advance<TASK, MODE, OBS, LEAN, ONE_CALL, true>(c, q, o, e, act, io, i, lane, valid, tile, out);
+    advance<TASK, MODE, OBS, LEAN, ONE_CALL, true, true>(c, q, o, e, act, io, i, lane, valid, tile, out);
 #pragma unroll
     for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
     fresh = out.did_reset;
