@@ -798,7 +798,7 @@ class CopterVecEnv(_VectorEnvBase):
         _lib.check(self._lib.cs_device_pci_address(self._ctx, buf, 32))
         return buf.value.decode()
 
-    def close(self):                                            # task.py:139-143
+    def close(self, **kwargs):                                  # task.py:139-143 (gymnasium.vector.VectorEnv.close(**kwargs))
         if not self.closed and self._ctx:
             self._lib.cs_destroy(self._ctx)
             self._ctx = C.c_void_p()
