@@ -244,3 +244,60 @@ def test_rollout_pid_with_upstreams_gains_compiled_in_equals_the_generic_kernel(
         assert int(sa["episode"].max()) > 1                      # episodes ended and restarted inside the launches
         lean.close()
         full.close()
+
+
+@pytest.mark.parametrize("form", ["many", "served"])
+def test_episode_counter_crosses_its_boundaries_inside_k_step_and_served_kernels(form):
+    """The kernels that keep the env in registers for many steps hold the WHOLE episode number in a register
+    (dev_task.h: resolve_episode / split_episode) -- a different code path from the one-launch step, which the round-4
+    test flies across the boundaries.  Same parking (just below 2^E, below 2^(E+1), below 2^32, an arbitrary large
+    number, small numbers), then K-step launches / served sessions with reset churn: outputs, episode numbers, the Philox
+    forces drawn for them and the EPH row's effect on a later one-launch step against the oracle."""
+    import torch
+    from gpu_util import assert_state_close, assert_step_close, device_episode_bits, MODE_TOL
+    from oracle import refvec
+    n, K, max_steps = 320, 12, 40
+    env, orc = make_pair("lander3d", n, "float32", "next_step", seed=33, max_steps=max_steps)
+    ebits = device_episode_bits(max_steps)
+    ep_mask = (1 << ebits) - 1
+    env.reset()
+    orc.reset()
+    ep = np.full(n, ep_mask - 1, np.uint32)
+    ep[::7] = ep_mask
+    ep[1::7] = 3
+    ep[2::7] = 2 * (ep_mask + 1) - 2
+    ep[3::7] = 0xFFFFFFFE
+    ep[4::7] = 0x9E3779B9
+    env.set_state(episode=ep)
+    orc.episode[:] = ep
+    orc.force[:] = refvec.draw_forces(orc.seed, orc.env_ids, ep - np.uint32(1), orc.tp.initial_random_force).astype(orc.T)
+    rng = np.random.default_rng(8)
+    for launch in range(4):
+        acts = rng.uniform(-1, 1, (K, n, 4)).astype(np.float32)
+        if form == "many":
+            o, r, te, tr = (to_np(v) for v in env.step_many(torch.from_numpy(acts).to(env.device)))
+            outs = [(o[k], r[k], te[k], tr[k]) for k in range(K)]
+        else:
+            env.serve_begin(K, ring=2, timeout=5.0)
+            outs = []
+            for k in range(K):
+                env.serve_submit(k, torch.from_numpy(acts[k]).to(env.device))
+                outs.append(tuple(to_np(v).copy() for v in env.serve_collect(k)))
+            assert env.serve_end() == K
+        for k in range(K):
+            want = orc.step(acts[k].astype(np.float64))
+            assert_step_close(outs[k], want, 2e-6, r_abs="auto", ctx="%s launch %d step %d" % (form, launch, k))
+        st = env.get_state()
+        assert np.array_equal(st["episode"], orc.episode), (form, launch)
+        assert np.array_equal(st["force"].astype(np.float32), orc.force.astype(np.float32)), (form, launch)
+    e0, e1 = ep.astype(np.int64), orc.episode.astype(np.int64)
+    assert np.any((e0 <= ep_mask) & (e1 > ep_mask)) and np.any((e0 > 0xFFFFFF00) & (e1 < 100) & (e1 >= 1))
+    # ... and the one-launch step picks up what the K-step kernels left in the EPH row
+    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    for t in range(6):
+        o, r, te, tr, _ = env.step(torch.from_numpy(a).to(env.device))
+        want = orc.step(a.astype(np.float64))
+        assert_step_close(tuple(to_np(v) for v in (o, r, te, tr)), want, 2e-6, r_abs="auto", ctx="%s tail %d" % (form, t))
+    assert np.array_equal(env.get_state(only=("episode",))["episode"], orc.episode)
+    assert_state_close(env, orc, MODE_TOL["float32"])
+    env.close()
