@@ -692,8 +692,9 @@ def issue_bound(valu_per_wave_step, n_envs, s_per_step, cus, clock_hz, measured_
     `valu_per_wave_step` vector instructions at 4 cycles apiece -> (floor in us, floor / measured = frac).  4 cycles per
     float64 vector instruction and SIMD is what profiles/r05_ubench_f64.txt measures with proven co-residency (4.19-4.45
     summed over two or more wavefronts, 4.6-4.9 for a lone one).  `frac` prices the floor at the PEAK engine clock (a
-    roofline is a peak); `frac_at_measured_clock` at the clock this device held under a float64 load in this run
-    (cs_clock_probe), which is what the kernel could have reached here."""
+    roofline is a peak); `frac_at_measured_clock` at the clock this device held under a DENSE float64 FMA load in this
+    run (cs_clock_probe) -- the lowest clock it runs at, so the two fractions bracket the fraction at the kernel's own
+    clock."""
     simds = cus * SIMDS_PER_CU
     waves = (n_envs + LANES_PER_WAVE - 1) // LANES_PER_WAVE
     per_simd = (waves + simds - 1) // simds
@@ -705,6 +706,10 @@ def issue_bound(valu_per_wave_step, n_envs, s_per_step, cus, clock_hz, measured_
     if measured_clock_hz:
         out["measured_f64_clock_GHz"] = measured_clock_hz / 1e9
         out["frac_at_measured_clock"] = out["frac"] * clock_hz / measured_clock_hz
+        out["measured_clock_is"] = ("cs_clock_probe: the clock under a DENSE float64 FMA stream -- the lowest this device clocks; a real "
+                                    "kernel with other instructions and memory phases in it holds more (the K-step kernels at 65 536 "
+                                    "envs: 2.13 GHz in-kernel, profiles/r05_kstep_phase_stamps.txt), so frac_at_measured_clock is an "
+                                    "UPPER bound of the fraction at the kernel's own clock and frac (peak clock) the lower one")
     return out
 
 

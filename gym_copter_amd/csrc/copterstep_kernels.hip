@@ -301,6 +301,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
                 ? s.stamps + (size_t)tile_index * kStampSlots + (k == num_steps / 2 ? 0 : 16) : nullptr;
 #endif
     CS_KSTAMP(CS_KST(o), 0);  // loop top
+    CS_KSTAMP_REALTIME(CS_KST(o), 12);
     // rows of step k (64-bit uniform offsets: K * N can exceed 32 bits)
     const size_t row = (size_t)k * n;
     float4 act_next = act;

@@ -36,8 +36,16 @@ namespace {
     __builtin_amdgcn_sched_barrier(0);                                              \
     if ((kst) != nullptr && threadIdx.x == 0) (kst)[slot] = t_;                     \
   } while (0)
+// the chip-wide 100 MHz clock into a slot (with the s_memtime stamp of the same place: the clock the kernel runs at)
+#define CS_KSTAMP_REALTIME(kst, slot)                                               \
+  do {                                                                              \
+    unsigned long long t_;                                                          \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
+    if ((kst) != nullptr && threadIdx.x == 0) (kst)[slot] = t_;                     \
+  } while (0)
 #else
 #define CS_KSTAMP(kst, slot) ((void)0)
+#define CS_KSTAMP_REALTIME(kst, slot) ((void)0)
 #endif
 
 #ifdef CS_SPAN

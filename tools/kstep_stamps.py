@@ -108,6 +108,11 @@ def main():
                 d = np.median(b[:, :, off + z] - b[:, :, off + a])
                 print("   %-72s %7.0f  (%4.1f %%)" % (label, d, 100.0 * d / whole))
         # the next iteration's loop top minus this one's = a full stamped iteration incl. the loop branch
+        # the clock the kernel itself runs at: shader-clock ticks per 100 MHz tick between the two loop tops
+        dt, dr = (b[:, :, 16] - b[:, :, 0]).astype(np.float64), (b[:, :, 28] - b[:, :, 12]).astype(np.float64)
+        ok = dr > 0
+        print("in-kernel clock over the stamped iteration: %.3f GHz (sum of s_memtime deltas / sum of s_memrealtime deltas x 100 MHz, "
+              "%d wavefront-launches; the stamps slow the iteration, not the clock)" % (dt[ok].sum() / dr[ok].sum() * 0.1, int(ok.sum())))
         full = np.median(b[:, :, 16] - b[:, :, 0])
         print("loop top of iteration %d -> loop top of iteration %d: %.0f cycles (stamped build; 10 stamps of ~%.0f cycles in it)"
               % (K // 2, K // 2 + 1, full, np.median(b[:, :, 15] - b[:, :, 14])))
