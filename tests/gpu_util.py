@@ -79,8 +79,11 @@ def reward_limit(wobs, wr, r_abs=2e-3, r_rel=2e-6):
     return np.minimum(5e-5 + 1e-5 * wr + 6e-7 * s, r_abs + r_rel * wr)
 
 
-def assert_step_close(got, want, x_tol, r_abs=5e-5, r_rel=1e-5, ctx=""):
-    """r_abs = "auto": the magnitude-aware reward tolerance of reward_limit() (bounded by 2e-3 + 2e-6 |r|)."""
+def assert_step_close(got, want, x_tol, r_abs=5e-5, r_rel=1e-5, ctx="", r_unit=0.0, shaping=None):
+    """r_abs = "auto": the magnitude-aware reward tolerance of reward_limit() (bounded by 2e-3 + 2e-6 |r|).
+    r_unit, shaping: with a numeric r_abs, an extra r_unit x (|shaping| + |r|), `shaping` being the ORACLE's shaping
+    value per env (the larger of before / after the step) -- the reward is a difference of two shaping values computed
+    from the state (one of them a stored word): its error scales with |shaping|, not with |r|."""
     obs, r, term, trunc = got
     wobs, wr, wterm, wtrunc = want
     assert np.array_equal(term.astype(bool), wterm), "terminated mismatch %s" % ctx
@@ -89,6 +92,9 @@ def assert_step_close(got, want, x_tol, r_abs=5e-5, r_rel=1e-5, ctx=""):
     assert e <= x_tol, "obs err %.3e > %.1e %s" % (e, x_tol, ctx)
     dr = np.abs(r.astype(np.float64) - wr)
     lim = reward_limit(wobs, wr) if isinstance(r_abs, str) else r_abs + r_rel * np.abs(wr)
+    if r_unit and shaping is not None and not isinstance(r_abs, str):
+        s = np.abs(wr) + np.abs(np.nan_to_num(np.asarray(shaping, dtype=np.float64), nan=0.0, posinf=np.inf, neginf=np.inf))
+        lim = lim + r_unit * s
     j = int(np.argmax(dr - lim))
     assert np.all(dr <= lim), "reward err %.3e at env %d (got %r want %r term %r obs %r) %s" % (
         float(dr[j]), j, r[j], wr[j], term[j], obs[j], ctx)

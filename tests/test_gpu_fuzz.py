@@ -9,14 +9,16 @@ every stretch are compared; discrete outputs exactly, the state to the same-mode
 rows to one ulp.
 
 Seeds 0..63 run in the suite (device and oracle are deterministic: the cases are fixed).  A one-off sweep of seeds
-0..399 (tools/fuzz_sweep.py; rounds 3, 4 and 5) passes 398 -- and of seeds 400..799 (round 5, profiles/r05_fuzz_sweep.txt)
-395, the five others (406, 412, 570, 667, 733) being further members of the one class described next;
-the two others (181, 360, both rounds) are not bugs but chaos: with auto-reset off, uniform full-range actions and 3
-substeps at 50 fps a finished env tumbles on at hundreds of m/s until the stretch ends, and one unit of the stored
-format grew to 2.7e-8 / 2.0e-7 within the stretch.  Where that unit comes from is pinned down in
-tests/test_gpu_round4.py: NOT the stored format (the codec is bit-exact against the oracle's model over 2.1 M values)
-but the float64 value that is rounded into it -- the float32 modes' shorter sin / cos polynomials move dx, dy, dz by
-~1e-11, which straddles a rounding boundary of the 29-bit format about once in 1e4 values (measured 9.9e-5).
+64..3199 (tools/fuzz_sweep.py; round 5, profiles/r05_fuzz_sweep.txt) passes 3 122 of 3 136 -- every float64 and
+float32_rn case, every case with an auto-reset mode, every case of the gentle action laws.  The fourteen others (181 and
+360 known since round 3) are not bugs but chaos, all of ONE class: default float32 words, auto-reset off, full-range
+actions -- a finished env tumbles on at hundreds of m/s until the stretch ends, and one unit of the stored format grows
+to 2.0-8.4e-8 on ONE lane within the stretch (tools/fuzz_trace.py shows it step by step).  Where that unit comes from is
+pinned down in tests/test_gpu_round4.py: NOT the stored format (the codec is bit-exact against the oracle's model over
+2.1 M values) but the float64 value that is rounded into it -- the float32 modes' shorter sin / cos polynomials move dx,
+dy, dz by ~1e-11, which straddles a rounding boundary of the 29-bit format about once in 1e4 values (measured 9.9e-5).
+Two more seeds of that sweep (2102, 2256) showed the same unit through the REWARD (REWARD_UNIT below) and run in the
+suite since.
 
 What the reference offers for this: nothing (it has no tests); the oracle is the reference's algorithm
 (envs/task.py:77-137, dynamics/__init__.py:114-197, envs/lander.py:46-74)."""
@@ -29,6 +31,14 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs 
 
 TASKS = ["lander3d", "hover3d", "lander2d", "lander1d", "hover2d", "hover1d"]
 OBS_ULP = 1.2e-7       # one float32 ulp relative to max(|ref|, 1)
+# reward = shaping - prev_shaping, and prev_shaping is kept as a float32 word in the float32 modes (a float64 in the
+# float64 mode), device and oracle alike: where the two states differ by one unit of the stored format the two
+# float64 shaping values differ a little, which now and then (2.5 % of such lanes at 120 m/s) rounds the WORD the other
+# way -- one float32 ulp of |shaping|, 2.4e-4 at |shaping| = 3200 (a full-throttle lane at hundreds of m/s or rad/s;
+# the yaw rate enters at 50 per rad/s and is not in the observation), which the fixed 5e-5 + 1e-5 |r| does not cover
+# when the reward itself is small.  Added on top of it, per unit of the ORACLE's |shaping|: one ulp of the word (two
+# where the state itself is float32-rounded).  Seeds 2102 and 2256 of the round-5 sweep: profiles/r05_fuzz_sweep.txt
+REWARD_UNIT = {"float64": 0.0, "float32": 2.0 ** -23, "float32_rn": 2.0 ** -22}
 HOVER = 0.016563        # per-motor value that just carries the DJI Phantom (tests/golden/meta.npz: hover_motor)
 
 
@@ -106,6 +116,13 @@ def test_random_configuration_and_stepping_forms_vs_oracle(seed, tmp_path_factor
     run_case(seed, tmp_path_factory)
 
 
+@pytest.mark.parametrize("seed", [2102, 2256])
+def test_cases_whose_reward_shows_one_ulp_of_the_shaping_word(seed, tmp_path_factory):
+    """Full-throttle lanes with |shaping| in the thousands and a small reward (REWARD_UNIT): the two seeds of the
+    64..3199 sweep that the fixed reward limit refused although state, observation and flags agreed."""
+    run_case(seed, tmp_path_factory)
+
+
 # The two seeds of the 400-seed sweep that do NOT pass (see the header): chaos after a one-unit rounding difference, not a
 # bug.  Kept as strict expected failures -- a change that makes one of them pass (or fail in another way: the second
 # test pins HOW they fail) is a change in the device's rounding behaviour and must be noticed.
@@ -177,10 +194,13 @@ def run_case(seed, tmp_path_factory):
                 outs.append(tuple(to_np(v).copy() for v in (o, r, te, tr)))
             assert env.serve_end() == k, ctx
         for j in range(k):
+            sh0 = np.abs(np.nan_to_num(orc.prev_shaping.astype(np.float64)))
             want = orc.step(acts[j].astype(np.float64))
+            sh = np.maximum(sh0, np.abs(np.nan_to_num(orc.prev_shaping.astype(np.float64))))
             # the float32 observation is a rounding of the stored word: where device and oracle differ by one unit of
             # the stored format (the state check below bounds that) the row may differ by one float32 ulp
-            assert_step_close(outs[j], want, max(OBS_ULP, tol), ctx="%s form %s step %d" % (ctx, form, t + j))
+            assert_step_close(outs[j], want, max(OBS_ULP, tol), ctx="%s form %s step %d" % (ctx, form, t + j),
+                              r_unit=REWARD_UNIT[cfg["mode"]], shaping=sh)
         t += k
         assert_state_close(env, orc, tol, ctx="%s form %s after step %d" % (ctx, form, t))
         if cfg["autoreset"] == "disabled":

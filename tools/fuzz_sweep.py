@@ -33,7 +33,8 @@ for seed in range(first, last):
         fn(seed, tmp)
     except Exception as e:      # noqa: BLE001
         bad.append(seed)
-        print("seed %d FAILED: %s" % (seed, str(e).splitlines()[0][:400]), flush=True)
+        msg = str(e) if os.environ.get("FUZZ_FULL") else str(e).splitlines()[0][:400]
+        print("seed %d FAILED: %s" % (seed, msg), flush=True)
         if os.environ.get("FUZZ_TRACE"):
             traceback.print_exc()
 print("fuzz sweep seeds %d..%d: %d passed, %d failed %s" % (first, last - 1, last - first - len(bad), len(bad), bad))
