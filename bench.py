@@ -1462,12 +1462,14 @@ struct Policy {
     if dist is not None:
         torch.cuda.synchronize()
         profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
-        if launched or profiled:       # (a profiler writes its files from exit handlers: leave normally)
+        if launched or profiled:
             dist.destroy_process_group()
-        else:
-            # the 1-rank group this process opened for --gather: leave without tearing RCCL down (its watchdog thread
-            # has been seen to abort the process during interpreter shutdown once hipGraphs that captured collectives
-            # are being freed); the line is out, nothing is left to flush
+        if not profiled:               # (a profiler writes its files from exit handlers: leave normally under one)
+            # leave without running the interpreter's shutdown: hipGraphs that captured collectives are still alive, and
+            # freeing them once RCCL is (being) torn down has been seen to end the process with SIGSEGV / SIGABRT
+            # (the watchdog thread during shutdown; a garbage collection at exit in tests/test_gpu_round3.py's RCCL
+            # child) -- after the line is out, which a launcher would report as a failed rank.  The line is written,
+            # the group is closed (launched runs), nothing is left to flush
             sys.stderr.flush()
             os._exit(0)
 

@@ -130,13 +130,25 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
 #pragma unroll
         for (int p = 0; p < AP; ++p) ok = ok && g[p].y == tag && g[p].w == tag;
         if (__all(ok)) break;
-        if (spin.nap_and_expired(v, &stopped)) {
+        const bool expired = spin.nap_and_expired(v, &stopped);
+        if (expired && !stopped) {
           give_up = true;
           break;
         }
         const uint32_t off = cs_serve::act_offset(v, step, tile_index, lane);
 #pragma unroll
         for (int p = 0; p < AP; ++p) g[p] = cs_serve::load16(ra, off + (uint32_t)p * 1024u);
+        if (expired) {
+          // the stop word is raised BEHIND everything the caller enqueued: a row published before it may have landed
+          // between the last look at the row and the look at the stop word.  The row as it reads NOW (after the stop
+          // word was seen) decides: there = take the step, not there = nobody will send it
+          bool there = true;
+#pragma unroll
+          for (int p = 0; p < AP; ++p) there = there && g[p].y == tag && g[p].w == tag;
+          if (__all(there)) break;
+          give_up = true;
+          break;
+        }
       }
       if (give_up) {
         timed_out = !stopped;

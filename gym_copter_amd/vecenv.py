@@ -17,13 +17,31 @@ accepted for drop-in use and then NumPy arrays are returned (paying PCIe both wa
 PyTorch is used only for device memory and streams.  There is no CPU implementation in
 this package: construction fails if libcopterstep.so or a HIP device is missing.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
 from . import _lib
 from .spaces import gymnasium_api
+
+# Envs that hold a device context.  Whatever is still open when the interpreter exits is closed by an exit handler,
+# i.e. BEFORE modules and the HIP runtime's own exit handlers are torn down: a context destroyed from __del__ during
+# interpreter shutdown calls into a runtime that may already be half gone.
+_open_envs = weakref.WeakSet()
+
+
+def _close_open_envs():
+    for env in list(_open_envs):
+        try:
+            env.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_open_envs)
 
 # With Gymnasium importable CopterVecEnv IS a gymnasium.vector.VectorEnv with gymnasium.spaces.Box spaces and a
 # gymnasium.vector.AutoresetMode in its metadata (what gymnasium.make_vec and VectorEnv consumers check); without it
@@ -181,6 +199,7 @@ class CopterVecEnv(_VectorEnvBase):
         lib, cfg = self._lib, self.config
         # cs_create fails loudly when no HIP device is usable (no CPU fallback)
         _lib.check(lib.cs_create(C.byref(cfg), C.byref(self._ctx)))
+        _open_envs.add(self)
         od, ad = C.c_int32(), C.c_int32()
         _lib.check(lib.cs_obs_dim(self._ctx, C.byref(od)))
         _lib.check(lib.cs_action_dim(self._ctx, C.byref(ad)))
@@ -803,6 +822,7 @@ class CopterVecEnv(_VectorEnvBase):
             self._lib.cs_destroy(self._ctx)
             self._ctx = C.c_void_p()
         self.closed = True
+        _open_envs.discard(self)
 
     def __del__(self):
         try:

@@ -63,6 +63,24 @@ def pytest_sessionstart(session):
                                "PYTHON=" + sys.executable], stdout=subprocess.DEVNULL)
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """Leave the GPU quiet before the interpreter goes down: envs a test left open are closed, hipGraphs and streams
+    the tests dropped are collected, the device is idle.  Destroying device objects from the interpreter's shutdown
+    (or from the runtime's own exit handlers, in whatever order) has ended a run in which every test had passed with
+    SIGSEGV at exit on one box -- which a driver reads as a failed run."""
+    torch = sys.modules.get("torch")
+    vecenv = sys.modules.get("gym_copter_amd.vecenv")
+    if vecenv is not None:
+        vecenv._close_open_envs()
+    if torch is not None and torch.cuda.is_initialized():
+        import gc
+        gc.collect()
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+
+
 class Cases:
     """Read-only view of one golden .npz: cases[name][field]."""
 

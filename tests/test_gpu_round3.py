@@ -474,6 +474,7 @@ for gather in ("obs", "all"):
     graph = torch.cuda.CUDAGraph()
     captured = "graph"
     import time; time.sleep(0.3)        # (the watchdog retires the eager collectives before the capture opens)
+    out = None
     try:
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):   # (RCCL's watchdog thread queries events meanwhile)
             out = env.step(acts[1])
@@ -487,6 +488,10 @@ for gather in ("obs", "all"):
             assert torch.equal(u.reshape(v.shape), v), (gather, "replay")
     print("RCCL_LEG", gather, captured)
     env.close(); plain.close()
+    # the graph that captured the collective goes BEFORE the communicator does: freed by the garbage collector at
+    # interpreter exit, after destroy_process_group, it has ended this process with SIGSEGV (1 run in 10)
+    del graph, out, env, plain
+    import gc; gc.collect(); torch.cuda.synchronize()
 ones = torch.ones(1, device="cuda"); dist.all_reduce(ones)
 assert int(ones.item()) == dist.get_world_size() == 1
 dist.barrier(); dist.destroy_process_group()

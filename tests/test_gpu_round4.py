@@ -340,7 +340,11 @@ def test_a_session_closed_without_waiting_is_drained_before_other_streams_touch_
         want = twin.step(acts[K])[:4]
         other.synchronize()
         for k in range(4):
-            assert torch.equal(got[k], want[k]), (rep, k)
+            if not torch.equal(got[k], want[k]):       # say WHAT differs: whole tiles (a stale tile) or single rows
+                d = (got[k] != want[k]).reshape(n, -1).any(dim=1)
+                idx = torch.nonzero(d).flatten().cpu().numpy()
+                raise AssertionError("rep %d output %d: %d envs differ, tiles %s, serve_status %r" % (
+                    rep, k, idx.size, np.unique(idx // 64)[:16], env.serve_status()))
     assert env.serve_status() == (K, K, 0)
     sa, sb = env.get_state(), twin.get_state()
     for k in sa:

@@ -301,3 +301,37 @@ def test_episode_counter_crosses_its_boundaries_inside_k_step_and_served_kernels
     assert np.array_equal(env.get_state(only=("episode",))["episode"], orc.episode)
     assert_state_close(env, orc, MODE_TOL["float32"])
     env.close()
+
+
+@pytest.mark.parametrize("n,K,ring", [(65536, 1, 2), (4096, 1, 2), (65536, 3, 2), (65536, 12, 4)])
+def test_a_session_stopped_right_behind_its_last_row_still_takes_that_row(n, K, ring):
+    """cs_serve_end raises the stop word BEHIND everything the caller enqueued: a row submitted before it must be
+    stepped, however closely the stop word follows it.  The env kernel used to look at the stop word after a (possibly
+    stale) look at the row and gave up on a row that had landed in between -- seen once as a mismatch in
+    test_a_session_closed_without_waiting_is_drained_before_other_streams_touch_the_tiles; now the row as it reads AFTER
+    the stop word was seen decides (copterstep_serve.hip).  Many short sessions, all rows submitted at once, closed
+    without waiting: every tile completes every step, and the envs end where a plain twin ends."""
+    import torch
+    import gym_copter_amd
+    kw = dict(task="lander3d", num_envs=n, seed=8, autoreset_mode="next_step")
+    env, twin = gym_copter_amd.CopterVecEnv(**kw), gym_copter_amd.CopterVecEnv(**kw)
+    env.reset()
+    twin.reset()
+    g = torch.Generator(device=env.device)
+    g.manual_seed(4)
+    acts = torch.rand((K, n, 4), generator=g, device=env.device) * 2 - 1
+    sessions = 150
+    for s in range(sessions):
+        env.serve_begin(K, ring=ring, timeout=5.0)
+        for k in range(K):
+            env.serve_submit(k, acts[k])
+        env.serve_end(wait=False)
+        assert env.serve_status() == (K, K, 0), s
+    for s in range(sessions):
+        for k in range(K):
+            twin.step(acts[k])
+    sa, sb = env.get_state(), twin.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    env.close()
+    twin.close()
