@@ -390,6 +390,8 @@ int cs_get_tuning(const cs_ctx* ctx, cs_tuning* out); /* the values in effect */
  *       OR  cs_serve_submit(ctx, s, actions_dev, stream)  +  cs_serve_collect(ctx, s, obs, ..., stream)
  *           (plain [N,A] rows in, plain rows out: one small kernel each)
  *   cs_serve_end(ctx, stream, &steps_done)                    stop word, join `stream` behind the env kernel
+ *       (the stop word is raised BEHIND everything enqueued on `stream` before it: every action row published by then
+ *       is still stepped; the session ends at the first step whose row is not there)
  *
  * What it costs and when it pays is measured in DESIGN.md section 8 (tools/serve_ubench.hip): a hand-off
  * between two wavefronts through device memory takes ~2 us on MI355X under this load, so a closed loop runs
