@@ -131,7 +131,11 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
         for (int p = 0; p < AP; ++p) ok = ok && g[p].y == tag && g[p].w == tag;
         if (__all(ok)) break;
         const bool expired = spin.nap_and_expired(v, &stopped);
+#ifdef CS_EXP_OLDSTOP  // timing / repro build only (make exp): the round-3 form, which gave up without a second look
+        if (expired) {
+#else
         if (expired && !stopped) {
+#endif
           give_up = true;
           break;
         }
