@@ -31,9 +31,12 @@ from .spaces import gymnasium_api
 # i.e. BEFORE modules and the HIP runtime's own exit handlers are torn down: a context destroyed from __del__ during
 # interpreter shutdown calls into a runtime that may already be half gone.
 _open_envs = weakref.WeakSet()
+_owner_pid = os.getpid()
 
 
 def _close_open_envs():
+    if os.getpid() != _owner_pid:      # a forked child: the contexts are the parent's
+        return
     for env in list(_open_envs):
         try:
             env.close()
