@@ -22,20 +22,21 @@ graph-launch and synchronisation overhead would be a third of it).  --regions su
 each reduced with MAX over ranks; the MEDIAN region gives ms_per_step = wall / (R * K) and
 value = total envs * R * K / wall.  `single_pass` reports one bare pass for comparison.
 
-Rank 0 prints ONE JSON line (see the task contract) with, besides the contract keys,
+Rank 0 prints ONE COMPACT JSON line on stdout (<= 8 000 bytes, asserted here and in tests/): the contract keys,
   roofline     : algorithmic bytes (176 B/env-step) per launch over the
-                 launch duration measured with HIP events on the launch stream, vs 8 TB/s
-  sweep        : the same kernel at the other single-GPU sizes / tasks (Lander3D and Hover3D at
-                 262 144 = BASELINE configs[2], 1 M and 4 M envs), each with launch_us and frac
-  config5      : BASELINE configs[4] (dt = 1e-3, 10 substeps) with its bounds: HBM, float64 vector ALU (flops
-                 executed, by PMC) and float64 instruction issue (vector instructions executed x 4 cycles)
+                 launch duration measured with HIP events on the launch stream, vs 8 TB/s; beside it the kernel-only
+                 span (kernel_span_us / kernel_frac) and the PMC traffic per launch
   cpu_baseline : the scalar NumPy port of the reference (oracle/refcpu.py), timed here on
                  the host, 1 core, bounded sample (a reported baseline, not a target); beside
-                 it the other action law, all host cores (one process and env each) and the
-                 vectorised NumPy oracle
-and, reported BESIDE the headline (never as `value`), the K-steps-per-launch paths on the same
-envs: step_many (open loop over the resident action ring), rollout_pid (closed loop under the
-on-device PID heuristic), rollout_random (actions drawn on device).
+                 it all usable host cores (one process and env each) and the vectorised NumPy oracle
+  summary      : <= 1.5 KB: roofline fraction per sweep point, us per step of the K-step paths, config 5's bounds
+and writes the FULL record (every leg with its clocks, region spreads, byte models, bounds and notes) to
+--full-out (default gpurun_out/bench_full.json) and to stderr.  The default run times the headline, its kernel-only span,
+the CPU baseline, Hover3D at 262 144 envs (BASELINE configs[2]), config 5 at 65 536 envs (configs[4]), the HBM-resident
+Lander3D point (4 M envs) and the two K-steps-per-launch paths on the headline's envs (cs_step_many: open loop over the
+resident action ring; cs_rollout_pid: closed loop under the on-device PID heuristic) -- reported BESIDE the headline,
+never as `value`.  --full adds the rest of the sweep (other action laws, 262 144 / 1 M envs, Hover3D 1 M / 4 M, config 5
+at 1 M, the K-step kernels at 4 M), cs_rollout_random, the caller-compiled policy, the served leg and the launch floor.
 Multi-GPU: the env batch is sharded by contiguous env-id range with no data-path
 collective in the timed region ("scaling": "weak"); the optional concatenated-observation
 all-gather over RCCL (--gather) is timed separately and reported as value_with_allgather.
@@ -64,6 +65,11 @@ HOVER = 0.016560178185018043                        # motor value with thrust ==
 PEAK_ENGINE_CLOCK_HZ = 2.4e9
 SIMDS_PER_CU, LANES_PER_WAVE, ISSUE_CYCLES = 4, 64, 4
 INFINITY_CACHE_BYTES = 256 << 20                    # MI355X_MICROARCH.md: 256 MiB memory-side cache
+# The ONE stdout line is for a reader with a bounded buffer (the driver keeps ~8 KB of a run's stdout): contract keys,
+# roofline, cpu_baseline and a short summary only.  Everything else goes to the full record (--full-out) and stderr.
+LINE_BUDGET = 8000
+DEGRADED_EXIT = 3                                   # exit code when the N > 1 gather leg hit its deadline ("status": "degraded")
+SUMMARY_BUDGET = 1500
 
 def parse(argv=None):
     p = argparse.ArgumentParser()
@@ -91,12 +97,23 @@ def parse(argv=None):
                         "deadline) in a 1-rank RCCL group with the collective forced -- to exercise that path where "
                         "only one GPU is at hand")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-seconds", type=float, default=6.0,
+                   help="seconds of the one-core scalar port (the other CPU rows take 2 s each)")
     p.add_argument("--no-sweep", action="store_true", help="skip the batch-size / task sweep and config 5")
+    p.add_argument("--full", action="store_true",
+                   help="everything: the whole batch-size / task / action-law sweep, the K-step kernels at 4 M envs, the "
+                        "on-device random policy and the caller-compiled policy, the served leg, the fused caller-policy "
+                        "child and the launch-floor probe.  The DEFAULT run is the headline + its kernel-only span + the "
+                        "CPU baseline + one point per remaining single-GPU BASELINE config (Hover3D 262 144, config 5 at "
+                        "65 536) + the HBM-resident Lander3D point (4 M envs) + cs_step_many / cs_rollout_pid")
+    p.add_argument("--full-out", default=None,
+                   help="where the FULL record goes (default gpurun_out/bench_full.json under the repo root); stdout "
+                        "carries only the compact line (<= %d bytes)" % LINE_BUDGET)
     p.add_argument("--pid", type=int, default=100,
                    help="also time cs_rollout_pid / cs_rollout_random with this many steps per launch (0 = skip)")
-    p.add_argument("--served", type=int, default=500,
-                   help="also time served stepping (cs_serve_*) with this many steps per session (0 = skip)")
+    p.add_argument("--served", type=int, default=None,
+                   help="also time served stepping (cs_serve_*) with this many steps per session (0 = skip; default: 500 "
+                        "under --full / --served-all, else skipped)")
     p.add_argument("--served-all", action="store_true",
                    help="also time the served forms that do not pay against cs_step (DESIGN.md section 8): the closed loop "
                         "with a policy kernel per step, the same with a persistent policy kernel, and the plain-rows "
@@ -111,7 +128,10 @@ def parse(argv=None):
     p.add_argument("--many", type=int, default=100,
                    help="also time cs_step_many with this many steps per launch (0 = skip)")
     p.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
-    return p.parse_args(argv)
+    a = p.parse_args(argv)
+    if a.served is None:
+        a.served = 500 if (a.full or a.served_all) else 0
+    return a
 
 
 # ------------------------------------------------------------------------------------------
@@ -339,27 +359,60 @@ class LaunchFloor:
             self.graph.replay()
 
 
+class Hip:
+    """What main() and Timer ask of the device runtime: the device of this rank, synchronisation, HIP events on the
+    current (= launch) stream, the process-group backend.  There is no CPU variant in the product: the constructor
+    refuses a machine without a HIP device.  (tests/test_bench_launcher.py swaps a double in -- inside its own worker
+    processes only -- to run the N > 1 line assembly under gloo at the world size of the target node.)"""
+    backend = "nccl"                       # = RCCL on ROCm
+    graphs = True                          # hipGraph capture / replay of the step launches
+
+    def __init__(self, torch, local):
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+        self.torch = torch
+        self.device = torch.device("cuda", local)
+        torch.cuda.set_device(self.device)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def stamp(self):
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def elapsed_s(self, ev0, ev1):
+        return ev0.elapsed_time(ev1) * 1e-3
+
+    def cus_and_clock_hz(self):
+        props = self.torch.cuda.get_device_properties(self.device)
+        cus = int(getattr(props, "multi_processor_count", 256) or 256)
+        return cus, float(getattr(props, "clock_rate", 0) or 0) * 1e3 or PEAK_ENGINE_CLOCK_HZ     # (kHz -> Hz)
+
+    def init_group(self, dist):
+        dist.init_process_group(self.backend, device_id=self.device)
+
+
 class Timer:
     """barrier + synchronize on both sides of a region; host clock for the wall time (MAX over
     ranks), HIP events on the launch stream for the device time of the same region."""
 
-    def __init__(self, torch, dist, device):
-        self.torch, self.dist, self.device = torch, dist, device
+    def __init__(self, hip, dist):
+        self.hip, self.torch, self.dist, self.device = hip, hip.torch, dist, hip.device
 
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+        self.hip.synchronize()
 
     def region(self, runner, count):
         torch = self.torch
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.barrier()
         t0 = time.perf_counter()
-        ev0.record()
+        ev0 = self.hip.stamp()
         runner.run(count)
-        ev1.record()
-        torch.cuda.synchronize()
+        ev1 = self.hip.stamp()
+        self.hip.synchronize()
         t1 = time.perf_counter()
         self.barrier()
         wall = t1 - t0
@@ -367,7 +420,7 @@ class Timer:
             t = torch.tensor([wall], device=self.device, dtype=torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             wall = float(t.item())
-        return wall, ev0.elapsed_time(ev1) * 1e-3
+        return wall, self.hip.elapsed_s(ev0, ev1)
 
     def measure(self, runner, steps, warmup, min_region_s, regions, quantum=1, sampler=None):
         """-> dict: the median of `regions` timed regions of R * steps steps each (R chosen so that
@@ -599,7 +652,7 @@ def cpu_baseline(task, law, seconds):
     steps, dt = _scalar_port((task, law, seconds, 0))
     # the 1-core row for both action laws of the headline workloads
     other = "const" if law != "const" else "uniform"
-    o_steps, o_dt = _scalar_port((task, other, max(2.0, seconds / 4), 1))
+    o_steps, o_dt = _scalar_port((task, other, 2.0, 1))
     scalar = steps / dt
     # All usable cores, one process and one env each.  The pool is sized by what this process may USE -- the affinity
     # set capped by the cgroup CPU quota -- not by os.cpu_count() (the host's thread count: round 4 started 256
@@ -609,7 +662,7 @@ def cpu_baseline(task, law, seconds):
     all_cores = None
     if topo["cores_usable"] > 1:
         import multiprocessing as mp
-        per = max(2.0, seconds / 4)
+        per = 2.0
         tried = []
         try:
             procs = topo["cores_usable"]
@@ -640,7 +693,7 @@ def cpu_baseline(task, law, seconds):
     acts = rng.uniform(-1, 1, (nv, 4))
     t0 = time.perf_counter()
     k = 0
-    while time.perf_counter() - t0 < max(2.0, seconds / 4):
+    while time.perf_counter() - t0 < 2.0:
         v.step(acts)
         k += 1
     vec = nv * k / (time.perf_counter() - t0)
@@ -766,6 +819,99 @@ def run_config(torch, timer, gca, a, task, n, law, substeps, device, rank, steps
     return m
 
 
+def _short(x, digits=6):
+    """Floats to `digits` significant digits (recursively): the compact line is read by people and a bounded parser."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _short(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_short(v, digits) for v in x]
+    return x
+
+
+def compact_line(full, full_path=None, budget=LINE_BUDGET, summary_budget=SUMMARY_BUDGET):
+    """The ONE stdout line (a str, no newline) from the full record `assemble()` builds: the contract keys, `roofline`
+    and `cpu_baseline` with their listed sub-keys only, and a `summary` of at most `summary_budget` bytes -- trimmed,
+    least important key first, until the whole line is within `budget` bytes.  Never raises on a missing key: a leg
+    that did not run is simply absent."""
+    pick = lambda d, *ks: {k: d[k] for k in ks if isinstance(d, dict) and k in d and d[k] is not None}
+    cfg = full.get("config", {})
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                     "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = dict(pick(cfg, "workload", "envs_per_gpu", "total_envs", "task", "actions", "state_words",
+                               "substeps", "parallelism"))
+    line["config"]["workload"] = str(line["config"].get("workload", ""))[:200]
+    line["status"] = full.get("status", "ok")
+    line.update(pick(full, "timed_steps_total", "timed_region_s"))
+    rf = full.get("roofline", {})
+    r = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    r.update(_short(pick(rf, "kernel", "launch_us", "kernel_span_us", "kernel_frac", "algorithmic_bytes_per_launch",
+                         "resident")))
+    r["source"] = ("achieved = algorithmic_bytes_per_launch / launch_us (HIP events on the launch stream, median region, "
+                   "dependent-launch gap included); kernel_span_us = the kernel alone (span build, child process); "
+                   "traffic = %s" % ("profiles/traffic.json (rocprofv3 PMC, stamped with this tree's kernel sources)"
+                                     if rf.get("traffic") is not None else "withheld (no PMC figure for these sources)"))
+    line["roofline"] = r
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = pick(cb, "value", "unit", "cores", "kind", "cpu_model")
+        c["sample"] = str(cb.get("sample", ""))[:220]
+        if isinstance(cb.get("all_cores"), dict) and "value" in cb["all_cores"]:
+            c["all_cores"] = _short(pick(cb["all_cores"], "value", "cores"))
+        if isinstance(cb.get("vectorised_numpy"), dict):
+            c["vectorised_numpy"] = _short(pick(cb["vectorised_numpy"], "value"))
+        line["cpu_baseline"] = c
+    if full.get("rccl") is not None:
+        line["rccl"] = full["rccl"]
+    line.update(pick(full, "value_with_packed_allgather", "ms_per_step_with_packed_allgather", "packed_allgather_note"))
+    if "value_with_packed_allgather" in full and full["value_with_packed_allgather"] is None:
+        line["value_with_packed_allgather"] = None
+    if full_path:
+        line["full_record"] = full_path
+    # the summary: most important first; dropped from the END until it fits
+    sm = full.get("summary", {}) if isinstance(full.get("summary"), dict) else {}
+    order = ("sweep_frac", "k_step_us", "config5", "config5_launch_us", "k_step_issue_frac", "f64_load_clock_GHz",
+             "with_packed_allgather", "sweep_4m_launch_us_min_median_max", "served_us", "fused_caller_policy_us")
+    summary = {k: _short(sm[k], 4) for k in order if sm.get(k) not in (None, {}, [])}
+    size = lambda o: len(json.dumps(o, separators=(", ", ": ")))
+    keys = list(summary)
+    while keys and size(summary) > summary_budget:
+        del summary[keys.pop()]
+    line["summary"] = summary
+    text = json.dumps(line)
+    while len(text) > budget and line["summary"]:
+        del line["summary"][list(line["summary"])[-1]]
+        text = json.dumps(line)
+    if len(text) > budget:          # (cannot happen with the fields above; a hard stop rather than a long line)
+        for k in ("cpu_baseline", "roofline"):
+            line[k].pop("sample", None)
+            line[k].pop("source", None)
+        text = json.dumps(line)
+    assert len(text) <= budget, "bench.py: compact line is %d bytes (> %d)" % (len(text), budget)
+    return text
+
+
+def emit(full, real_stdout, full_out):
+    """Full record -> the side file and stderr; compact line -> the saved stdout descriptor (ONE line, last)."""
+    path = full_out or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    shown = None
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f)
+            f.write("\n")
+        shown = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT + os.sep) else path
+    except OSError as e:
+        print("bench.py: full record not written to %s: %r" % (path, e), file=sys.stderr, flush=True)
+    try:
+        sys.stderr.write("bench.py full record: " + json.dumps(full) + "\n")
+        sys.stderr.flush()
+    except Exception:
+        pass
+    os.write(real_stdout, (compact_line(full, shown) + "\n").encode())
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse(argv)
@@ -813,11 +959,9 @@ def main(argv=None):
             # world 1: gym_copter_amd.sharded would shortcut the all-gathers to a return / a device copy;
             # the legs below are there to exercise RCCL, so ask for the collective
             os.environ.setdefault("COPTERSTEP_FORCE_COLLECTIVE", "1")
-        torch.cuda.set_device(local)
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
-    timer = Timer(torch, dist, device)
+    hip = Hip(torch, local)
+    device = hip.device
+    timer = Timer(hip, dist)
     rccl = None
     with stdout_to_stderr():
         if dist is not None:
@@ -826,7 +970,7 @@ def main(argv=None):
                 # whatever else the box has can cost minutes; the data path is xGMI either way
                 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
                 os.environ.setdefault("NCCL_IB_DISABLE", "1")
-            dist.init_process_group("nccl", device_id=device)
+            hip.init_group(dist)
         timer.barrier()      # (N > 1: the communicator is set up here, outside every timed region)
         if dist is not None:
             # what RCCL itself saw: an all-reduce of ones over the group (the driver can check N ranks took part)
@@ -838,9 +982,7 @@ def main(argv=None):
     import gym_copter_amd as gca
     n = a.envs
     min_region_s = a.min_region_ms * 1e-3
-    props = torch.cuda.get_device_properties(device)
-    cus = int(getattr(props, "multi_processor_count", 256) or 256)
-    clock_hz = float(getattr(props, "clock_rate", 0) or 0) * 1e3 or PEAK_ENGINE_CLOCK_HZ     # (kHz -> Hz)
+    cus, clock_hz = hip.cus_and_clock_hz()
     pmc, pmc_src = load_stamped("pmc_counts.json")
     pmc = pmc or {}
     env = gca.CopterVecEnv(task=a.task, num_envs=n, device=local, seed=1234,
@@ -866,7 +1008,7 @@ def main(argv=None):
     # graphs have been instantiated is served several times more slowly by the hardware scheduler (DESIGN.md section 8;
     # the env kernel's own stream is created with the context for the same reason)
     served_side = [torch.cuda.Stream(device=device) for _ in (0, 1)] if a.served > 0 else None
-    use_graph = not a.no_graph
+    use_graph = hip.graphs and not a.no_graph
     chunk = graph_chunk_for(a.steps, a.graph_chunk)
     stepper = Stepper(torch, env, actions, use_graph, chunk, produce=a.produce_actions)
     m = timer.measure(stepper, a.steps, a.warmup, min_region_s, a.regions, quantum=chunk if use_graph else 1,
@@ -908,8 +1050,9 @@ def main(argv=None):
             # `steps` echoes --steps; what was actually timed (the driver's consistency arithmetic should use these):
             "timed_steps_total": m["steps"] * m["repeats"] * m["regions"],
             "timed_region_s": m["wall_s"],
-            "timing": "median of %d regions of %d x %d steps (hipGraphs of %d launches), each bracketed by barrier + "
-                      "synchronize, MAX over ranks" % (m["regions"], m["repeats"], m["steps"], chunk),
+            "timing": "median of %d regions of %d x %d steps (%s), each bracketed by barrier + "
+                      "synchronize, MAX over ranks" % (m["regions"], m["repeats"], m["steps"],
+                                                       "hipGraphs of %d launches" % chunk if use_graph else "eager launches"),
             "single_pass": m["single_pass"],
             "config": {"workload": "%s, %d envs/GPU, %s actions, auto-reset NEXT_STEP, %s state words, "
                                    "dt=%g x %d substeps, %s" % (a.task, n, a.actions, a.state,
@@ -989,7 +1132,6 @@ def main(argv=None):
                                              ("closed_loop_law_with_state", "linear_policy_44_weights", "replay_policy")
                                              if k in extra.get("rollout_custom", {})},
                   "rccl": rccl}
-        out["roofline"]["digest"] = digest
         out["summary"] = digest
         return out
 
@@ -1005,7 +1147,7 @@ def main(argv=None):
             """step + collective per step, hipGraph-captured like the headline when RCCL allows it."""
             if bind is not None:
                 bind()
-            mode = "graph"
+            mode = "graph" if use_graph else "eager"
             try:
                 st = Stepper(torch, env, actions, use_graph, chunk, post=post)
             except Exception as e:      # capture of the collective refused: time it eagerly instead
@@ -1037,7 +1179,7 @@ def main(argv=None):
             pipe = HalfBatchPipeline(task=a.task, total_envs=total_envs, gather="all", device=local, seed=1234,
                                      autoreset_mode="next_step", state_dtype=a.state, substeps=a.substeps)
             pipe.reset()
-            mode4 = "graph"
+            mode4 = "graph" if use_graph else "eager"
             try:
                 pr = PipeStepper(torch, pipe, actions, device, use_graph, chunk)
             except Exception as e:
@@ -1092,14 +1234,14 @@ def main(argv=None):
                    "cs_rollout_pid: closed loop, upstream's PID landing heuristic evaluated on device "
                    "(tests/test_gpu_parity.py::test_rollout_pid_policy_is_bit_exact); episodes under "
                    "upstream's gains end by tilt after ~130 steps and auto-reset")
-    if a.pid > 0:
+    if a.pid > 0 and a.full:
         # random policy on device: the headline's action law with no action tensor, K steps per launch
         k = a.pid
         env.reset()
         k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 136.0 / k,
                    "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
                    "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)")
-    if a.pid > 0 and world == 1:     # (N = 1 only: a compile that failed on ONE rank would leave the others at a barrier)
+    if a.pid > 0 and world == 1 and a.full:     # (N = 1 only: a compile that failed on ONE rank would leave the others at a barrier)
         # the CALLER'S OWN policy fused into the K-step kernel, the Python route: a linear law given as HIP source,
         # compiled with hipcc here and now (gym_copter_amd.compile_policy), K closed-loop steps per launch
         try:
@@ -1233,7 +1375,7 @@ struct Policy {
                         "bit-identical to cs_step_many / a twin stepped with cs_step in the same run"}
         except Exception as e:              # an extra never costs the headline
             extra["rollout_custom"] = {"error": repr(e)}
-    if a.pid > 0 and world == 1 and not any(k.startswith("ROCPROF") for k in os.environ) \
+    if a.full and a.pid > 0 and world == 1 and not any(k.startswith("ROCPROF") for k in os.environ) \
             and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
         fused_policy_leg()
     if (world > 1 or a.default_gather_leg) and dist is not None and not a.gather:
@@ -1249,17 +1391,15 @@ struct Policy {
             extra["packed_allgather_note"] = "the default packed all-gather leg did not finish within its deadline: abandoned"
             try:
                 if rank == 0:
-                    line = None
                     for _ in range(5):          # (the main thread may be adding a key at this very moment)
                         try:
-                            line = json.dumps(assemble())
+                            emit(assemble(), real_stdout, a.full_out)
                             break
                         except RuntimeError:
                             time.sleep(0.05)
-                    if line is not None:
-                        os.write(real_stdout, (line + "\n").encode())
             finally:
-                os._exit(0)
+                # non-zero: a launcher must see that this run did not finish all it set out to do (the line is out)
+                os._exit(DEGRADED_EXIT)
         deadline_s = float(os.environ.get("BENCH_GATHER_DEADLINE_S", 150.0))
         dog = threading.Timer(deadline_s, give_up)
         dog.daemon = True
@@ -1287,6 +1427,8 @@ struct Policy {
                   ("lander3d", 1048576, "uniform", 8),
                   ("hover3d", 1048576, "uniform", 8), ("lander3d", 4194304, "uniform", 4),
                   ("hover3d", 4194304, "uniform", 4)]
+        if not a.full:       # the default run: BASELINE configs[2] and the HBM-resident point of the headline's kernel
+            points = [("hover3d", 262144, "uniform", 16), ("lander3d", 4194304, "uniform", 4)]
         tile_bytes = 5632 if a.state != "float64" else 10752     # copterstep_internal.h: make_layout (4 groups + FE + RET + EPH)
 
         def resident(task, nn, ring):
@@ -1371,9 +1513,10 @@ struct Policy {
             torch.cuda.empty_cache()
         # ... and where an instruction-issue bound is a bound: 16 wavefronts per SIMD (VERDICT round 4 #1b)
         try:
-            c5 = config5_point(1048576, 8, 3)
-            c5["actions"] = "near_hover_substeps10"
-            sweep.append(c5)
+            if a.full:
+                c5 = config5_point(1048576, 8, 3)
+                c5["actions"] = "near_hover_substeps10"
+                sweep.append(c5)
         except Exception as e:
             sweep.append({"task": "lander3d", "envs": 1048576, "actions": "near_hover_substeps10", "error": repr(e)})
             torch.cuda.empty_cache()
@@ -1414,7 +1557,7 @@ struct Policy {
                 envL.close()
                 del envL
                 torch.cuda.empty_cache()
-        if a.many > 0 and a.state == "float32":
+        if a.full and a.many > 0 and a.state == "float32":
             nn, k = 4194304, 16
             try:
                 def mk_many(envL):
@@ -1424,7 +1567,7 @@ struct Policy {
             except Exception as e:
                 sweep.append({"leg": "step_many", "envs": nn, "actions": "step_many", "task": "lander3d", "error": repr(e)})
                 torch.cuda.empty_cache()
-        if a.pid > 0 and a.state == "float32":
+        if a.full and a.pid > 0 and a.state == "float32":
             nn, k = 4194304, 16
             try:
                 def mk_pid(envL):
@@ -1437,13 +1580,13 @@ struct Policy {
                 torch.cuda.empty_cache()
         extra["sweep"] = sweep
 
-    if rank == 0 and use_graph and not a.no_sweep:
+    if rank == 0 and use_graph and not a.no_sweep and a.full:
         # context for the headline's latency-bound figure: what ONE dependent launch costs on this box when the
         # kernel does next to nothing -- a hipGraph chain of in-place adds on 64 Ki floats (1 024 x 64 threads)
         try:
             probe = torch.zeros(65536, dtype=torch.float32, device=device)
 
-            fl = Timer(torch, None, device).measure(LaunchFloor(torch, probe, device), 2000, 200, min_region_s, 3,
+            fl = Timer(hip, None).measure(LaunchFloor(torch, probe, device), 2000, 200, min_region_s, 3,
                                                     quantum=100)
             extra["dependent_launch_floor"] = {
                 "us_per_launch": fl["launch_s"] * 1e6,
@@ -1457,10 +1600,10 @@ struct Policy {
     if sampler_proc is not None:
         sampler_proc.close()
     if rank == 0:
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        emit(out, real_stdout, a.full_out)
     os.close(real_stdout)
     if dist is not None:
-        torch.cuda.synchronize()
+        hip.synchronize()
         profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
         if launched or profiled:
             dist.destroy_process_group()

@@ -34,6 +34,8 @@ for src, dst in (("/trace/*/*_kernel_stats.csv", "kernel_stats_bench_default.csv
 for name in ("summary.txt", "summary.json"):
     shutil.copy(P + "/" + name, R + "/profiles/%s_%s" % (RND, name))
 shutil.copy(P + "/bench_unprofiled.json", R + "/profiles/%s_bench_default.json" % RND)
+if os.path.exists(P + "/bench_full_unprofiled.json"):       # (round 6 on: the line is compact, the full record beside it)
+    shutil.copy(P + "/bench_full_unprofiled.json", R + "/profiles/%s_bench_full.json" % RND)
 for f in sorted(glob.glob(P + "/span_*.json")):
     shutil.copy(f, R + "/profiles/%s_%s" % (RND, os.path.basename(f)))
 

@@ -15,11 +15,14 @@ T="timeout ${STEP_TIMEOUT:-400}"
 step() {  # <label>: note how long the previous step took (progress.txt travels back even if a later step is killed)
   echo "$(date +%s) $1" >> $OUT/progress.txt
 }
-BENCH="python3 $R/bench.py --steps 1000 --warmup 200 --no-cpu-baseline"
+# --full: every leg (the default bench run is a subset); the profiled runs keep the compact stdout line in their logs and
+# drop their full record, the un-profiled run's full record is kept beside its line
+BENCH0="python3 $R/bench.py --steps 1000 --warmup 200 --no-cpu-baseline --full"
+BENCH="$BENCH0 --full-out /dev/null"
 LIGHT="$BENCH --no-sweep --pid 0 --many 0 --served 0"
 step bench_unprofiled
-# 0. the un-profiled bench line of the same build (what the profiled figures are compared with)
-$T $BENCH > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+# 0. the un-profiled bench line of the same build (what the profiled figures are compared with) + its full record
+$T $BENCH0 --full-out $OUT/bench_full_unprofiled.json > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 step trace
 # 1. per-kernel time of the bench default command (65 536 envs, hipGraph replay, with the sweep, config 5 and
 #    the K-step extras).  The summary groups kernel_trace.csv by (kernel name, grid size): the 262 144-env and

@@ -171,3 +171,19 @@ def device_episode_bits(max_steps):
     while (1 << s) - 1 < 2 * (max_steps + 1):
         s += 1
     return 29 - s
+
+
+def bench_records(stdout, full_path):
+    """bench.py's two outputs -> (compact line as a dict, full record as a dict).  Asserts what a bounded reader of
+    stdout relies on: ONE line, at most 8 000 bytes, nothing after it, and that the line agrees with the full record
+    on the contract values."""
+    import json
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and stdout.endswith("\n"), stdout[-2000:]
+    assert len(lines[0]) <= 8000, len(lines[0])
+    line = json.loads(lines[0])
+    full = json.load(open(full_path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "status"):
+        assert line[k] == full[k], k
+    assert line["roofline"]["frac"] == full["roofline"]["frac"]
+    return line, full

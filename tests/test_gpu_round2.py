@@ -478,17 +478,17 @@ def test_bench_as_a_torchrun_rank_with_gather_legs(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20",
            "--warmup", "5", "--gather", "--no-sweep", "--no-cpu-baseline", "--pid", "0", "--many", "0",
-           "--min-region-ms", "5", "--regions", "3"]
+           "--min-region-ms", "5", "--regions", "3", "--full-out", str(tmp_path / "full.json")]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     from gpu_util import run_with_rccl
     p = run_with_rccl(cmd, env, 300, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-4000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    d = json.loads(lines[0])
+    from gpu_util import bench_records
+    line, d = bench_records(p.stdout, tmp_path / "full.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
-        assert k in d, k
+        assert k in d and k in line, k
+    assert line["rccl"] == d["rccl"] and line["value_with_packed_allgather"] == d["value_with_packed_allgather"]
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
     assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     for k in ("value_with_allgather", "value_with_packed_allgather", "value_with_pipelined_allgather"):

@@ -524,15 +524,15 @@ def test_bench_gather_on_one_gpu_reports_what_rccl_saw(tmp_path):
     import sys
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--gather",
            "--no-sweep", "--no-cpu-baseline", "--pid", "0", "--many", "0", "--served", "0", "--min-region-ms", "5",
-           "--regions", "3"]
+           "--regions", "3", "--full-out", str(tmp_path / "full.json")]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("COPTERSTEP_FORCE_COLLECTIVE", None)
     from gpu_util import run_with_rccl
     p = run_with_rccl(cmd, env, 300, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-4000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    d = json.loads(lines[0])
+    from gpu_util import bench_records
+    line, d = bench_records(p.stdout, tmp_path / "full.json")
+    assert line["rccl"] == d["rccl"] and list(line)[-1] == "summary"
     assert d["rccl"] == {"backend": "nccl", "world_size": 1, "ranks_seen": 1}
     assert d["allgather_is_a_collective"] is True
     assert set(d["allgather_launch_mode"]) == {"obs", "packed", "pipelined"}

@@ -505,21 +505,25 @@ def test_a_differing_stored_word_after_one_step_is_a_straddled_rounding_boundary
 # ---------------------------------------------------------------------------------------
 # bench.py: the line's new parts
 # ---------------------------------------------------------------------------------------
-def _bench(args, tmp_path, extra_env=None):
+def _bench(args, tmp_path, extra_env=None, expect_rc=0):
     import json
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-           "--no-cpu-baseline", "--min-region-ms", "5", "--regions", "3"] + args
+           "--no-cpu-baseline", "--min-region-ms", "5", "--regions", "3", "--full-out", str(tmp_path / "full.json")] + args
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     env.pop("COPTERSTEP_FORCE_COLLECTIVE", None)
     from gpu_util import run_with_rccl
     p = run_with_rccl(cmd, env, 300, cwd=str(tmp_path))
-    assert p.returncode == 0, p.stderr[-4000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    if expect_rc == 0:
+        assert p.returncode == 0, p.stderr[-4000:]
+    else:
+        assert p.returncode == expect_rc, (p.returncode, p.stderr[-4000:])
+    from gpu_util import bench_records
+    line, full = bench_records(p.stdout, tmp_path / "full.json")
+    full["_line"] = line
+    return full
 
 
 def test_bench_default_gather_leg_and_its_deadline(tmp_path):
@@ -532,8 +536,10 @@ def test_bench_default_gather_leg_and_its_deadline(tmp_path):
     assert set(d["allgather_launch_mode"]) == {"packed"} and 0 < d["value_with_packed_allgather"] <= d["value"] * 1.05
     assert d["packed_allgather_bytes_per_rank"] == 65536 * 12 * 4
     assert d["summary"]["with_packed_allgather"]["value_with_packed_allgather"] == d["value_with_packed_allgather"]
-    d = _bench(light, tmp_path, {"BENCH_GATHER_DEADLINE_S": "4", "BENCH_TEST_HANG_GATHER": "1"})
+    assert d["_line"]["value_with_packed_allgather"] == d["value_with_packed_allgather"] and d["_line"]["status"] == "ok"
+    d = _bench(light, tmp_path, {"BENCH_GATHER_DEADLINE_S": "4", "BENCH_TEST_HANG_GATHER": "1"}, expect_rc=3)
     assert d["value"] > 1e9 and d["value_with_packed_allgather"] is None and "deadline" in d["packed_allgather_note"]
+    assert d["status"] == "degraded" and d["_line"]["status"] == "degraded" and d["_line"]["value_with_packed_allgather"] is None
 
 
 def test_bench_line_carries_span_issue_bounds_and_residency(tmp_path):
@@ -541,7 +547,7 @@ def test_bench_line_carries_span_issue_bounds_and_residency(tmp_path):
     the span build), the issue bound of the headline and of a K-step leg from the stamped PMC counts (or the reason they
     are withheld), config 5's three bounds, `resident` on every sweep point, the constant-thrust leg."""
     import os
-    d = _bench(["--pid", "0", "--served", "0", "--many", "64"], tmp_path)
+    d = _bench(["--pid", "0", "--served", "0", "--many", "64", "--full"], tmp_path)
     rf = d["roofline"]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if os.path.exists(os.path.join(root, "gym_copter_amd", "csrc", "build", "libcopterstep_span.so")):
@@ -561,7 +567,7 @@ def test_bench_line_carries_span_issue_bounds_and_residency(tmp_path):
     assert ("lander3d", 65536, "const") in sweep and sweep[("lander3d", 65536, "const")]["frac"] > 0.2
     assert sweep[("hover3d", 262144, "uniform")]["resident"] == "infinity_cache"
     assert sweep[("lander3d", 4194304, "uniform")]["resident"] == "hbm"
-    assert "served_submit_collect" not in d and list(d)[-1] == "summary"
+    assert "served_submit_collect" not in d and list(d["_line"])[-1] == "summary"
     assert d["summary"]["sweep_resident"]["lander3d_4194304_uniform"] == "hbm"
 
 

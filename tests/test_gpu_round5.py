@@ -172,21 +172,22 @@ def test_clock_probe_and_pci_address():
 
 
 def _bench(args, tmp_path, timeout=900):
+    from gpu_util import bench_records
     out = tmp_path / "line.json"
     with open(out, "w") as f:
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=f, stderr=subprocess.PIPE,
-                           text=True, timeout=timeout)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--full-out", str(tmp_path / "full.json")] + args,
+                           stdout=f, stderr=subprocess.PIPE, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = open(out).read().strip().splitlines()
-    assert len(lines) == 1, "stdout must carry ONE line"
-    return json.loads(lines[0])
+    line, full = bench_records(open(out).read(), tmp_path / "full.json")
+    full["_line"] = line
+    return full
 
 
 def test_bench_line_round5_blocks(tmp_path):
     """The driver-form line: status, clocks (sysfs + in-kernel), region spreads on the HBM-resident points, the sweep
     points where an instruction-issue bound binds (config 5 at 1 M envs, the K-step kernels at 4 M envs), a CPU
     baseline whose all-core row names the cores it could use, and only the served leg that pays."""
-    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "4"], tmp_path)
+    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "4", "--full"], tmp_path)
     assert d["status"] == "ok" and d["summary"]["status"] == "ok"
     ck = d["clocks"]
     assert 0.8 < ck["f64_load_clock_GHz"]["4"] <= 2.6 and ck["peak_engine_clock_GHz"] > 2.0
@@ -216,6 +217,37 @@ def test_bench_line_round5_blocks(tmp_path):
         assert 0.4 < allc["scaling_efficiency"] < 1.3, allc
     assert "served_producers_ahead" in d and "served_closed_loop" not in d and "served_closed_loop_persistent_policy" not in d
     assert "next_action_prefetch" not in d["config"]
+
+
+def test_default_bench_line_is_compact_and_on_a_diet(tmp_path):
+    """The driver's exact command: ONE stdout line of at most 8 000 bytes with the contract
+    keys, `roofline` and `cpu_baseline`; the default run times one point per single-GPU BASELINE config, the
+    HBM-resident Lander3D point and the two K-step paths, nothing else; the full record sits beside it."""
+    import time
+    t0 = time.time()
+    d = _bench(["--gpus", "1", "--steps", "20", "--warmup", "5"], tmp_path)
+    wall = time.time() - t0
+    line = d["_line"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "status", "roofline", "cpu_baseline", "summary"):
+        assert k in line, k
+    assert line["metric"].startswith("env-steps/sec Lander3D at 65 536 envs") and line["n_gpus"] == 1
+    assert (line["steps"], line["warmup"], line["status"], line["dtype"]) == (20, 5, "ok", "f64")
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and rf["algorithmic_bytes_per_launch"] == 176 * 65536
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.2 < rf["frac"] < 1.0
+    assert abs(rf["achieved"] - 176 * 65536 / (rf["launch_us"] * 1e-6) / 1e9) < 1e-3 * rf["achieved"]
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and 1e3 < cb["value"] < 1e6 and "refcpu" in cb["sample"]
+    sm = line["summary"]
+    assert set(sm["sweep_frac"]) == {"hover3d_262144_uniform", "lander3d_4194304_uniform"}
+    assert set(sm["k_step_us"]) == {"step_many", "rollout_pid"} and len(sm["config5"]) == 3
+    sweep = {(e["task"], e["envs"], e["actions"]) for e in d["sweep"]}
+    assert sweep == {("hover3d", 262144, "uniform"), ("lander3d", 4194304, "uniform")}
+    assert d["config5"]["envs"] == 65536 and d["config5"]["substeps"] == 10
+    for k in ("rollout_random", "rollout_policy_linear", "served_producers_ahead", "rollout_custom", "dependent_launch_floor"):
+        assert k not in d, k
+    assert wall < 90, wall        # (incl. a cold `import torch`; the driver saw 30.6 s for round 5's default run)
 
 
 def test_rollout_pid_with_upstreams_gains_compiled_in_equals_the_generic_kernel():
