@@ -44,6 +44,62 @@ __device__ __forceinline__ void sincos_kernel(const double* t, double y, double&
   }
 }
 
+// The three kernels above in LOCK-STEP: one Horner step of all six chains, then the next -- the same operations on the
+// same values as three sincos_kernel calls (bit-identical), in an order the compiler may not undo: an empty asm
+// statement that names the six accumulators after every step (each next step depends on its outputs; asm volatile
+// statements keep their order).  Left to itself the compiler emits each chain as back-to-back dependent float64 FMAs
+// (8 cycles apiece for a lone wavefront, profiles/r02_issue_cost_ubench.txt) although the six chains are independent;
+// six-way interleaved an instruction costs 4.5-5.  (__builtin_amdgcn_sched_barrier does not do it: the optimiser moves
+// the arithmetic across the intrinsic before the machine scheduler ever sees it -- tried, round 6.)
+#define CS_PIN6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
+#define CS_PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+template <bool FULL>
+__device__ __forceinline__ void sincos3_lockstep(const double* t, double a, double b, double g, double& sa,
+                                                 double& ca, double& sb, double& cb, double& sg, double& cg) {
+  double za = a * a, zb = b * b, zg = g * g;
+  CS_PIN3(za, zb, zg);
+  constexpr int S0 = FULL ? 9 : 19, NS = FULL ? 5 : 3;   // sine: t[S0] .. t[S0 - NS], NS Horner steps
+  constexpr int C0 = FULL ? 15 : 24, NC = FULL ? 5 : 4;  // cosine: t[C0] .. t[C0 - NC]
+  double pa = fma(za, t[S0], t[S0 - 1]), pb = fma(zb, t[S0], t[S0 - 1]), pg = fma(zg, t[S0], t[S0 - 1]);
+  double qa = fma(za, t[C0], t[C0 - 1]), qb = fma(zb, t[C0], t[C0 - 1]), qg = fma(zg, t[C0], t[C0 - 1]);
+  CS_PIN6(pa, pb, pg, qa, qb, qg);
+#pragma unroll
+  for (int k = 2; k <= NS; ++k) {
+    pa = fma(za, pa, t[S0 - k]);
+    pb = fma(zb, pb, t[S0 - k]);
+    pg = fma(zg, pg, t[S0 - k]);
+    qa = fma(za, qa, t[C0 - k]);
+    qb = fma(zb, qb, t[C0 - k]);
+    qg = fma(zg, qg, t[C0 - k]);
+    CS_PIN6(pa, pb, pg, qa, qb, qg);
+  }
+  double ya = a * za, yb = b * zb, yg = g * zg;
+  if constexpr (FULL) {
+    double wa = -(za * za) * qa, wb = -(zb * zb) * qb, wg = -(zg * zg) * qg;
+    CS_PIN6(ya, yb, yg, wa, wb, wg);
+    sa = fma(ya, pa, a);
+    sb = fma(yb, pb, b);
+    sg = fma(yg, pg, g);
+    double ua = fma(0.5, za, wa), ub = fma(0.5, zb, wb), ug = fma(0.5, zg, wg);
+    CS_PIN6(sa, sb, sg, ua, ub, ug);
+    ca = 1.0 - ua;
+    cb = 1.0 - ub;
+    cg = 1.0 - ug;
+  } else {
+    static_assert(FULL || NC == NS + 1, "short form: the cosine chains are one step longer");
+    qa = fma(za, qa, t[C0 - NC]);  // the cosine's last Horner step shares a slot with the sine's y * z
+    qb = fma(zb, qb, t[C0 - NC]);
+    qg = fma(zg, qg, t[C0 - NC]);
+    CS_PIN6(ya, yb, yg, qa, qb, qg);
+    sa = fma(ya, pa, a);
+    sb = fma(yb, pb, b);
+    sg = fma(yg, pg, g);
+    ca = fma(za, qa, 1.0);
+    cb = fma(zb, qb, 1.0);
+    cg = fma(zg, qg, 1.0);
+  }
+}
+
 template <bool FULL>
 __device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& s, double& c) {
   if (__builtin_expect(fabs(x) >= 8.0e5, 0)) {

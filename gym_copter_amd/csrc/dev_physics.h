@@ -166,9 +166,13 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, co
     // the controllers' sixteen state words live across the step, six interleaved chains cost them 1 % instead of
     // saving 1-2 %: interleaved A/B, round 5.)
     if (__builtin_expect(__all(fabs(x[6]) < 0.785 && fabs(x[8]) < 0.785 && fabs(x[10]) < 0.785), 1)) {
+#ifdef CS_EXP_LOCKSTEP
+      sincos3_lockstep<FULL>(c.trig, x[6], x[8], x[10], t.sph, t.cph, t.sth, t.cth, t.sps, t.cps);
+#else
       sincos_kernel<FULL>(c.trig, x[6], t.sph, t.cph);
       sincos_kernel<FULL>(c.trig, x[8], t.sth, t.cth);
       sincos_kernel<FULL>(c.trig, x[10], t.sps, t.cps);
+#endif
     } else {
       sincos_roll_pitch<FULL, IN_LOOP>(c, x[6], x[8], t);
       sincos_yaw<FULL, IN_LOOP>(c, x[10], t);
@@ -197,9 +201,13 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, co
 template <bool FULL, bool GYRO>
 __device__ __forceinline__ void physics_flight(const DevConst& c, const Coef& q, const Wrench& w, double (&x)[12]) {
   Trig t;
+#ifdef CS_EXP_LOCKSTEP
+  sincos3_lockstep<FULL>(c.trig, x[6], x[8], x[10], t.sph, t.cph, t.sth, t.cth, t.sps, t.cps);
+#else
   sincos_kernel<FULL>(c.trig, x[6], t.sph, t.cph);
   sincos_kernel<FULL>(c.trig, x[8], t.sth, t.cth);
   sincos_kernel<FULL>(c.trig, x[10], t.sps, t.cps);
+#endif
   double ax, ay, netz;
   thrust_ned(q, w.bz, t, ax, ay, netz);
   const double dt = c.dt;

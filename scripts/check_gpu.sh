@@ -14,9 +14,9 @@ timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log
 echo "smoke rc=$?" >> $OUT/smoke.log
 tail -3 $OUT/smoke.log
 # the driver's exact command: the compact line on stdout (<= 8 000 bytes), the full record beside it; wall time noted
-t0=$(date +%s.%N)
+t0=$(date +%s%N)
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --full-out $OUT/bench_full.json > $OUT/bench_driver_form.json 2> $OUT/bench_driver_form.err
-echo "bench rc=$? wall=$(echo "$(date +%s.%N) - $t0" | bc) s bytes=$(wc -c < $OUT/bench_driver_form.json)" | tee $OUT/bench_driver_form.wall
+echo "bench rc=$? wall_ms=$(( ($(date +%s%N) - t0) / 1000000 )) bytes=$(wc -c < $OUT/bench_driver_form.json)" | tee $OUT/bench_driver_form.wall
 cat $OUT/bench_driver_form.json
 if [ -f $R/gym_copter_amd/csrc/build/libcopterstep_kstamps.so ]; then
   timeout 600 python3 $R/tools/kstep_stamps.py 65536 8 > $OUT/kstep_stamps.txt 2> $OUT/kstep_stamps.err

@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 gloo process group.  The product's sharding host code
+"""N>1 path on CPU: gloo process groups of 2, 4 and 8 ranks (8 = the target node).  The product's sharding host code
 (shard arithmetic, global-id keyed seeding, all-gather ordering) runs unmodified; the local
 stepper class it instantiates (gym_copter_amd.vecenv.CopterVecEnv, which needs a GPU) is swapped --
 inside this test's worker processes only -- for a stand-in backed by the CPU oracle.  The sharded
@@ -23,7 +23,7 @@ TOTAL, STEPS = 96, 40
 class OracleLocalEnv:
     """Test double with CopterVecEnv's surface, computing on the CPU oracle."""
 
-    def __init__(self, task, num_envs, device, env_id_base, seed=0, autoreset_mode="next_step"):
+    def __init__(self, task, num_envs, device, env_id_base, seed=0, autoreset_mode="next_step", **_):
         self.o = VecOracle(task, num_envs, store_mode="float32", seed=seed, env_id_base=env_id_base,
                            autoreset={"next_step": refvec.AUTORESET_NEXT_STEP,
                                       "disabled": refvec.AUTORESET_DISABLED}[autoreset_mode])
@@ -79,6 +79,33 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
+def _obs_worker(rank, world, port, out_dir):
+    """gather="obs": the observation rows come back global (rank-major = env-id order), reward and flags stay local."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gym_copter_amd.vecenv as vecenv
+    vecenv.CopterVecEnv = OracleLocalEnv
+    try:
+        env = ShardedCopterVecEnv("lander3d", TOTAL, gather="obs", seed=77)
+        n_local = TOTAL // world
+        assert (env.env_id_base, env.n_local, env.num_envs) == (rank * n_local, n_local, TOTAL)
+        acts = torch.from_numpy(_actions())
+        obs, _ = env.reset()
+        assert obs.shape == (TOTAL, 10)
+        rows = [obs.numpy().copy()]
+        for t in range(STEPS):
+            obs, r, term, trunc, _ = env.step(acts[t] if t % 2 else acts[t][env.local_slice()])
+            assert obs.shape == (TOTAL, 10) and r.shape == (n_local,) and term.shape == (n_local,)
+            # the local columns scattered into their global rows, zeros elsewhere: the test sums the ranks' files
+            g = np.zeros((3, TOTAL), np.float32)
+            g[0, env.local_slice()], g[1, env.local_slice()], g[2, env.local_slice()] = r.numpy(), term.numpy(), trunc.numpy()
+            rows.append(np.concatenate([obs.numpy().ravel(), g.ravel()]))
+        np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([x.ravel() for x in rows]))
+    finally:
+        dist.destroy_process_group()
+
+
 def _pipeline_worker(rank, world, port, out_dir):
     """The double-buffered half-batch schedule: policy(half 1) between step_async(0) and wait(0)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -119,24 +146,53 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("worker", [_worker, _pipeline_worker], ids=["sharded", "half_batch_pipeline"])
-def test_two_rank_sharding_matches_unsharded_batch(tmp_path, worker):
-    world = 2
-    mp.spawn(worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+def _unsharded_rows():
     ref = VecOracle("lander3d", TOTAL, store_mode="float32", seed=77,
                     autoreset=refvec.AUTORESET_NEXT_STEP)
-    rows = [ref.reset()]
+    rows = [(ref.reset(),)]
     acts = _actions()
     ends = 0
     for t in range(STEPS):
         obs, r, term, trunc = ref.step(acts[t].astype(np.float64))
         ends += int(term.sum())
-        rows.append(np.concatenate([obs.ravel(), r.astype(np.float32), term, trunc]))
-    want = np.concatenate([x.ravel() for x in rows])
-    assert ends > TOTAL     # auto-resets (Philox keyed by global env id) happened on both shards
+        rows.append((obs, r.astype(np.float32), term, trunc))
+    assert ends > TOTAL     # auto-resets (Philox keyed by global env id) happened on every shard
+    return rows
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("worker", [_worker, _pipeline_worker], ids=["sharded", "half_batch_pipeline"])
+def test_sharding_matches_unsharded_batch(tmp_path, worker, world):
+    """ShardedCopterVecEnv(gather="all"), flat and [world, n_local, ...], and the HalfBatchPipeline's half-major ids,
+    at world sizes 2, 4 and 8 (TOTAL = 96 envs: 6 per rank and half at world 8): every rank holds the same, correct
+    concatenation of the unsharded oracle batch."""
+    assert TOTAL % 16 == 0
+    mp.spawn(worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rows = _unsharded_rows()
+    want = np.concatenate([np.concatenate([np.asarray(x).ravel() for x in row]).ravel() for row in rows])
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank))
-        assert np.array_equal(got, want), rank     # every rank holds the same, correct concatenation
+        assert np.array_equal(got, want), rank
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_obs_gather_matches_unsharded_batch(tmp_path, world):
+    """gather="obs" (BASELINE configs[3]: the all-gather of the concatenated observation return): global observation
+    rows on every rank, local reward / flag rows that tile the unsharded batch exactly once."""
+    mp.spawn(_obs_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rows = _unsharded_rows()
+    got = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % rank)) for rank in range(world)]
+    n0 = TOTAL * 10
+    per = TOTAL * 10 + 3 * TOTAL
+    for rank in range(world):
+        assert np.array_equal(got[rank][:n0], rows[0][0].ravel()), rank                      # reset: global obs
+    for t in range(STEPS):
+        obs, r, term, trunc = rows[t + 1]
+        lo = n0 + t * per
+        for rank in range(world):
+            assert np.array_equal(got[rank][lo:lo + TOTAL * 10], obs.ravel()), (t, rank)     # every rank: all rows
+        local = sum(g[lo + TOTAL * 10:lo + per] for g in got).reshape(3, TOTAL)               # ranks' rows, scattered
+        assert np.array_equal(local[0], r) and np.array_equal(local[1], term) and np.array_equal(local[2], trunc), t
 
 
 def test_half_batch_pipeline_rejects_odd_batches():
@@ -146,6 +202,7 @@ def test_half_batch_pipeline_rejects_odd_batches():
 
 def test_shard_bounds():
     assert shard_bounds(524288, 8, 3) == (3 * 65536, 65536)
+    assert [shard_bounds(524288, 8, r)[0] for r in range(8)] == [r * 65536 for r in range(8)]     # BASELINE configs[3]
     assert shard_bounds(10, 1, 0) == (0, 10)
     with pytest.raises(ValueError):
         shard_bounds(10, 4, 0)
