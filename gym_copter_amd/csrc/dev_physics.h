@@ -310,6 +310,9 @@ __device__ __forceinline__ double shaping_yaw(const DevConst& c, double psi, dou
   return c.yaw_pen * sqrt_f64<1>(fma(dpsi, dpsi, psi * psi));
 }
 __device__ __forceinline__ double lander_shaping(const DevConst& c, const double (&x)[12]) {
+#ifdef CS_EXP_NOSHAPING  // (TIMING-ONLY build, wrong rewards: what the two sqrt chains cost a K-step loop -- tools/lib_ab.py)
+  return x[0];
+#endif
   double sh = -(shaping_position(c, x) + shaping_yaw(c, x[10], x[11]));
   if (fabs(x[5]) > c.dz_max) sh -= c.dz_pen;
   return sh;
