@@ -4,8 +4,12 @@ Only what the hot path needs lives here: csrc/ (HIP kernels + C ABI), the ctypes
 and the Gymnasium-style vector-env host class.  See DESIGN.md and INTEGRATION.md.
 """
 from ._lib import CopterStepError  # noqa: F401
-from .spaces import Box  # noqa: F401
 from .vecenv import CopterVecEnv  # noqa: F401
+from .spaces import box_class as _box_class
+
+# The Box class the envs' spaces are instances of: gymnasium.spaces.Box when Gymnasium is importable (so that
+# isinstance(env.single_action_space, gym_copter_amd.Box) and Box.__eq__ hold there too), else the minimal one of spaces.py
+Box = _box_class()
 from .policy_jit import compile_policy, load_policy  # noqa: F401
 
 __version__ = "0.1.0"

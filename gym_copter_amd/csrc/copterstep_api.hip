@@ -259,7 +259,9 @@ bool capturing(hipStream_t s) {
 int refuse_packed_rows(const cs_ctx* ctx, const char* who, const float* obs, const float* reward, const uint8_t* term,
                        const uint8_t* trunc) {
   const int od = cs::task_obs_dim(ctx->cfg.task);
-  if (obs != nullptr && reward == obs + od && term == reinterpret_cast<const uint8_t*>(obs + od + 1) && trunc == term + 1)
+  // (one env: the pattern is what adjacent fields of a caller's struct look like, and one env's plain arrays cannot
+  // overlap -- the n > 1 rule of CS_OUTPUT_AUTO, include/copterstep.h)
+  if (ctx->cfg.num_envs > 1 && obs != nullptr && reward == obs + od && term == reinterpret_cast<const uint8_t*>(obs + od + 1) && trunc == term + 1)
     return fail(CS_ERR_ARG, std::string(who) + ": the outputs are the columns of one packed [N, obs_dim + 2] array; that "
                                                "form is written by cs_step / cs_step_ex only -- pass separate arrays here");
   return CS_OK;

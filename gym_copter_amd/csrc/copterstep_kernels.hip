@@ -198,11 +198,12 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // controller gains, reward constants) are made vector-resident up front instead.
   // (The DIRECT_ROWS instantiations are the ones for <= 65 536 envs -- one wavefront per SIMD, where registers are free.
   // The others run with as many wavefronts per SIMD as their registers allow, and there a parked constant costs
-  // occupancy: the PID kernel at 254 registers held ONE wavefront per SIMD at 4 M envs.  They leave the constants where
-  // the compiler puts them.)
+  // occupancy: the PID kernel at 254 registers held ONE wavefront per SIMD at 4 M envs.  Those leave the PID GAINS
+  // where the compiler puts them -- park_gains below is gated on DIRECT_ROWS; the step's own constants
+  // (park_constants) are parked in every instantiation.)
   DevConst c = c_arg;
   PidConst pc = pc_arg;
-  park_constants<MODE == CS_STATE_F64>(c);
+  park_constants<MODE == CS_STATE_F64 || kFullTrigInEveryMode>(c);
   constexpr bool kPid = POLICY == kPolicyPid || POLICY == kPolicyPidHover || POLICY == kPolicyPidUpstream;
   constexpr int NCTL = POLICY == kPolicyPidHover ? kPidControllers : 4;
   // which terms the controllers have: decided on the kernel ARGUMENTS (scalar registers), before the gains are made
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // stores -- a whole store round trip per step (round 5, found in the ISA; what the open-loop kernel's action
   // row had in round 2).
 #ifndef CS_EXP_NOPREWAIT  // (A/B timing build)
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   for (int k = 0; k < num_steps; ++k) {
 #ifdef CS_KSTAMPS
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void set_motors_kernel(const DevConst c, const DevState s,
                                                             const float* __restrict__ motors) {
-  constexpr bool FULL = MODE == CS_STATE_F64;
+  constexpr bool FULL = MODE == CS_STATE_F64 || kFullTrigInEveryMode;
   const uint32_t tile_index = blockIdx.x;
   const uint32_t i = tile_index * kBlock + threadIdx.x;
   if (i >= s.n) return;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     if (pose == nullptr) {
       e.x[4] = (double)(T)c.z0;
       e.fs = c.status0;
-      e.prev_sh = c.reset_shaping;  // NaN (= None) for Hover3D
+      e.prev_sh = (T)c.reset_shaping;  // NaN (= None) for Hover3D
     } else {
       // _reset(pose=(x, y, altitude, phi_deg, theta_deg)), task.py:163-170: NED z, np.radians
       const double deg = 3.14159265358979323846 / 180.0;
@@ -512,9 +513,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
       e.fs = e.x[4] < 0.0 ? CS_STATUS_AIRBORNE : CS_STATUS_LANDED;  // setState, :215-217
       // the 'initializing' step's shaping (task.py:197 -> lander.py:48-57), NaN (= None) for Hover
       if constexpr (task_is_lander(TASK)) {
-        e.prev_sh = (double)(T)lander_shaping(c, e.x);
+        e.prev_sh = (T)lander_shaping(c, e.x);
       } else {
-        e.prev_sh = c.reset_shaping;
+        e.prev_sh = (T)c.reset_shaping;
       }
     }
     store_env<MODE, TILE>(c, tile, e);
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void state_gather_kernel(const DevConst c, 
   if (a.steps) a.steps[i] = (int32_t)e.steps;
   if (a.flags)
     a.flags[i] = (uint8_t)((e.pend ? 1 : 0) | ((meta & kMetaResetPending) ? 2 : 0) | (e.expl ? 4 : 0));
-  if (a.prev) a.prev[i] = e.prev_sh;
+  if (a.prev) a.prev[i] = (double)e.prev_sh;
   if (a.force) {
     // this episode's reset perturbation: the explicit force of the FE group, or the Philox draw of
     // (seed, global env id, episode - 1); zero before the first reset
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void state_scatter_kernel(const DevConst c,
     tile.store_eph(hi);
   }
   if (a.ticks && c.ticks) tile.store_ticks((uint32_t)a.ticks[i]);
-  if (a.prev) e.prev_sh = (double)(T)a.prev[i];
+  if (a.prev) e.prev_sh = (T)a.prev[i];
   store_env<MODE, TILE>(c, tile, e);
   if (a.ret) tile.store_ret((float)a.ret[i]);
 }
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void clock_probe_kernel(unsigned long long*
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): both clock reads have landed
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // both clock reads have landed
 #pragma clang loop unroll(disable)
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(kBlock) void clock_probe_kernel(unsigned long long*
   __builtin_amdgcn_sched_barrier(0);
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-  __builtin_amdgcn_s_waitcnt(0xC07F);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   double sum = 0.0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) sum += acc[j];

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void serve_kernel(char* const tiles, const 
   constexpr int AP = (ACT + 1) / 2, OP = (OBS + 2) / 2;
   static_assert((OBS + 2) % 2 == 0, "obs + reward + flags fill whole granule pairs");
   DevConst c = c_arg;
-  park_constants<MODE == CS_STATE_F64>(c);
+  park_constants<MODE == CS_STATE_F64 || kFullTrigInEveryMode>(c);
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;

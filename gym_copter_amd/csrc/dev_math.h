@@ -15,6 +15,13 @@ namespace {
 // rounded to 29 or 24 significant bits anyway.  Larger angles than 2^19*pi/2 (not reached by a
 // physical trajectory: 8e5 rad) are first folded by multiples of 2^17 * 2pi, which keeps full
 // accuracy up to ~8e11 rad and degrades gracefully beyond.
+// (experiment build -DCS_EXP_FULLTRIG: the fdlibm-length polynomials in the float32 storage modes as well -- what the
+// short ones save in time against what they cost in parity)
+#ifdef CS_EXP_FULLTRIG
+constexpr bool kFullTrigInEveryMode = true;
+#else
+constexpr bool kFullTrigInEveryMode = false;
+#endif
 template <bool FULL>
 __device__ __forceinline__ void sincos_kernel(const double* t, double y, double& sy, double& cy) {
   const double z = y * y;

@@ -125,7 +125,7 @@ struct Env {
   //    split_episode() undoes that before store_env.  Nothing of this is inside the loop.
   uint32_t episode, ep_far, ep_hi;
   uint32_t ticks;      // Dynamics._ticks of this episode (kept only under cs_config.track_time)
-  double prev_sh;
+  T prev_sh;           // prev_shaping as its stored word (one register in the float32 modes); widened where the reward uses it
   float ep_ret;
 };
 
@@ -163,7 +163,7 @@ __device__ __forceinline__ void unpack_env(const DevConst& c, const typename TIL
 #endif
   e.ep_hi = 0u;
   e.steps = (int)(meta & c.steps_mask);
-  e.prev_sh = (double)TILE::prev_of(r2);
+  e.prev_sh = TILE::prev_of(r2);
   e.fs = (int)(gT >> kStatusShift);
   e.pend = (meta & kMetaPerturbPending) != 0;
   e.expl = (meta & kMetaExplicitForce) != 0;
@@ -231,7 +231,7 @@ __device__ __forceinline__ void store_env(const DevConst& c, const TILE& tile, c
   words6<MODE>(e.x + 6, w + 6);
   const uint32_t gT = pack_guards6<MODE>(e.x) | ((uint32_t)e.fs << kStatusShift);
   // (the far flag also for a carry that finish_carry() is about to move into the EPH row: 0 - over has bit 31 set for
-  // every over in [1, 2^31])
+  // every over in [1, 2^31]; a compare + select here instead took the one-step kernels from 71-73 to 75-77 VGPRs, round 6)
   const uint32_t over = e.episode >> c.ep_bits;
   const uint32_t gR = pack_guards6<MODE>(e.x + 6) | ((e.ep_far | (0u - over)) & kEpisodeFarFlag);
   typename TILE::Group t1, t2, r1, r2;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void finish_carry(const DevConst& c, const TILE& tile
     tile.store_eph(hi & hi_mask);
     e.episode &= c.ep_mask;
     e.ep_far = (hi & hi_mask) != 0u ? kEpisodeFarFlag : 0u;
-    e.ep_hi = (hi & hi_mask) << c.ep_bits;
+    e.ep_hi = hi & hi_mask;  // (UNSHIFTED = what the EPH row holds, as resolve_episode / split_episode keep it)
     if (hi > hi_mask) {  // wrapped past 2^32 - 1: one more (0 is skipped), and the groups again with the new number
       e.episode += 1u;
       store_env<MODE, TILE>(c, tile, e);
@@ -380,7 +380,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
                                         StepOut<OBS>& out) {
   using T = typename ModeOf<MODE>::T;
   constexpr int FIRST = task_obs_first(TASK);
-  constexpr bool FULL = MODE == CS_STATE_F64;
+  constexpr bool FULL = MODE == CS_STATE_F64 || kFullTrigInEveryMode;
   const bool resetting = e.reset_pending;  // only ever set under NEXT_STEP auto-reset
   double reward = 0.0;
   bool term = false, trunc = false;
@@ -398,6 +398,10 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     } else {
       w.bz = thrust_model(q, a0, a1, a2, a3);
       torque_model(q, a0, a1, a2, a3, w);
+      // (Pinning the wrench HERE, before the trigonometry, takes the one-step kernels from 73 to 71-72 VGPRs = a seventh
+      // wavefront per SIMD -- and measured +1.6 % at 65 536 envs, +0.3 % at 4 M, +1.2-2.2 % on Hover3D: the compiler's
+      // own order, motor model sunk behind the sin / cos kernels where the action row has long arrived, is the faster
+      // one.  profiles/r06_ab_seventh_wavefront.txt)
     }
     double px, py, pz;
     pending_perturbation<MODE, IN_LOOP>(c, q, tile, i, e.episode, e.ep_far, e.pend, e.expl, px, py,
@@ -428,10 +432,10 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
   if (!resetting) {
     double sh = 0.0;
     if constexpr (task_is_lander(TASK)) sh = lander_shaping(c, e.x);
-    const Verdict v = judge_step<TASK>(c, o.trunc, status0, e.steps, sh, e.prev_sh,
+    const Verdict v = judge_step<TASK>(c, o.trunc, status0, e.steps, sh, (double)e.prev_sh,
                                        test_inside(c, e.x[0], e.x[2]), test_oob(c, e.x[0], e.x[2]),
                                        test_tilt(c, e.x[6], e.x[8]));
-    if constexpr (task_is_lander(TASK)) e.prev_sh = (double)(T)sh;
+    if constexpr (task_is_lander(TASK)) e.prev_sh = (T)sh;
     reward = v.reward;
     term = v.term;
     trunc = v.trunc;
@@ -483,7 +487,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     e.steps = 1;
     e.ticks = 0;  // a new Dynamics object (task.py:161)
     e.ep_ret = 0.f;
-    e.prev_sh = c.reset_shaping;
+    e.prev_sh = (T)c.reset_shaping;  // (a stored word already: host-rounded, copterstep_api.hip)
   }
   out.reward = reward;
   out.term = term;

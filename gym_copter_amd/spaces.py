@@ -40,6 +40,15 @@ def batch_space(space, n):
     return Box(space.low.flat[0], space.high.flat[0], (n,) + space.shape, space.dtype)
 
 
+def box_class():
+    """The class of the spaces gymnasium_api()'s `box` builds: gymnasium.spaces.Box if importable, else Box above."""
+    try:
+        from gymnasium.spaces import Box as GBox
+        return GBox
+    except ImportError:
+        return Box
+
+
 class _OwnAutoresetMode:
     """Stand-in for gymnasium.vector.AutoresetMode (same member names and values) for hosts without gymnasium."""
 

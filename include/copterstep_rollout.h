@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
   using T = typename ModeOf<MODE>::T;
   constexpr int OBS = task_obs_dim(TASK), FIRST = task_obs_first(TASK), ACT = task_act_dim(TASK);
   DevConst c = c_arg;
-  park_constants<MODE == CS_STATE_F64>(c);   // loop body: the deep constants out of the scalar registers' way
+  park_constants<MODE == CS_STATE_F64 || kFullTrigInEveryMode>(c);   // loop body: the deep constants out of the scalar registers' way
   DevState s = s_rest;
   s.tiles = tiles;
   s.n = n_envs;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
      the compiler, the wait for each loaded register sits at its first use INSIDE the loop, and the memory counter
      retires loads and stores in issue order: from the second iteration on such a wait sits out the previous step's
      row stores -- a whole store round trip per step (round 5: -13 % per step for a 44-weight linear law). */
-  __builtin_amdgcn_s_waitcnt(0x0F70);  /* vmcnt(0) */
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* (the assembler encodes the count for the target) */
   for (int k = 0; k < num_steps; ++k) {
 #ifdef CS_KSTAMPS  /* diagnostic build (make kstamps; tools/kstep_stamps.py): phase stamps of two iterations */
     o.kst = (s.stamps != nullptr && (k == num_steps / 2 || k == num_steps / 2 + 1))

@@ -42,6 +42,10 @@ def build_gymnasium_standin():
         def contains(self, x):
             return np.shape(x) == self.shape
 
+        def __eq__(self, other):      # (gymnasium.spaces.Box.__eq__: same type, shape, dtype and bounds)
+            return (isinstance(other, Box) and self.shape == other.shape and self.dtype == other.dtype
+                    and np.array_equal(self.low, other.low) and np.array_equal(self.high, other.high))
+
     class AutoresetMode(enum.Enum):
         NEXT_STEP = "NextStep"
         SAME_STEP = "SameStep"
@@ -190,19 +194,38 @@ def _drop(prefixes):
     return saved
 
 
+def real_gymnasium():
+    """The installed Gymnasium (>= 1.0: make_vec with vector_entry_point), or None.  The build image has none; the
+    first user WITH the package runs these same tests against the real thing instead of the stand-in."""
+    try:
+        import gymnasium
+        from gymnasium.envs.registration import register, registry  # noqa: F401
+        from gymnasium.vector import VectorEnv  # noqa: F401
+        return gymnasium if hasattr(gymnasium, "make_vec") else None
+    except Exception:
+        return None
+
+
 @pytest.fixture
 def gca_with_gymnasium():
-    """gym_copter_amd re-imported against the stand-in; the original modules are put back afterwards."""
-    saved = _drop(("gym_copter_amd", "gym-copter_amd", "gymnasium"))
-    mods = build_gymnasium_standin()
-    sys.modules.update(mods)
+    """gym_copter_amd re-imported against Gymnasium -- the REAL package when it is importable, else the stand-in; the
+    original modules are put back afterwards.  -> (gym_copter_amd, gymnasium, constructors seen, is_stand_in)."""
+    real = real_gymnasium()
+    saved = _drop(("gym_copter_amd", "gym-copter_amd") + (() if real else ("gymnasium",)))
+    if real is None:
+        mods = build_gymnasium_standin()
+        sys.modules.update(mods)
+    gym = real if real is not None else mods["gymnasium"]
     try:
         gca = importlib.import_module("gym_copter_amd")
         opened = []
         gca.CopterVecEnv._open_device = lambda self: opened.append(self)      # the device half: not here
-        yield gca, mods["gymnasium"], opened
+        yield gca, gym, opened
     finally:
-        _drop(("gym_copter_amd", "gymnasium"))
+        if real is not None:      # leave the real registry as it was found
+            for full in list(getattr(gca, "_GYMNASIUM_IDS", [])):
+                real.envs.registration.registry.pop(full, None)
+        _drop(("gym_copter_amd",) + (() if real else ("gymnasium",)))
         sys.modules.update(saved)
 
 
@@ -234,7 +257,8 @@ def test_make_vec_reaches_the_batch_env_with_the_vector_env_attribute_set(gca_wi
     assert env.num_envs == 7 and env.task == "lander3d" and env.config.num_envs == 7 and env.config.seed == 3
     assert env.config.max_steps == 1000                               # max_episode_steps -> the env's own limit
     assert env.unwrapped is env and env.spec is not None and env.spec.id == "gym_copter_amd/Lander-v0"
-    assert env.spec.kwargs["num_envs"] == 7 and env.spec.kwargs["vectorization_mode"] == "vector_entry_point"
+    assert env.spec.kwargs["num_envs"] == 7
+    assert str(getattr(env.spec.kwargs["vectorization_mode"], "value", env.spec.kwargs["vectorization_mode"])) == "vector_entry_point"
     assert env.metadata["autoreset_mode"] is gym.vector.AutoresetMode.NEXT_STEP
     assert env.metadata["render_fps"] == 100 and env.metadata["render_modes"] == []       # task.py:27-30
     assert env.render_mode is None and env.closed is False
@@ -243,6 +267,7 @@ def test_make_vec_reaches_the_batch_env_with_the_vector_env_attribute_set(gca_wi
     assert isinstance(env.single_action_space, box) and env.single_action_space.shape == (4,)
     assert isinstance(env.observation_space, box) and env.observation_space.shape == (7, 10)
     assert isinstance(env.action_space, box) and env.action_space.shape == (7, 4)
+    assert gca.Box is box and env.single_action_space == gca.Box(-1, 1, (4,), np.float32)     # the class actually in use
     assert env.single_action_space.low.min() == -1 and env.single_action_space.high.max() == 1       # task.py:52-55
     assert np.isinf(env.single_observation_space.high).all() and env.single_observation_space.dtype == np.float32
     assert env.FRAMES_PER_SECOND == 100 and env.STATE_NAMES[0] == "X" and len(env.STATE_NAMES) == 10

@@ -40,7 +40,7 @@ def main():
                 cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--envs", str(n), "--actions", law,
                        "--substeps", str(nsub), "--task", task, "--steps", str(steps), "--warmup", "100",
                        "--ring", str(ring), "--no-sweep", "--pid", "0", "--many", "0", "--served", "0",
-                       "--no-cpu-baseline", "--regions", "5"]
+                       "--no-cpu-baseline", "--no-span", "--full-out", "/dev/null", "--regions", "7"]
                 out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
                 try:
                     d = json.loads(out.stdout.strip().splitlines()[-1])
