@@ -1223,7 +1223,7 @@ def main(argv=None):
         block = actions[:k].contiguous()
         k_step_leg("step_many", k, lambda: env.step_many(block), 16 + 4 * od + 4 + 2 + 136.0 / k,
                    "cs_step_many: bit-identical to K single-step launches "
-                   "(tests/test_gpu_parity.py::test_step_many_is_bit_identical_to_single_steps); "
+                   "(tests/test_gpu_stepping_forms.py::test_step_many_is_bit_identical_to_single_steps); "
                    "open-loop actions only, so it is reported beside, not as, the headline value")
     if a.pid > 0 and a.task == "lander3d":
         # closed loop: K steps per launch with the on-device PID heuristic choosing every action
@@ -1232,7 +1232,7 @@ def main(argv=None):
         env.reset()
         k_step_leg("rollout_pid", k, lambda: env.rollout_pid(k), 4 * od + 4 + 2 + (136.0 + 384.0) / k,
                    "cs_rollout_pid: closed loop, upstream's PID landing heuristic evaluated on device "
-                   "(tests/test_gpu_parity.py::test_rollout_pid_policy_is_bit_exact); episodes under "
+                   "(tests/test_gpu_stepping_forms.py::test_rollout_pid_policy_is_bit_exact); episodes under "
                    "upstream's gains end by tilt after ~130 steps and auto-reset")
     if a.pid > 0 and a.full:
         # random policy on device: the headline's action law with no action tensor, K steps per launch
@@ -1240,7 +1240,7 @@ def main(argv=None):
         env.reset()
         k_step_leg("rollout_random", k, lambda: env.rollout_random(k), 4 * od + 4 + 2 + 136.0 / k,
                    "cs_rollout_random: actions ~ U[-1,1)^4 drawn in the kernel (Philox, keyed by seed / env "
-                   "id / episode / step; tests/test_gpu_parity.py::test_rollout_random_is_bit_exact)")
+                   "id / episode / step; tests/test_gpu_stepping_forms.py::test_rollout_random_is_bit_exact)")
     if a.pid > 0 and world == 1 and a.full:     # (N = 1 only: a compile that failed on ONE rank would leave the others at a barrier)
         # the CALLER'S OWN policy fused into the K-step kernel, the Python route: a linear law given as HIP source,
         # compiled with hipcc here and now (gym_copter_amd.compile_policy), K closed-loop steps per launch
@@ -1269,7 +1269,7 @@ struct Policy {
             k_step_leg("rollout_policy_linear", k, lambda: env.rollout_policy(pol, k, W), 4 * od + 4 + 2 + 136.0 / k,
                        "env.rollout_policy: the caller's own policy (a linear law, %d weights, given as HIP source and "
                        "compiled by hipcc in %.1f s%s) fused into the K-step kernel (include/copterstep_rollout.h; "
-                       "tests/test_gpu_round3.py::test_python_callers_policy_source_is_compiled_and_fused)"
+                       "tests/test_gpu_stepping_forms.py::test_python_callers_policy_source_is_compiled_and_fused)"
                        % (ad * od + ad, compile_s, "" if compile_s > 0.5 else ", cached"))
         except Exception as e:              # an extra never costs the headline
             extra["rollout_policy_linear"] = {"error": repr(e)}
@@ -1314,7 +1314,7 @@ struct Policy {
                        "closed loop with the policy as its OWN kernel per step (cs_serve_policy_pid: outputs of step "
                        "s-1 -> PID heuristic -> actions of step s) against the persistent env kernel: one launch per "
                        "step, two hand-offs through device memory; bit-identical to cs_rollout_pid "
-                       "(tests/test_gpu_round3.py::test_served_closed_loop_policy_kernel_equals_rollout_pid); compare "
+                       "(tests/test_gpu_served.py::test_served_closed_loop_policy_kernel_equals_rollout_pid); compare "
                        "with a policy kernel + cs_step per step (config.actions_produced_by_a_preceding_kernel)",
                        prepare=lambda: env.configure_pid())
             served_leg("served_closed_loop_persistent_policy",
@@ -1328,7 +1328,7 @@ struct Policy {
                        wire + 4 * env.action_dim + 4 * od + 6,
                        "plain tensors in and out: cs_serve_submit + cs_serve_collect per step (two small launches on one "
                        "stream) against the persistent env kernel; bit-identical to cs_step "
-                       "(tests/test_gpu_round3.py::test_served_steps_are_bit_identical_to_cs_step)")
+                       "(tests/test_gpu_served.py::test_served_steps_are_bit_identical_to_cs_step)")
         side = served_side
 
         def submit_two_streams(s):
@@ -1610,7 +1610,7 @@ struct Policy {
         if not profiled:               # (a profiler writes its files from exit handlers: leave normally under one)
             # leave without running the interpreter's shutdown: hipGraphs that captured collectives are still alive, and
             # freeing them once RCCL is (being) torn down has been seen to end the process with SIGSEGV / SIGABRT
-            # (the watchdog thread during shutdown; a garbage collection at exit in tests/test_gpu_round3.py's RCCL
+            # (the watchdog thread during shutdown; a garbage collection at exit in tests/test_gpu_multigpu.py's RCCL
             # child) -- after the line is out, which a launcher would report as a failed rank.  The line is written,
             # the group is closed (launched runs), nothing is left to flush
             sys.stderr.flush()

@@ -293,7 +293,11 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // stores -- a whole store round trip per step (round 5, found in the ISA; what the open-loop kernel's action
   // row had in round 2).
 #ifndef CS_EXP_NOPREWAIT  // (A/B timing build)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx940__) || defined(__gfx90a__) || defined(__gfx908__) || defined(__gfx906__) || defined(__gfx900__)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) in the gfx9 encoding; the builtin, not asm text: an asm statement with a memory clobber here cost cs_rollout_pid +7 % (round 6, interleaved A/B) 
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // another s_waitcnt layout: let the assembler encode it 
+#endif
 #endif
   for (int k = 0; k < num_steps; ++k) {
 #ifdef CS_KSTAMPS
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
     if (pose == nullptr) {
       e.x[4] = (double)(T)c.z0;
       e.fs = c.status0;
-      e.prev_sh = (T)c.reset_shaping;  // NaN (= None) for Hover3D
+      e.prev_sh = c.reset_shaping;  // NaN (= None) for Hover3D
     } else {
       // _reset(pose=(x, y, altitude, phi_deg, theta_deg)), task.py:163-170: NED z, np.radians
       const double deg = 3.14159265358979323846 / 180.0;
@@ -513,9 +517,9 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevConst c, const D
       e.fs = e.x[4] < 0.0 ? CS_STATUS_AIRBORNE : CS_STATUS_LANDED;  // setState, :215-217
       // the 'initializing' step's shaping (task.py:197 -> lander.py:48-57), NaN (= None) for Hover
       if constexpr (task_is_lander(TASK)) {
-        e.prev_sh = (T)lander_shaping(c, e.x);
+        e.prev_sh = (double)(T)lander_shaping(c, e.x);
       } else {
-        e.prev_sh = (T)c.reset_shaping;
+        e.prev_sh = c.reset_shaping;
       }
     }
     store_env<MODE, TILE>(c, tile, e);
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void state_gather_kernel(const DevConst c, 
   if (a.steps) a.steps[i] = (int32_t)e.steps;
   if (a.flags)
     a.flags[i] = (uint8_t)((e.pend ? 1 : 0) | ((meta & kMetaResetPending) ? 2 : 0) | (e.expl ? 4 : 0));
-  if (a.prev) a.prev[i] = (double)e.prev_sh;
+  if (a.prev) a.prev[i] = e.prev_sh;
   if (a.force) {
     // this episode's reset perturbation: the explicit force of the FE group, or the Philox draw of
     // (seed, global env id, episode - 1); zero before the first reset
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(kBlock) void state_scatter_kernel(const DevConst c,
     tile.store_eph(hi);
   }
   if (a.ticks && c.ticks) tile.store_ticks((uint32_t)a.ticks[i]);
-  if (a.prev) e.prev_sh = (T)a.prev[i];
+  if (a.prev) e.prev_sh = (double)(T)a.prev[i];
   store_env<MODE, TILE>(c, tile, e);
   if (a.ret) tile.store_ret((float)a.ret[i]);
 }

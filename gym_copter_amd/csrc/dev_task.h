@@ -125,7 +125,7 @@ struct Env {
   //    split_episode() undoes that before store_env.  Nothing of this is inside the loop.
   uint32_t episode, ep_far, ep_hi;
   uint32_t ticks;      // Dynamics._ticks of this episode (kept only under cs_config.track_time)
-  T prev_sh;           // prev_shaping as its stored word (one register in the float32 modes); widened where the reward uses it
+  double prev_sh;      // (kept widened: as a T word it cost the K-step kernels +1-2 %, round 6)
   float ep_ret;
 };
 
@@ -163,7 +163,7 @@ __device__ __forceinline__ void unpack_env(const DevConst& c, const typename TIL
 #endif
   e.ep_hi = 0u;
   e.steps = (int)(meta & c.steps_mask);
-  e.prev_sh = TILE::prev_of(r2);
+  e.prev_sh = (double)TILE::prev_of(r2);
   e.fs = (int)(gT >> kStatusShift);
   e.pend = (meta & kMetaPerturbPending) != 0;
   e.expl = (meta & kMetaExplicitForce) != 0;
@@ -432,10 +432,10 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
   if (!resetting) {
     double sh = 0.0;
     if constexpr (task_is_lander(TASK)) sh = lander_shaping(c, e.x);
-    const Verdict v = judge_step<TASK>(c, o.trunc, status0, e.steps, sh, (double)e.prev_sh,
+    const Verdict v = judge_step<TASK>(c, o.trunc, status0, e.steps, sh, e.prev_sh,
                                        test_inside(c, e.x[0], e.x[2]), test_oob(c, e.x[0], e.x[2]),
                                        test_tilt(c, e.x[6], e.x[8]));
-    if constexpr (task_is_lander(TASK)) e.prev_sh = (T)sh;
+    if constexpr (task_is_lander(TASK)) e.prev_sh = (double)(T)sh;
     reward = v.reward;
     term = v.term;
     trunc = v.trunc;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     e.steps = 1;
     e.ticks = 0;  // a new Dynamics object (task.py:161)
     e.ep_ret = 0.f;
-    e.prev_sh = (T)c.reset_shaping;  // (a stored word already: host-rounded, copterstep_api.hip)
+    e.prev_sh = c.reset_shaping;
   }
   out.reward = reward;
   out.term = term;

@@ -129,7 +129,12 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
      the compiler, the wait for each loaded register sits at its first use INSIDE the loop, and the memory counter
      retires loads and stores in issue order: from the second iteration on such a wait sits out the previous step's
      row stores -- a whole store round trip per step (round 5: -13 % per step for a 44-weight linear law). */
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* (the assembler encodes the count for the target) */
+#if defined(__gfx950__) || defined(__gfx942__) || defined(__gfx940__) || defined(__gfx90a__) || defined(__gfx908__) || defined(__gfx906__) || defined(__gfx900__)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  /* vmcnt(0) in the gfx9 encoding; the builtin, not asm text: an asm statement with a
+                                          memory clobber here cost cs_rollout_pid +7 % (round 6, interleaved A/B) */
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  /* another s_waitcnt layout: let the assembler encode it */
+#endif
   for (int k = 0; k < num_steps; ++k) {
 #ifdef CS_KSTAMPS  /* diagnostic build (make kstamps; tools/kstep_stamps.py): phase stamps of two iterations */
     o.kst = (s.stamps != nullptr && (k == num_steps / 2 || k == num_steps / 2 + 1))

@@ -11,8 +11,7 @@ cd $R
 FULL=$R/gym_copter_amd/csrc/build/libcopterstep_fulltrig.so
 timeout 900 python3 tools/lib_ab.py short=gym_copter_amd/libcopterstep.so full=gym_copter_amd/csrc/build/libcopterstep_fulltrig.so --reps 3 > $OUT/ab.txt 2>&1
 cat $OUT/ab.txt
-T=tests/test_gpu_round4.py::test_a_differing_stored_word_after_one_step_is_a_straddled_rounding_boundary
-[ -f tests/test_gpu_numerics.py ] && T=tests/test_gpu_numerics.py::test_a_differing_stored_word_after_one_step_is_a_straddled_rounding_boundary
+T=tests/test_gpu_numerics.py::test_a_differing_stored_word_after_one_step_is_a_straddled_rounding_boundary
 timeout 300 python3 -m pytest -q -s $T > $OUT/straddle_short.txt 2>&1; grep -E "overall|per component|passed|failed" $OUT/straddle_short.txt
 COPTERSTEP_LIB=$FULL timeout 300 python3 -m pytest -q -s $T > $OUT/straddle_full.txt 2>&1; grep -E "overall|per component|passed|failed" $OUT/straddle_full.txt
 COPTERSTEP_LIB=$FULL timeout 900 python3 tools/fuzz_sweep.py 64 3200 > $OUT/fuzz_full.txt 2>&1; tail -2 $OUT/fuzz_full.txt

@@ -66,7 +66,7 @@ def step_both(env, orc, actions):
 
 def reward_limit(wobs, wr, r_abs=2e-3, r_rel=2e-6):
     """Per-env tolerance of the float32 reward against the oracle's float64 one: the golden-trace formula
-    5e-5 + 1e-5 |r| + 6e-7 |prev_shaping| (tests/test_gpu_parity.py: prev_shaping is a float32 word, so the reward
+    5e-5 + 1e-5 |r| + 6e-7 |prev_shaping| (tests/test_gpu_golden.py: prev_shaping is a float32 word, so the reward
     carries its rounding), with |prev_shaping| bounded from what the step returned: |shaping now| + |r|, shaping now
     <= 25 * |first six observed components| + 110 (the |dz| penalty and a yaw term the observation does not show).
     About 2.7e-4 for an env at altitude 10; never looser than the (r_abs, r_rel) a test passes -- that pair is what
@@ -126,7 +126,7 @@ def run_with_rccl(cmd, env, timeout, cwd=None):
     import subprocess
     env = dict(env, PYTHONFAULTHANDLER="1")
     # a world of one on this host: keep RCCL's bootstrap off whatever other interfaces the box has (probing an
-    # unreachable one costs minutes), as tests/test_gpu_parity.py::test_c_host_rccl_allgather does for the C host
+    # unreachable one costs minutes), as tests/test_gpu_multigpu.py::test_c_host_rccl_allgather does for the C host
     env.setdefault("NCCL_SOCKET_IFNAME", "lo")
     env.setdefault("NCCL_IB_DISABLE", "1")
 

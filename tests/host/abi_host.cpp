@@ -1,5 +1,5 @@
 // A plain C++ host driving libcopterstep.so through include/copterstep.h only: no Python, no
-// torch.  Run by tests/test_gpu_parity.py::test_c_host_known_answers on the GPU box; built by
+// torch.  Run by tests/test_gpu_outputs_abi.py::test_c_host_known_answers on the GPU box; built by
 // __graft_entry__.build().  Known answers come from the reference: reset observation
 // (0,0,0,0,-10,0,0,0,0,0); constant thrust 1.625e-2 (lander.py:21) gives netz = 0.363923869 m/s^2,
 // so without a perturbation dz after the first step is netz * dt; a free-falling copter (motors 0)

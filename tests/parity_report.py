@@ -10,7 +10,7 @@ is what the other parity tests assert; here the literal one:
 over every step of every golden E (env), V (1D / 2D variants), D (Dynamics.setMotors), W (other vehicles /
 worlds) and R (pose resets) episode while the episode is alive (through its first `done`), replayed as
 batches through a BACKEND: the CPU oracle in a storage mode (tests/test_oracle_vec.py, the model of the
-device format) or the device env (tests/test_gpu_round3.py).  `collect()` returns the worst value per
+device format) or the device env (tests/test_gpu_golden.py).  `collect()` returns the worst value per
 component with where it happened.
 
 Where the literal bar does not hold in the default (float32 + 5 guard bits) mode is exactly where SURVEY H1
@@ -193,7 +193,7 @@ def batches(float32_inputs_only):
     for fps in (100, 1000):
         cs = [c for c in DYN.names() if int(DYN[c]["fps"]) == fps and c != "D12_full_range"]
         # (D12: full-range random motors, angles of hundreds of radians: chaotic at any word precision short
-        #  of float64 -- its own float64-mode test in test_gpu_parity.py)
+        #  of float64 -- its own float64-mode test in test_gpu_golden.py)
         n, T = len(cs), max(len(DYN[c]["status"]) for c in cs)
         motors = np.zeros((T, n, 4))
         for i, c in enumerate(cs):

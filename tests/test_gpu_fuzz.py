@@ -14,7 +14,7 @@ float32_rn case, every case with an auto-reset mode, every case of the gentle ac
 360 known since round 3) are not bugs but chaos, all of ONE class: default float32 words, auto-reset off, full-range
 actions -- a finished env tumbles on at hundreds of m/s until the stretch ends, and one unit of the stored format grows
 to 2.0-8.4e-8 on ONE lane within the stretch (tools/fuzz_trace.py shows it step by step).  Where that unit comes from is
-pinned down in tests/test_gpu_round4.py: NOT the stored format (the codec is bit-exact against the oracle's model over
+pinned down in tests/test_gpu_numerics.py: NOT the stored format (the codec is bit-exact against the oracle's model over
 2.1 M values) but the float64 value that is rounded into it -- the float32 modes' shorter sin / cos polynomials move dx,
 dy, dz by ~1e-11, which straddles a rounding boundary of the 29-bit format about once in 1e4 values (measured 9.9e-5).
 Two more seeds of that sweep (2102, 2256) showed the same unit through the REWARD (REWARD_UNIT below) and run in the

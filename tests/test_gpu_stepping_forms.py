@@ -1,0 +1,718 @@
+"""-m gpu: every way of advancing an env other than one cs_step launch must be BIT-IDENTICAL to cs_step: hipGraph
+replay, K steps per launch (cs_step_many, cs_rollout_pid, cs_rollout_random), the stream-hint and row-store instantiations,
+the caller's own policy fused into the K-step kernel (C++ header and compile_policy), two contexts on two threads."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import load_cases
+from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu,
+                      make_pair, reward_limit, scaled_err, step_both, to_np)
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
+
+HOVER = float(np.load(os.path.join(os.path.dirname(__file__), "golden", "meta.npz"))["hover_motor"])
+PID_GAINS = {
+    "upstream": {},
+    "hover": dict(heuristic="hover"),
+    "hover_tuned": dict(heuristic="hover", alt_kp=0.02, alt_ki=5.0, rate_kp=0.002, rate_kd=0.002, rate_ki=0.01,
+                        pos_kp=0.0002, pos_ki=0.0, pos_kd=0.0),
+    "soft": dict(rate_kp=0.002, rate_kd=0.002, pos_kp=0.0002, pos_ki=0.0, pos_kd=0.0,
+                 descent_kp=0.004, descent_kd=0.012),
+    "integral": dict(rate_ki=0.05, pos_ki=0.3, rate_big_deg=5.0),
+}
+# ---------------------------------------------------------------------------------------
+# a REAL RCCL collective on the one GPU there is: a 1-rank nccl group whose
+# all-gathers are issued (force_collective) instead of being shortcut
+# ---------------------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LINEAR_POLICY = """
+struct Policy {
+  const float* params;                 // [ACT][OBS] weights, then ACT biases, then one thrust trim per env
+  float w[ACT * OBS + ACT];
+  float trim;
+  __device__ void load(uint32_t env, bool valid) {
+    for (int j = 0; j < ACT * OBS + ACT; ++j) w[j] = params[j];
+    trim = valid ? params[ACT * OBS + ACT + env] : 0.f;
+  }
+  __device__ void store(uint32_t, bool) {}
+  __device__ void operator()(const float (&obs)[OBS], uint32_t, int, bool, float (&a)[ACT]) const {
+    for (int m = 0; m < ACT; ++m) {
+      float s = w[ACT * OBS + m];
+      for (int j = 0; j < OBS; ++j) s += w[m * OBS + j] * obs[j];
+      a[m] = s + trim;
+    }
+  }
+};
+"""
+
+
+def _oracle_gains(kw):
+    from oracle.refcpu import PidGains
+    return PidGains(**{("rate_big" if k == "rate_big_deg" else k): v for k, v in kw.items()})
+
+
+def _assert_same_state(a, b):
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+
+
+def test_hipgraph_replay_matches_eager_and_oracle():
+    """bench.py times hipGraph replays of captured step launches: a replayed chunk must advance
+    the envs exactly like eager launches (no host-side state is baked into the captured
+    kernels; the reset draw is keyed by per-env episode counters kept on the device)."""
+    import torch
+    rng = np.random.default_rng(8)
+    n, chunk, reps = 5000, 10, 4
+    env, orc = make_pair("lander3d", n, "float32", autoreset="next_step", seed=21)
+    eager, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=21)
+    acts = rng.uniform(-1, 1, (chunk, n, 4)).astype(np.float32)
+    dev_acts = torch.from_numpy(acts).to(env.device)
+    env.reset()
+    eager.reset()
+    orc.reset()
+    side = torch.cuda.Stream(device=env.device)
+    side.wait_stream(torch.cuda.current_stream(env.device))
+    with torch.cuda.stream(side):
+        env.step(dev_acts[0])          # warm-up launch outside capture ...
+    torch.cuda.current_stream(env.device).wait_stream(side)
+    torch.cuda.synchronize()
+    eager.step(dev_acts[0])            # ... mirrored on the eager twin and the oracle
+    orc.step(acts[0].astype(np.float64))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for j in range(chunk):
+            env.step(dev_acts[j])
+    for rep in range(reps):
+        graph.replay()
+        torch.cuda.synchronize()
+        for j in range(chunk):
+            got_e = eager.step(dev_acts[j])
+            want = orc.step(acts[j].astype(np.float64))
+        # after each replayed chunk: last step's outputs and the whole state agree
+        obs_g = to_np(env._obs)
+        assert np.array_equal(obs_g, to_np(got_e[0])), rep
+        assert np.array_equal(to_np(env._reward), to_np(got_e[1])), rep
+        assert np.array_equal(to_np(env._term), to_np(eager._term)), rep
+        sg, se = env.get_state(), eager.get_state()
+        for k in ("x", "status", "steps", "episode", "force", "flags", "prev_shaping"):
+            assert np.array_equal(sg[k], se[k], equal_nan=True), (rep, k)
+        assert_state_close(env, orc, 2e-6, ctx="replay %d" % rep)
+        assert np.array_equal(sg["episode"], orc.episode)
+    assert sg["episode"].max() > 3      # several auto-resets happened inside the replays
+    env.close()
+    eager.close()
+
+
+@pytest.mark.parametrize("task,mode,autoreset", [
+    ("lander3d", "float32", "next_step"), ("lander3d", "float32", "same_step"),
+    ("lander3d", "float32", "disabled"), ("hover3d", "float32", "next_step"),
+    ("lander3d", "float64", "next_step"), ("lander3d", "float32_rn", "next_step")])
+def test_step_many_is_bit_identical_to_single_steps(task, mode, autoreset):
+    """cs_step_many (K steps in one launch, env state kept in registers) returns exactly what K
+    calls of cs_step return -- every output of every step and the final state, bit for bit --
+    and both match the oracle."""
+    import torch
+    rng = np.random.default_rng(17)
+    n, K = 4133, 24
+    many, orc = make_pair(task, n, mode, autoreset=autoreset, seed=5, episode_stats=True)
+    single, _ = make_pair(task, n, mode, autoreset=autoreset, seed=5, episode_stats=True)
+    many.reset()
+    single.reset()
+    orc.reset()
+    for chunk in range(3):
+        law = rng.uniform(-1, 1, (K, n, 4)) if chunk != 1 else HOVER * (1 + 0.05 * rng.standard_normal((K, n, 4)))
+        acts = law.astype(np.float32)
+        dev = torch.from_numpy(acts).to(many.device)
+        obs_m, rew_m, term_m, trunc_m = many.step_many(dev)
+        for k in range(K):
+            o, r, t, tr, _ = single.step(dev[k])
+            assert torch.equal(obs_m[k], o) and torch.equal(rew_m[k], r), (chunk, k)
+            assert torch.equal(term_m[k], t) and torch.equal(trunc_m[k], tr), (chunk, k)
+            want = orc.step(acts[k].astype(np.float64))
+        sm, ss = many.get_state(), single.get_state()
+        for key in sm:
+            assert np.array_equal(sm[key], ss[key], equal_nan=True), (chunk, key)
+        assert_step_close((to_np(obs_m[K - 1]), to_np(rew_m[K - 1]), to_np(term_m[K - 1]), to_np(trunc_m[K - 1])),
+                          want, 2e-6, r_abs="auto")
+        assert_state_close(many, orc, 2e-6 if mode != "float64" else 1e-9)
+    many.close()
+    single.close()
+
+
+@pytest.mark.parametrize("gains", list(PID_GAINS))
+@pytest.mark.parametrize("task,mode,autoreset", [("lander3d", "float32", "next_step"),
+                                                 ("lander3d", "float64", "same_step"),
+                                                 ("lander3d", "float32_rn", "disabled"),
+                                                 ("hover3d", "float32", "next_step"),
+                                                 ("hover3d", "float64", "disabled")])
+def test_rollout_pid_policy_is_bit_exact(task, mode, autoreset, gains):
+    if PID_GAINS[gains].get("heuristic") == "hover" and task != "hover3d":
+        pytest.skip("the hover heuristic reads dpsi: Hover3D observation only")
+    """The on-device controllers against the oracle's (VecPid), bit for bit: a twin device env is
+    stepped one cs_step at a time with the ORACLE's actions computed from the observations the
+    device returned.  Both envs share the HIP physics, so every action, every output of every step,
+    the final env state and the final controller state must be identical -- any float64 operation
+    of the device policy that differed from upstream's order would show up in the actions."""
+    import torch
+    from oracle.refvec import VecPid
+    n, K = 2500, 40
+    kw = PID_GAINS[gains]
+    roll, _ = make_pair(task, n, mode, autoreset=autoreset, seed=21, episode_stats=True)
+    twin, _ = make_pair(task, n, mode, autoreset=autoreset, seed=21, episode_stats=True)
+    roll.configure_pid(**kw)
+    pid = VecPid(n, _oracle_gains(kw))
+    obs, _ = roll.reset()
+    obs_t, _ = twin.reset()
+    seen = to_np(obs_t).copy()
+    resets = 0
+    for chunk in range(4):
+        obs_k, rew_k, term_k, trunc_k, act_k = roll.rollout_pid(K, return_actions=True)
+        for k in range(K):
+            a = pid.action(seen)
+            assert np.array_equal(a, to_np(act_k[k]), equal_nan=True), (chunk, k)
+            before = twin.get_state()["episode"] if autoreset != "disabled" else None
+            o, r, t, tr, _ = twin.step(torch.from_numpy(a).to(twin.device))
+            assert torch.equal(obs_k[k], o) and torch.equal(rew_k[k], r), (chunk, k)
+            assert torch.equal(term_k[k], t) and torch.equal(trunc_k[k], tr), (chunk, k)
+            seen = to_np(o).copy()
+            if before is not None:     # envs that began a new episode fly with fresh controllers
+                started = twin.get_state()["episode"] != before
+                pid.reset(started)
+                resets += int(started.sum())
+        sr, st = roll.get_state(), twin.get_state()
+        for key in sr:
+            assert np.array_equal(sr[key], st[key], equal_nan=True), (chunk, key)
+        assert np.array_equal(roll.pid_get_state(), pid.state.reshape(24, n)), chunk
+    if autoreset != "disabled" and gains == "upstream":
+        assert resets > 0      # the bang-bang upstream gains tip the copter over within ~130 steps
+    roll.close()
+    twin.close()
+
+
+@pytest.mark.parametrize("gains", ["upstream", "soft"])
+def test_rollout_pid_matches_full_oracle(gains):
+    """Device rollout vs the complete CPU closed loop (VecOracle physics + VecPid), default storage
+    mode, auto-reset on: flags exact, observations within the mode tolerance while the loops are
+    still on the same trajectory."""
+    from oracle.refvec import VecPid
+    n, K = 1024, 300
+    kw = PID_GAINS[gains]
+    env, orc = make_pair("lander3d", n, "float32", autoreset="next_step", seed=8)
+    env.configure_pid(**kw)
+    pid = VecPid(n, _oracle_gains(kw))
+    env.reset()
+    seen = orc.reset()
+    obs, rew, term, trunc = (to_np(v) for v in env.rollout_pid(K))
+    for k in range(K):
+        a = pid.action(seen)
+        seen, r, t, tr = orc.step(a.astype(np.float64))
+        pid.reset(orc.last_reset)
+        assert np.array_equal(term[k], t) and np.array_equal(trunc[k], tr), k
+        assert scaled_err(obs[k], seen) <= 2e-6, (k, scaled_err(obs[k], seen))
+        assert np.all(np.abs(rew[k] - r) <= reward_limit(seen, r)), k
+    env.close()
+
+
+def test_variant_rollout_pid_is_refused():
+    env, _ = make_pair("lander2d", 64, "float32")
+    env.configure_pid()
+    env.reset()
+    with pytest.raises(Exception, match="3D tasks only"):
+        env.rollout_pid(4)
+    env.close()
+
+
+# ---------------------------------------------------------------------------------------
+# rollouts under the on-device random policy (cs_rollout_random)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task,mode,autoreset", [("lander3d", "float32", "next_step"),
+                                                 ("hover3d", "float64", "same_step"),
+                                                 ("lander2d", "float32_rn", "next_step"),
+                                                 ("hover1d", "float32", "disabled")])
+def test_rollout_random_is_bit_exact(task, mode, autoreset):
+    """The kernel's action draw against the oracle's draw_actions (same specification), bit for
+    bit, and the rollout against a twin device env stepped one cs_step at a time with those
+    actions; then the whole thing against the CPU oracle.  Launch grouping must not matter: the
+    same steps as 3 launches of 20 and as 60 launches of 1 give identical results."""
+    import torch
+    from oracle.refvec import draw_actions
+    n, K = 2111, 20
+    roll, orc = make_pair(task, n, mode, autoreset=autoreset, seed=77, env_id_base=5000, episode_stats=True)
+    twin, _ = make_pair(task, n, mode, autoreset=autoreset, seed=77, env_id_base=5000, episode_stats=True)
+    ones, _ = make_pair(task, n, mode, autoreset=autoreset, seed=77, env_id_base=5000, episode_stats=True)
+    for e in (roll, twin, ones):
+        e.reset()
+    orc.reset()
+    ids = np.arange(5000, 5000 + n)
+    tol = max(MODE_TOL[mode], 2e-6)
+    for chunk in range(3):
+        obs_k, rew_k, term_k, trunc_k, act_k = roll.rollout_random(K, return_actions=True)
+        for k in range(K):
+            st = twin.get_state()
+            a = draw_actions(77, ids, st["episode"], st["steps"], twin.action_dim)
+            assert np.array_equal(a, to_np(act_k[k])), (chunk, k)
+            assert np.array_equal(a, draw_actions(77, ids, orc.episode, orc.steps, orc.act_dim)), (chunk, k)
+            o, r, t, tr, _ = twin.step(torch.from_numpy(a).to(twin.device))
+            assert torch.equal(obs_k[k], o) and torch.equal(rew_k[k], r), (chunk, k)
+            assert torch.equal(term_k[k], t) and torch.equal(trunc_k[k], tr), (chunk, k)
+            want = orc.step(a.astype(np.float64))
+            assert_step_close((to_np(o), to_np(r), to_np(t), to_np(tr)), want, tol, r_abs="auto",
+                              ctx=(task, mode, chunk, k))
+            o1 = ones.rollout_random(1)
+            assert torch.equal(o1[0][0], o) and torch.equal(o1[1][0], r), (chunk, k)
+        sr, st, so = roll.get_state(), twin.get_state(), ones.get_state()
+        for key in sr:
+            assert np.array_equal(sr[key], st[key], equal_nan=True), (chunk, key)
+            assert np.array_equal(sr[key], so[key], equal_nan=True), (chunk, key)
+        assert_state_close(roll, orc, tol)
+    for e in (roll, twin, ones):
+        e.close()
+
+
+def test_full_size_all_stepping_paths_agree():
+    """BASELINE size (65 536 envs), 500 steps with reset churn: the random-policy rollout, the open-loop
+    K-step kernel and single steps -- eager and replayed from a hipGraph -- fed the same actions produce
+    bit-identical observations, rewards, flags and final states; the recorded actions are the oracle's
+    draw."""
+    import torch
+    from oracle.refvec import draw_actions
+    n, K, chunks = 65536, 50, 10
+    mk = lambda: make_pair("lander3d", n, "float32", autoreset="next_step", seed=2024)[0]
+    roll, many, single, graphed = mk(), mk(), mk(), mk()
+    for e in (roll, many, single, graphed):
+        e.reset()
+    ids = np.arange(n)
+    static_act = torch.zeros((n, 4), device=graphed.device)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        graphed.step(static_act)                       # warm-up outside capture (this step is re-done below)
+    torch.cuda.current_stream().wait_stream(s)
+    graphed.reset()
+    graphed.set_state(**{k: v for k, v in single.get_state().items()})   # identical starting point
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        g_out = graphed.step(static_act)
+    for c in range(chunks):
+        st = roll.get_state()
+        obs_r, rew_r, term_r, trunc_r, act = roll.rollout_random(K, return_actions=True)
+        assert np.array_equal(to_np(act[0]), draw_actions(2024, ids, st["episode"], st["steps"]))
+        obs_m, rew_m, term_m, trunc_m = many.step_many(act)
+        assert torch.equal(obs_r, obs_m) and torch.equal(rew_r, rew_m)
+        assert torch.equal(term_r, term_m) and torch.equal(trunc_r, trunc_m)
+        for k in range(K):
+            o, r, t, tr, _ = single.step(act[k])
+            assert torch.equal(o, obs_r[k]) and torch.equal(r, rew_r[k]) and torch.equal(t, term_r[k]), (c, k)
+            static_act.copy_(act[k])
+            g.replay()
+            assert torch.equal(g_out[0], o) and torch.equal(g_out[1], r) and torch.equal(g_out[2], t), (c, k)
+    assert int(term_r.sum()) > 0
+    ref = roll.get_state()
+    for e in (many, single, graphed):
+        st = e.get_state()
+        for key in ref:
+            assert np.array_equal(ref[key], st[key], equal_nan=True), key
+    for e in (roll, many, single, graphed):
+        e.close()
+
+
+def test_rollouts_are_graph_capturable():
+    """cs_rollout_random / cs_rollout_pid / cs_step_many only enqueue work: captured into a hipGraph
+    and replayed they advance the envs exactly as eager launches do."""
+    import torch
+    n, K = 5000, 16
+    mk = lambda: make_pair("lander3d", n, "float32", autoreset="next_step", seed=9)[0]
+    eager, graphed = mk(), mk()
+    for e in (eager, graphed):
+        e.configure_pid()
+        e.reset()
+    acts = torch.rand((K, n, 4), device=eager.device) * 2 - 1
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):                      # warm-up (allocates the rollout buffers), then rewind
+        graphed.rollout_random(K)
+        graphed.rollout_pid(K)
+        graphed.step_many(acts)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graphed.reset()
+    graphed.set_state(**eager.get_state())
+    graphed.pid_set_state(eager.pid_get_state())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        r1 = graphed.rollout_random(K)
+        o_rand = r1[0].clone()
+        r2 = graphed.rollout_pid(K)
+        o_pid = r2[0].clone()
+        r3 = graphed.step_many(acts)
+        o_many = r3[0].clone()
+    for rep in range(3):
+        g.replay()
+        e1 = eager.rollout_random(K)[0].clone()
+        e2 = eager.rollout_pid(K)[0].clone()
+        e3 = eager.step_many(acts)[0].clone()
+        assert torch.equal(o_rand, e1) and torch.equal(o_pid, e2) and torch.equal(o_many, e3), rep
+    se, sg = eager.get_state(), graphed.get_state()
+    for key in se:
+        assert np.array_equal(se[key], sg[key], equal_nan=True), key
+    assert np.array_equal(eager.pid_get_state(), graphed.pid_get_state())
+    eager.close()
+    graphed.close()
+
+
+@pytest.mark.parametrize("mode", ["float32", "float64"])
+def test_streaming_instantiation_matches_k_step_kernel(mode):
+    """From 3.5 M envs up the launcher picks the step-kernel instantiation that streams the state past
+    the caches (non-temporal loads / stores, whole-row FE traffic).  The K-step kernel never streams:
+    single steps at such a batch size must reproduce it bit for bit, through resets."""
+    import torch
+    n, K = 3670016 + 5 * 64 + 37, 8
+    mk = lambda: make_pair("lander3d", n, mode, autoreset="next_step", seed=31)[0]
+    single, many = mk(), mk()
+    single.reset()
+    many.reset()
+    g = torch.Generator(device=single.device)
+    g.manual_seed(5)
+    resets = 0
+    for chunk in range(3):
+        acts = torch.rand((K, n, 4), generator=g, device=single.device) * 2 - 1
+        obs_m, rew_m, term_m, trunc_m = many.step_many(acts)
+        for k in range(K):
+            o, r, t, tr, _ = single.step(acts[k])
+            assert torch.equal(o, obs_m[k]) and torch.equal(r, rew_m[k]) and torch.equal(t, term_m[k]), (chunk, k)
+        resets += int(term_m.sum())
+    assert resets > n            # every env finished at least one episode on average
+    ss, sm = single.get_state(), many.get_state()
+    for key in ss:
+        assert np.array_equal(ss[key], sm[key], equal_nan=True), key
+    single.close()
+    many.close()
+
+
+# ---------------------------------------------------------------------------------------
+# launcher choices (stream hints by batch size) never change results
+# ---------------------------------------------------------------------------------------
+def test_tuning_overrides_from_the_environment(monkeypatch):
+    """COPTERSTEP_* environment variables are read by cs_create; cs_set_tuning overrides them;
+    zero returns to the built-in default."""
+    import gym_copter_amd
+    monkeypatch.setenv("COPTERSTEP_NT_ACTION_MAX_ENVS", "1234")
+    env = gym_copter_amd.CopterVecEnv("lander3d", 256)
+    t = env.get_tuning()
+    assert t["nt_action_max_envs"] == 1234 and t["nt_state_min_envs"] == 3670016
+    assert t["direct_rows_max_envs"] == 65536
+    t = env.set_tuning(nt_state_min_envs=512)
+    assert t == {"nt_action_max_envs": 98304, "nt_state_min_envs": 512, "direct_rows_max_envs": 65536}
+    env.close()
+
+
+@pytest.mark.parametrize("task", ["lander3d", "hover3d"])
+def test_k_step_row_store_instantiations_agree(task):
+    """cs_step_many / cs_rollout_* store observation rows per lane up to direct_rows_max_envs and through
+    the LDS transpose beyond: the same results either way, also on a ragged last wavefront."""
+    import torch
+    n, K = 3000 + 37, 12
+    rng = np.random.default_rng(4)
+    envs = []
+    for direct_max in (1, 1 << 30):          # transpose / per-lane rows
+        e, _ = make_pair(task, n, "float32", autoreset="next_step", seed=6)
+        e.set_tuning(direct_rows_max_envs=direct_max)
+        e.configure_pid("hover" if task == "hover3d" else "lander")
+        e.reset()
+        envs.append(e)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (K, n, 4)).astype(np.float32)).to(envs[0].device)
+    for call in (lambda e: e.step_many(acts), lambda e: e.rollout_random(K, return_actions=True),
+                 lambda e: e.rollout_pid(K, return_actions=True)):
+        a, b = call(envs[0]), call(envs[1])
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    s1, s2 = envs[0].get_state(), envs[1].get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k], equal_nan=True), k
+    for e in envs:
+        e.close()
+
+
+@pytest.mark.parametrize("tuning", [dict(nt_action_max_envs=1, nt_state_min_envs=1),      # streamed state
+                                    dict(nt_action_max_envs=1)])                           # plain (vs streamed actions)
+def test_stream_hint_instantiations_agree(tuning):
+    """The three instantiations of the lean kernel (streamed actions / plain / streamed state) produce
+    identical results on the same batch: the thresholds only choose cache hints."""
+    import torch
+    n = 3000
+    rng = np.random.default_rng(9)
+    ref, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=2)
+    alt, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=2)
+    alt.set_tuning(**tuning)
+    ref.reset()
+    alt.reset()
+    for t in range(50):
+        a = torch.from_numpy(rng.uniform(-1, 1, (n, 4)).astype(np.float32)).to(ref.device)
+        for u, v in zip(ref.step(a)[:4], alt.step(a)[:4]):
+            assert torch.equal(u, v), (tuning, t)
+    s1, s2 = ref.get_state(), alt.get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k], equal_nan=True), k
+    ref.close()
+    alt.close()
+
+
+# ---------------------------------------------------------------------------------------
+# sizes: odd batches in the K-step kernels (8-byte aligned row blocks), the context size limit
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task,n", [("lander3d", 4131), ("hover2d", 1023), ("lander1d", 63)])
+def test_step_many_on_odd_batch_sizes(task, n):
+    """With an odd n the row block of step k >= 1 (obs_dev + k*n*OBS floats) is only 8-byte aligned: the
+    K-step kernels then store rows without the 16-byte vector path.  Bit-identical to single steps."""
+    import torch
+    K = 7
+    rng = np.random.default_rng(n)
+    many, _ = make_pair(task, n, "float32", autoreset="next_step", seed=3)
+    one, _ = make_pair(task, n, "float32", autoreset="next_step", seed=3)
+    many.reset()
+    one.reset()
+    for chunk in range(3):
+        acts = torch.from_numpy(rng.uniform(-1, 1, (K, n, many.action_dim)).astype(np.float32)).to(many.device)
+        obs, rew, term, trunc = many.step_many(acts)
+        for k in range(K):
+            o, r, t, u, _ = one.step(acts[k])
+            assert torch.equal(obs[k], o) and torch.equal(rew[k], r) and torch.equal(term[k], t), (chunk, k)
+    many.close()
+    one.close()
+
+
+def test_two_contexts_driven_from_two_threads():
+    """include/copterstep.h: contexts are not thread-safe, distinct contexts are independent -- two host threads,
+    each with its own context and its own stream, stepping concurrently, produce what the same contexts produce
+    when stepped one after the other."""
+    import threading
+    import torch
+    import gym_copter_amd
+    n, T = 4096, 400
+    g = torch.Generator(device="cuda")
+    g.manual_seed(23)
+    acts = torch.rand((T, n, 4), generator=g, device="cuda") * 2 - 1
+
+    def fly(env, stream, out, errs):
+        try:
+            with torch.cuda.stream(stream):
+                env.reset()
+                for t in range(T):
+                    o, r, term, _, _ = env.step(acts[t])
+                    if t % 50 == 49:
+                        out.append((o.clone(), r.clone(), term.clone()))
+                stream.synchronize()
+        except Exception as e:      # surfaced by the main thread
+            errs.append(e)
+
+    def run(threaded):
+        envs = [gym_copter_amd.CopterVecEnv("lander3d", n, seed=31 + k, autoreset_mode="next_step") for k in (0, 1)]
+        streams = [torch.cuda.Stream() for _ in envs]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        outs, errs = ([], []), []
+        if threaded:
+            th = [threading.Thread(target=fly, args=(envs[k], streams[k], outs[k], errs)) for k in (0, 1)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        else:
+            for k in (0, 1):
+                fly(envs[k], streams[k], outs[k], errs)
+        assert not errs, errs
+        torch.cuda.synchronize()
+        states = [e.get_state() for e in envs]
+        for e in envs:
+            e.close()
+        return outs, states
+
+    (a0, a1), sa = run(True)
+    (b0, b1), sb = run(False)
+    for x, y in zip(a0 + a1, b0 + b1):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v)
+    for s1, s2 in zip(sa, sb):
+        for k in s1:
+            assert np.array_equal(s1[k], s2[k], equal_nan=True), k
+
+
+def test_caller_side_policy_fused_into_the_k_step_kernel():
+    """tests/host/rollout_policy_host.hip: the caller's OWN policy as a device functor, instantiated into the K-step
+    kernel in the caller's translation unit (include/copterstep_rollout.h on cs_get_launch_view): a replay policy is
+    bit-identical to cs_step_many, a closed-loop policy with per-env state is bit-identical to a twin stepped with
+    cs_step on the recorded actions (and the host re-evaluates the law from what the twin returned), on the lean and
+    on the full-featured instantiation; the wrong task is refused.  Prints us per env step at 65 536 envs."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "rollout_policy_host")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    p = subprocess.run([exe, "time"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert "rollout_policy_host: OK" in p.stdout
+    print(p.stdout)
+
+
+def test_launch_view_describes_the_context():
+    import ctypes as C
+    import gym_copter_amd
+    from gym_copter_amd import _lib
+    for kw, lean in ((dict(), 1), (dict(episode_stats=True), 0), (dict(substeps=3), 1)):
+        env = gym_copter_amd.CopterVecEnv(task="hover3d", num_envs=1000, state_dtype="float64", **kw)
+        v = _lib.LaunchView()
+        # struct_size is an in-parameter: a caller built against another layout is refused and not written to
+        v.struct_size, v.grid = C.sizeof(_lib.LaunchView) - 8, 777
+        assert env._lib.cs_get_launch_view(env._ctx, C.byref(v)) == _lib.ERR_ABI and v.grid == 777
+        assert "struct_size" in env._lib.cs_last_error().decode()
+        v.struct_size = C.sizeof(_lib.LaunchView)
+        _lib.check(env._lib.cs_get_launch_view(env._ctx, C.byref(v)))
+        assert (v.struct_size, v.abi_version) == (C.sizeof(_lib.LaunchView), _lib.ABI_VERSION)
+        assert (v.task, v.state_mode, v.num_envs, v.grid, v.block) == (_lib.TASK_HOVER3D, _lib.STATE_F64, 1000, 16, 64)
+        assert v.lean == lean and v.one_call == (0 if "substeps" in kw else 1) and v.direct_rows == 1
+        assert v.consts and v.state and v.consts_size > 256 and v.state_size >= 32
+        env.serve_begin(2, timeout=1.0)                      # refused while a served session is open
+        assert env._lib.cs_get_launch_view(env._ctx, C.byref(v)) == _lib.ERR_ARG
+        env._lib.cs_set_last_error(b"said by a caller-side header")     # (what copterstep_rollout.h's refusals use)
+        assert env._lib.cs_last_error() == b"said by a caller-side header"
+        env.serve_end(wait=False)
+        env.close()
+
+
+@pytest.mark.parametrize("task,mode", [("lander3d", "float32"), ("hover2d", "float64")])
+def test_python_callers_policy_source_is_compiled_and_fused(task, mode, tmp_path):
+    """gym_copter_amd.compile_policy + env.rollout_policy: a policy given as HIP source (a linear law with shared
+    weights and one parameter per env) is compiled with hipcc at run time, fused into the K-step kernel and flown
+    closed-loop for K steps in one launch.  Checked against a twin env stepped with step() on the actions the policy
+    recorded (bit-identical outputs and state: the loop is closed and the fused kernel IS the step), and the law
+    itself against NumPy on the observations returned."""
+    import shutil
+    import torch
+    import gym_copter_amd
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("compile_policy needs hipcc on the box")
+    n, K = 1500, 40
+    mk = lambda: gym_copter_amd.CopterVecEnv(task=task, num_envs=n, state_dtype=mode, seed=5, autoreset_mode="next_step",
+                                             max_steps=25)
+    env, twin = mk(), mk()
+    od, ad = env.obs_dim, env.action_dim
+    rng = np.random.default_rng(3)
+    W = (rng.standard_normal((ad, od)) * 1e-3).astype(np.float32)
+    b = np.full(ad, HOVER, np.float32)
+    trim = (rng.standard_normal(n) * 2e-4).astype(np.float32)
+    params = torch.from_numpy(np.concatenate([W.ravel(), b, trim])).to(env.device)
+    policy = gym_copter_amd.compile_policy(env, _LINEAR_POLICY, cache_dir=str(tmp_path))
+    again = gym_copter_amd.compile_policy(env, _LINEAR_POLICY, cache_dir=str(tmp_path))     # served from the cache
+    assert again.path == policy.path and os.path.exists(policy.path)
+    obs0, _ = env.reset()
+    obs0 = to_np(obs0).copy()
+    twin.reset()
+    obs, rew, term, trunc, acts = (to_np(v).copy() for v in env.rollout_policy(policy, K, params, return_actions=True))
+    seen = obs0
+    for k in range(K):
+        want = (seen.astype(np.float64) @ W.T.astype(np.float64) + b + trim[:, None]).astype(np.float32)
+        assert np.allclose(acts[k], want, rtol=1e-5, atol=1e-7), k
+        o, r, t, u, _ = twin.step(torch.from_numpy(acts[k]).to(twin.device))
+        assert np.array_equal(to_np(o), obs[k]) and np.array_equal(to_np(r), rew[k]), k
+        assert np.array_equal(to_np(t), term[k]) and np.array_equal(to_np(u), trunc[k]), k
+        seen = obs[k]
+    assert term.any() or trunc.any()                     # episodes ended and restarted inside the launch
+    _assert_same_state(env, twin)
+    other = gym_copter_amd.CopterVecEnv(task="lander1d", num_envs=64)
+    with pytest.raises(ValueError):
+        other.rollout_policy(policy, 2, params)
+    with pytest.raises(RuntimeError, match="hipcc failed"):
+        gym_copter_amd.compile_policy(env, "struct Policy { this is not HIP };", cache_dir=str(tmp_path))
+    for e in (env, twin, other):
+        e.close()
+
+
+def test_rollout_pid_with_upstreams_gains_compiled_in_equals_the_generic_kernel():
+    """Under upstream's own gains a lean Lander3D env of <= 65 536 envs runs the K-step kernel whose PID terms are
+    compiled in (kPolicyPidUpstream: no masks, no integral term in the rate controllers); a twin with episode statistics
+    on runs the generic, mask-driven kernel (full-featured instantiation).  Same actions, outputs, env state and
+    controller state, bit for bit, across auto-resets; and a gain set with another term pattern takes the generic path
+    on the lean env too (it must still agree with ITS twin)."""
+    import torch
+    for gains in ({}, dict(rate_ki=0.05, pos_kd=0.0)):
+        n, K = 3000, 60
+        lean, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=5)
+        full, _ = make_pair("lander3d", n, "float32", autoreset="next_step", seed=5, episode_stats=True)
+        for e in (lean, full):
+            e.configure_pid(**gains)
+            e.reset()
+        for chunk in range(3):
+            a = lean.rollout_pid(K, return_actions=True)
+            b = full.rollout_pid(K, return_actions=True)
+            for k in range(5):
+                assert torch.equal(a[k], b[k]), (gains, chunk, k)
+        sa, sb = lean.get_state(), full.get_state()
+        for key in sa:
+            assert np.array_equal(sa[key], sb[key], equal_nan=True), (gains, key)
+        assert np.array_equal(lean.pid_get_state(), full.pid_get_state()), gains
+        assert int(sa["episode"].max()) > 1                      # episodes ended and restarted inside the launches
+        lean.close()
+        full.close()
+
+
+@pytest.mark.parametrize("form", ["many", "served"])
+def test_episode_counter_crosses_its_boundaries_inside_k_step_and_served_kernels(form):
+    """The kernels that keep the env in registers for many steps hold the WHOLE episode number in a register
+    (dev_task.h: resolve_episode / split_episode) -- a different code path from the one-launch step, which the round-4
+    test flies across the boundaries.  Same parking (just below 2^E, below 2^(E+1), below 2^32, an arbitrary large
+    number, small numbers), then K-step launches / served sessions with reset churn: outputs, episode numbers, the Philox
+    forces drawn for them and the EPH row's effect on a later one-launch step against the oracle."""
+    import torch
+    from gpu_util import assert_state_close, assert_step_close, device_episode_bits, MODE_TOL
+    from oracle import refvec
+    n, K, max_steps = 320, 12, 40
+    env, orc = make_pair("lander3d", n, "float32", "next_step", seed=33, max_steps=max_steps)
+    ebits = device_episode_bits(max_steps)
+    ep_mask = (1 << ebits) - 1
+    env.reset()
+    orc.reset()
+    ep = np.full(n, ep_mask - 1, np.uint32)
+    ep[::7] = ep_mask
+    ep[1::7] = 3
+    ep[2::7] = 2 * (ep_mask + 1) - 2
+    ep[3::7] = 0xFFFFFFFE
+    ep[4::7] = 0x9E3779B9
+    env.set_state(episode=ep)
+    orc.episode[:] = ep
+    orc.force[:] = refvec.draw_forces(orc.seed, orc.env_ids, ep - np.uint32(1), orc.tp.initial_random_force).astype(orc.T)
+    rng = np.random.default_rng(8)
+    for launch in range(4):
+        acts = rng.uniform(-1, 1, (K, n, 4)).astype(np.float32)
+        if form == "many":
+            o, r, te, tr = (to_np(v) for v in env.step_many(torch.from_numpy(acts).to(env.device)))
+            outs = [(o[k], r[k], te[k], tr[k]) for k in range(K)]
+        else:
+            env.serve_begin(K, ring=2, timeout=5.0)
+            outs = []
+            for k in range(K):
+                env.serve_submit(k, torch.from_numpy(acts[k]).to(env.device))
+                outs.append(tuple(to_np(v).copy() for v in env.serve_collect(k)))
+            assert env.serve_end() == K
+        for k in range(K):
+            want = orc.step(acts[k].astype(np.float64))
+            assert_step_close(outs[k], want, 2e-6, r_abs="auto", ctx="%s launch %d step %d" % (form, launch, k))
+        st = env.get_state()
+        assert np.array_equal(st["episode"], orc.episode), (form, launch)
+        assert np.array_equal(st["force"].astype(np.float32), orc.force.astype(np.float32)), (form, launch)
+    e0, e1 = ep.astype(np.int64), orc.episode.astype(np.int64)
+    assert np.any((e0 <= ep_mask) & (e1 > ep_mask)) and np.any((e0 > 0xFFFFFF00) & (e1 < 100) & (e1 >= 1))
+    # ... and the one-launch step picks up what the K-step kernels left in the EPH row
+    a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+    for t in range(6):
+        o, r, te, tr, _ = env.step(torch.from_numpy(a).to(env.device))
+        want = orc.step(a.astype(np.float64))
+        assert_step_close(tuple(to_np(v) for v in (o, r, te, tr)), want, 2e-6, r_abs="auto", ctx="%s tail %d" % (form, t))
+    assert np.array_equal(env.get_state(only=("episode",))["episode"], orc.episode)
+    assert_state_close(env, orc, MODE_TOL["float32"])
+    env.close()

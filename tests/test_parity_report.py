@@ -1,6 +1,6 @@
 """CPU twin of the per-component pure-relative parity report (tests/parity_report.py): the oracle in the
 device's storage modes against every golden E / V / D / W / R episode of the reference.  The -m gpu twin is
-tests/test_gpu_round3.py::test_pure_relative_parity_per_component."""
+tests/test_gpu_golden.py::test_pure_relative_parity_per_component."""
 import pytest
 
 import parity_report as pr

@@ -2,7 +2,7 @@
 """GPU box: stress the END of a served session -- cs_serve_end raises the stop word right behind the last submitted
 action row; the env kernel must still take that row.  Many short sessions (K steps each, all rows submitted at once,
 closed without waiting), each followed by cs_serve_status: a session whose tiles did not all complete K steps is a
-failure (round 5: one flaky run of tests/test_gpu_round4.py::test_a_session_closed_without_waiting_is_drained_...
+failure (round 5: one flaky run of tests/test_gpu_served.py::test_a_session_closed_without_waiting_is_drained_...
 led here -- the env kernel looked at the stop word AFTER a stale look at the row and gave up on a row that had arrived
 in between).
 
