@@ -112,13 +112,8 @@ def parse(argv=None):
     p.add_argument("--pid", type=int, default=100,
                    help="also time cs_rollout_pid / cs_rollout_random with this many steps per launch (0 = skip)")
     p.add_argument("--served", type=int, default=None,
-                   help="also time served stepping (cs_serve_*) with this many steps per session (0 = skip; default: 500 "
-                        "under --full / --served-all, else skipped)")
-    p.add_argument("--served-all", action="store_true",
-                   help="also time the served forms that do not pay against cs_step (DESIGN.md section 8): the closed loop "
-                        "with a policy kernel per step, the same with a persistent policy kernel, and the plain-rows "
-                        "compatibility form (cs_serve_submit + cs_serve_collect per step); the default run keeps "
-                        "served_producers_ahead only")
+                   help="also time served stepping (cs_serve_*: producers ahead of the env) with this many steps per session "
+                        "(0 = skip; default: 500 under --full, else skipped)")
     p.add_argument("--no-clock-sampling", action="store_true",
                    help="do not read the device's hwmon sensors (sclk / power / temperature) around the timed regions")
     p.add_argument("--no-span", action="store_true",
@@ -130,7 +125,7 @@ def parse(argv=None):
     p.add_argument("--master-port", type=int, default=0, help="self-launch only: rendezvous port (0 = pick a free one)")
     a = p.parse_args(argv)
     if a.served is None:
-        a.served = 500 if (a.full or a.served_all) else 0
+        a.served = 500 if a.full else 0
     return a
 
 
@@ -1125,8 +1120,7 @@ def main(argv=None):
                                         if isinstance(extra.get(k, {}).get("roofline", {}).get("frac"), float)},
                   "with_packed_allgather": pick(extra, "value_with_packed_allgather", "ms_per_step_with_packed_allgather"),
                   "served_us": {k: round(extra[k]["us_per_step"], 3)
-                                for k in ("served_closed_loop", "served_closed_loop_persistent_policy",
-                                          "served_submit_collect", "served_producers_ahead")
+                                for k in ("served_producers_ahead",)
                                 if "us_per_step" in extra.get(k, {})},
                   "fused_caller_policy_us": {k: extra["rollout_custom"][k] for k in
                                              ("closed_loop_law_with_state", "linear_policy_44_weights", "replay_policy")
@@ -1309,26 +1303,6 @@ struct Policy {
                 except Exception:
                     pass
 
-        if a.served_all and a.task in ("lander3d", "hover3d"):
-            served_leg("served_closed_loop", lambda s: env.serve_policy_pid(s), 2, wire + 256.0,
-                       "closed loop with the policy as its OWN kernel per step (cs_serve_policy_pid: outputs of step "
-                       "s-1 -> PID heuristic -> actions of step s) against the persistent env kernel: one launch per "
-                       "step, two hand-offs through device memory; bit-identical to cs_rollout_pid "
-                       "(tests/test_gpu_served.py::test_served_closed_loop_policy_kernel_equals_rollout_pid); compare "
-                       "with a policy kernel + cs_step per step (config.actions_produced_by_a_preceding_kernel)",
-                       prepare=lambda: env.configure_pid())
-            served_leg("served_closed_loop_persistent_policy",
-                       lambda s: env.serve_policy_pid(0, num_steps=k) if s == 0 else None, 4, wire,
-                       "the same closed loop with the POLICY persistent as well (cs_serve_policy_pid_many: one policy "
-                       "kernel per session, controllers in registers): no launch left in the loop -- two hand-offs "
-                       "through device memory and the two kernels' arithmetic per step")
-        if a.served_all:
-            served_leg("served_submit_collect",
-                       lambda s: (env.serve_submit(s, actions[s % actions.shape[0]]), env.serve_collect(s)), 4,
-                       wire + 4 * env.action_dim + 4 * od + 6,
-                       "plain tensors in and out: cs_serve_submit + cs_serve_collect per step (two small launches on one "
-                       "stream) against the persistent env kernel; bit-identical to cs_step "
-                       "(tests/test_gpu_served.py::test_served_steps_are_bit_identical_to_cs_step)")
         side = served_side
 
         def submit_two_streams(s):
