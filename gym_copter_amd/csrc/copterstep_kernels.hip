@@ -222,7 +222,13 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   const uint32_t i = tile_index * kBlock + threadIdx.x;
   const int lane = threadIdx.x;
   const uint32_t env0 = i - lane;
-  const bool valid = i < n;
+  // DIRECT_ROWS (the <= 65 536-env instantiations, one wavefront per SIMD: the loop is bound by its INSTRUCTION COUNT,
+  // scalar ones included -- profiles/r06_ab_kstep_shaping.txt) is also the form with UNCONDITIONAL outputs: the launcher
+  // picks it only for whole tiles (n % 64 == 0: no ragged last wavefront) whose four output arrays are all there with the
+  // flags interleaved ([K, N, 2], what CopterVecEnv allocates), so a step's stores need no exec masks, no pointer tests
+  // and no branches (nine s_cbranch + a dozen scalar instructions per step in the general form).  Any other call runs the
+  // LDS-transpose instantiation, which keeps every test.
+  const bool valid = DIRECT_ROWS ? true : i < n;
   using TILE = TileIO<MODE>;
   const TILE tile(s, tile_index, lane);
 
@@ -351,19 +357,21 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       asm volatile("" : "+v"(act_next.x), "+v"(act_next.y), "+v"(act_next.z), "+v"(act_next.w));
     }
     CS_KSTAMP(CS_KST(o), 7);  // controller hand-over / action row delivered
-    if (valid) {
-      if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
-      write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
-    }
-    CS_KSTAMP(CS_KST(o), 8);  // reward + flag stores issued
     if constexpr (DIRECT_ROWS) {
-      // one wavefront per SIMD: instruction issue is the limit, and three row stores per lane cost fewer
-      // instructions than the LDS transpose (whose full-line stores win as soon as SIMDs hold two wavefronts)
-      if (obs_dev != nullptr && valid) {
-        float* dst = obs_dev + (row + i) * OBS;
-        store_row_direct<OBS>(dst, out.row);
-      }
+      // unconditional (see `valid` above): reward, the two flags as one 2-byte store, and the observation row straight
+      // from the lane -- at one wavefront per SIMD three row stores per lane cost fewer instructions than the LDS
+      // transpose (whose full-line stores win as soon as SIMDs hold two wavefronts)
+      CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
+      const uint16_t both = (uint16_t)((out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u));
+      CS_NT_STORE(both, at32<uint16_t>(terminated_dev + 2 * row, i << 1));
+      CS_KSTAMP(CS_KST(o), 8);  // reward + flag stores issued
+      store_row_direct<OBS>(obs_dev + (row + i) * OBS, out.row);
     } else {
+      if (valid) {
+        if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
+        write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
+      }
+      CS_KSTAMP(CS_KST(o), 8);  // reward + flag stores issued
       write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
     }
     CS_KSTAMP(CS_KST(o), 9);   // observation row stores issued
@@ -808,6 +816,9 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
   const dim3 grid(grid_for(s.n)), block(kBlock);
   const bool lean = lean_config(c, s);
   const uint32_t direct_max = tune.direct_rows_max_envs ? tune.direct_rows_max_envs : kDirectRowsMaxEnvs;
+  // per-lane rows AND unconditional outputs (step_many_kernel: DIRECT_ROWS): whole tiles, all four outputs, flags interleaved
+  const bool direct = s.n <= direct_max && s.n % (uint32_t)kBlock == 0u && obs != nullptr && reward != nullptr &&
+                      term != nullptr && trunc == term + 1;
   const PidConst pc = pid ? *pid : PidConst{};
 #define CS_MANY_N(LEAN, POLICY, ONE, DIRECT)                                                           \
   hipLaunchKernelGGL((step_many_kernel<TASK, MODE, LEAN, POLICY, ONE, DIRECT>), grid, block, 0, stream, \
@@ -819,7 +830,7 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
   do {                                                         \
     if constexpr (LEAN && is_tuned(TASK, MODE)) {              \
       if (c.nsub == 1) {                                       \
-        if (s.n <= direct_max)                                 \
+        if (direct)                                            \
           CS_MANY_N(LEAN, POLICY, true, true);                 \
         else                                                   \
           CS_MANY_N(LEAN, POLICY, true, false);                \
@@ -840,7 +851,7 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
         } else {
           return hipErrorInvalidValue;
         }
-      } else if (lean && is_tuned(TASK, MODE) && c.nsub == 1 && s.n <= direct_max &&
+      } else if (lean && is_tuned(TASK, MODE) && c.nsub == 1 && direct &&
                  (pc.terms & (kPidRateI | kPidRateD | kPidPosI | kPidPosD)) == kPidUpstreamTerms) {
         // upstream's own gains at <= 65 536 envs: the instantiation with their terms compiled in
         if constexpr (is_tuned(TASK, MODE)) CS_MANY_N(true, kPolicyPidUpstream, true, true);

@@ -420,11 +420,17 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
 
   CS_KSTAMP(CS_KST(o), 3);  // Dynamics.setMotors done
   // ---- round to the stored precision; everything below sees exactly what is stored ----
+  // The float32 observation row = round-to-nearest of the stored value (slots FIRST .. FIRST+OBS-1).  ROW_LATE (the lean
+  // K-step loops, which are bound by their instruction count): converted once, AFTER the masked reset has put the fresh
+  // state into e.x -- the same values ((float)(double)w0 == (float)w0) without the OBS moves that overwrite the row in
+  // every step in which any lane of the wavefront resets.  (SAME_STEP's final_obs needs the pre-reset row: not LEAN.)
+  constexpr bool ROW_LATE = IN_LOOP && LEAN;
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     e.x[k] = round_stored<MODE>(e.x[k]);
-    // float32 observation: round-to-nearest of the stored value (slots FIRST .. FIRST+OBS-1)
-    if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)e.x[k];
+    if constexpr (!ROW_LATE) {
+      if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)e.x[k];
+    }
   }
 
   CS_KSTAMP(CS_KST(o), 4);  // stored-word rounding + observation row done
@@ -478,7 +484,9 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     for (int k = 0; k < 12; ++k) {
       const T w0 = (k == 4) ? (T)c.z0 : (T)0;
       e.x[k] = (double)w0;
-      if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
+      if constexpr (!ROW_LATE) {
+        if (k >= FIRST && k < FIRST + OBS) out.row[k - FIRST] = (float)w0;
+      }
     }
     next_episode<MODE, IN_LOOP>(e);
     e.fs = c.status0;
@@ -488,6 +496,14 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
     e.ticks = 0;  // a new Dynamics object (task.py:161)
     e.ep_ret = 0.f;
     e.prev_sh = c.reset_shaping;
+  }
+  if constexpr (ROW_LATE) {
+    // (the empty asm hides that a reset lane's e.x holds constants: otherwise the compiler converts inside the no-reset
+    // branch and keeps the OBS constant moves inside the reset branch -- the instruction count this form is there to cut)
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) asm volatile("" : "+v"(e.x[FIRST + k]));
+#pragma unroll
+    for (int k = 0; k < OBS; ++k) out.row[k] = (float)e.x[FIRST + k];
   }
   out.reward = reward;
   out.term = term;
