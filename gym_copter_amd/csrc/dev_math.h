@@ -139,11 +139,17 @@ __device__ __forceinline__ void sincos_f64(const DevConst& k, double x, double& 
 struct Trig {
   double sph, cph, sth, cth, sps, cps;
 };
+// __all() without its detour through an integer: HIP's __all(p) turns p into 0 / 1 in a vector register and compares that
+// again (v_cndmask + v_cmp per call); a ballot of the NEGATED predicate against zero is scalar work on the compare's own
+// mask.  Same meaning: true iff p holds on every ACTIVE lane.  Used in the K-step loops (bound by their instruction
+// count); the one-launch kernels keep __all -- their schedule is frozen.
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
 // IN_LOOP: the call sits in a K-step loop, where laying the in-range path out as the fall-through pays
 // (-3 % per step); in the one-step kernel the same layout measured +2.5 %, so it keeps the compiler's
 template <bool FULL, bool IN_LOOP>
 __device__ __forceinline__ void sincos_roll_pitch(const DevConst& c, double phi, double the, Trig& t) {
-  const bool in_range = __all(fabs(phi) < 0.785 && fabs(the) < 0.785);
+  const bool in_range = IN_LOOP ? wave_all(fabs(phi) < 0.785 && fabs(the) < 0.785)
+                                : __all(fabs(phi) < 0.785 && fabs(the) < 0.785);
   if (IN_LOOP ? __builtin_expect(in_range, 1) : in_range) {
     sincos_kernel<FULL>(c.trig, phi, t.sph, t.cph);
     sincos_kernel<FULL>(c.trig, the, t.sth, t.cth);
@@ -154,7 +160,7 @@ __device__ __forceinline__ void sincos_roll_pitch(const DevConst& c, double phi,
 }
 template <bool FULL, bool IN_LOOP>
 __device__ __forceinline__ void sincos_yaw(const DevConst& c, double psi, Trig& t) {
-  const bool in_range = __all(fabs(psi) < 0.785);
+  const bool in_range = IN_LOOP ? wave_all(fabs(psi) < 0.785) : __all(fabs(psi) < 0.785);
   if (IN_LOOP ? __builtin_expect(in_range, 1) : in_range) {
     sincos_kernel<FULL>(c.trig, psi, t.sps, t.cps);
   } else {

@@ -165,7 +165,7 @@ __device__ __forceinline__ int physics_call(const DevConst& c, const Coef& q, co
     // two-stage form below.  Same operations on the same values either way.  (TRIG3 is off in the PID kernels: with
     // the controllers' sixteen state words live across the step, six interleaved chains cost them 1 % instead of
     // saving 1-2 %: interleaved A/B, round 5.)
-    if (__builtin_expect(__all(fabs(x[6]) < 0.785 && fabs(x[8]) < 0.785 && fabs(x[10]) < 0.785), 1)) {
+    if (__builtin_expect(wave_all(fabs(x[6]) < 0.785 && fabs(x[8]) < 0.785 && fabs(x[10]) < 0.785), 1)) {
 #ifdef CS_EXP_LOCKSTEP
       sincos3_lockstep<FULL>(c.trig, x[6], x[8], x[10], t.sph, t.cph, t.sth, t.cth, t.sps, t.cps);
 #else

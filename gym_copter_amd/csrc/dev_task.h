@@ -274,6 +274,22 @@ __device__ __forceinline__ void finish_carry(const DevConst& c, const TILE& tile
 // One action row -> the four motor demands: _get_motors (lander.py:95-97 for the 3D tasks; the
 // fan-outs of attic lander2d.py:48-50 / lander1d.py:46-48 for the variants).  Coalesced
 // 16 / 8 / 4 bytes per lane.
+// ... the same from a per-lane pointer (the K-step loop's running row pointer: one 64-bit add per step instead of
+// rebuilding base + k * N * A with a 64-bit multiply)
+template <int TASK>
+__device__ __forceinline__ float4 load_action_at(const float* p) {
+  constexpr int A = task_act_dim(TASK);
+  if constexpr (A == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    return make_float4(a.x, a.y, a.z, a.w);
+  } else if constexpr (A == 2) {
+    const f32x2 a = *reinterpret_cast<const f32x2*>(p);
+    return make_float4(a.x, a.y, a.y, a.x);
+  } else {
+    const float a = *p;
+    return make_float4(a, a, a, a);
+  }
+}
 template <int TASK, bool STREAM = false>
 __device__ __forceinline__ float4 load_action(const float* base, uint32_t env) {
   constexpr int A = task_act_dim(TASK);

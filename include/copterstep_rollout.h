@@ -81,7 +81,10 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
   const int lane = threadIdx.x;
   const uint32_t i = tile_index * kBlock + lane;
   const uint32_t env0 = i - lane;
-  const bool valid = i < n;
+  /* DIRECT_ROWS = per-lane observation rows AND unconditional outputs: cs_rollout_custom picks it only for whole tiles
+     (n % 64 == 0) with all four output arrays present and the flags interleaved, as the library's own K-step kernels do
+     (copterstep_kernels.hip: step_many_kernel) -- no exec masks, pointer tests or branches around a step's stores */
+  const bool valid = DIRECT_ROWS ? true : i < n;
   using TILE = TileIO<MODE>;
   const TILE tile(s, tile_index, lane);
 
@@ -162,15 +165,16 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
     fresh = out.did_reset;
     CS_KSTAMP(CS_KST(o), 7);
-    if (valid) {
-      if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
-      write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
-    }
     if constexpr (DIRECT_ROWS) {  /* one wavefront per SIMD: three row stores per lane cost fewer instructions */
-      if (obs_dev != nullptr && valid) {
-        store_row_direct<OBS>(obs_dev + (row + i) * OBS, out.row);
-      }
+      CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
+      const uint16_t both = (uint16_t)((out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u));
+      CS_NT_STORE(both, at32<uint16_t>(terminated_dev + 2 * row, i << 1));
+      store_row_direct<OBS>(obs_dev + (row + i) * OBS, out.row);
     } else {
+      if (valid) {
+        if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
+        write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
+      }
       write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
     }
     CS_KSTAMP(CS_KST(o), 9);
@@ -225,7 +229,10 @@ int cs_rollout_custom(cs_ctx* ctx, int num_steps, POLICY policy, float* actions_
   hipLaunchKernelGGL((cs::rollout_custom_kernel<TASK, MODE, LEAN, ONE, DIRECT, POLICY>), grid, block, 0, stream,    \
                      s.tiles, s.n, actions_out, obs_dev, reward_dev, terminated_dev, truncated_dev, num_steps, c, s, \
                      policy)
-  if (v.lean && v.one_call && v.direct_rows)
+  /* per-lane rows with unconditional outputs: whole tiles, all four outputs, flags interleaved ([K, N, 2]) */
+  const bool direct = v.direct_rows && s.n % (uint32_t)cs::kBlock == 0u && obs_dev != nullptr && reward_dev != nullptr &&
+                      terminated_dev != nullptr && truncated_dev == terminated_dev + 1;
+  if (v.lean && v.one_call && direct)
     CS_ROLLOUT_LAUNCH(true, true, true);
   else if (v.lean && v.one_call)
     CS_ROLLOUT_LAUNCH(true, true, false);
