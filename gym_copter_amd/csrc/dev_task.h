@@ -440,7 +440,13 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
   // K-step loops, which are bound by their instruction count): converted once, AFTER the masked reset has put the fresh
   // state into e.x -- the same values ((float)(double)w0 == (float)w0) without the OBS moves that overwrite the row in
   // every step in which any lane of the wavefront resets.  (SAME_STEP's final_obs needs the pre-reset row: not LEAN.)
+  // Not in kernels that fuse a CALLER'S policy (CS_NO_ROW_LATE, set by include/copterstep_rollout.h): there the form is
+  // worth 1-2 % for a light policy and cost a register-hungry one (a per-lane MLP at 410 registers) 30 %.
+#ifdef CS_NO_ROW_LATE
+  constexpr bool ROW_LATE = false;
+#else
   constexpr bool ROW_LATE = IN_LOOP && LEAN;
+#endif
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     e.x[k] = round_stored<MODE>(e.x[k]);

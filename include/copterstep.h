@@ -263,7 +263,11 @@ int cs_step_ex(cs_ctx* ctx, const cs_step_io* io, void* stream);
  * obs_dev [K,N,obs_dim], reward_dev [K,N], terminated_dev / truncated_dev [K,N] (each
  * nullable).  The result is bit-identical to K calls of cs_step with actions_dev[k]; the
  * env state stays in registers between the steps instead of crossing HBM every step.
- * The optional outputs of cs_step_ex (done list, final_obs) are not produced here. */
+ * The optional outputs of cs_step_ex (done list, final_obs) are not produced here.
+ * Fastest form (this and every cs_rollout_* entry point, up to cs_tuning.direct_rows_max_envs = 65 536 envs): whole tiles
+ * (num_envs a multiple of 64), all four outputs present, the flags interleaved (truncated_dev == terminated_dev + 1, i.e.
+ * one [K,N,2] byte array) -- the kernel then stores without masks, pointer tests or branches (-5 ... -9 % per step).  Any
+ * other combination is served by the general instantiation; the results are the same bits either way. */
 int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float* obs_dev,
                  float* reward_dev, uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
 

@@ -57,6 +57,8 @@
 #include "dev_codec.h"
 #include "dev_math.h"
 #include "dev_physics.h"
+/* the caller's policy may need every register there is: no late row conversion in these kernels (dev_task.h: ROW_LATE) */
+#define CS_NO_ROW_LATE 1
 #include "dev_task.h"
 #include "dev_pid.h"
 
@@ -82,10 +84,9 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
   const uint32_t i = tile_index * kBlock + lane;
   const uint32_t env0 = i - lane;
   /* DIRECT_ROWS = per-lane observation rows AND unconditional outputs: cs_rollout_custom picks it only for whole tiles
-     (n % 64 == 0) with all four output arrays present, as the library's own K-step kernels do (copterstep_kernels.hip:
-     step_many_kernel) -- no exec masks or pointer tests around a step's stores, one uniform branch on the flags' form */
+     (n % 64 == 0) with all four output arrays present and the flags interleaved ([K, N, 2]), as the library's own K-step
+     kernels do (copterstep_kernels.hip: step_many_kernel) -- no exec masks, pointer tests or branches around a step's stores */
   const bool valid = DIRECT_ROWS ? true : i < n;
-  const bool flags_interleaved = truncated_dev == terminated_dev + 1;
   using TILE = TileIO<MODE>;
   const TILE tile(s, tile_index, lane);
 
@@ -168,13 +169,8 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     CS_KSTAMP(CS_KST(o), 7);
     if constexpr (DIRECT_ROWS) {  /* one wavefront per SIMD: three row stores per lane cost fewer instructions */
       CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
-      if (flags_interleaved) {
-        const uint16_t both = (uint16_t)((out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u));
-        CS_NT_STORE(both, at32<uint16_t>(terminated_dev + 2 * row, i << 1));
-      } else {
-        CS_NT_STORE((uint8_t)(out.term ? 1 : 0), at32<uint8_t>(terminated_dev + row, i));
-        CS_NT_STORE((uint8_t)(out.trunc ? 1 : 0), at32<uint8_t>(truncated_dev + row, i));
-      }
+      const uint16_t both = (uint16_t)((out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u));
+      CS_NT_STORE(both, at32<uint16_t>(terminated_dev + 2 * row, i << 1));
       store_row_direct<OBS>(obs_dev + (row + i) * OBS, out.row);
     } else {
       if (valid) {
@@ -235,9 +231,9 @@ int cs_rollout_custom(cs_ctx* ctx, int num_steps, POLICY policy, float* actions_
   hipLaunchKernelGGL((cs::rollout_custom_kernel<TASK, MODE, LEAN, ONE, DIRECT, POLICY>), grid, block, 0, stream,    \
                      s.tiles, s.n, actions_out, obs_dev, reward_dev, terminated_dev, truncated_dev, num_steps, c, s, \
                      policy)
-  /* per-lane rows with unconditional outputs: whole tiles, all four output arrays present */
+  /* per-lane rows with unconditional outputs: whole tiles, all four outputs, flags interleaved ([K, N, 2]) */
   const bool direct = v.direct_rows && s.n % (uint32_t)cs::kBlock == 0u && obs_dev != nullptr && reward_dev != nullptr &&
-                      terminated_dev != nullptr && truncated_dev != nullptr;
+                      terminated_dev != nullptr && truncated_dev == terminated_dev + 1;
   if (v.lean && v.one_call && direct)
     CS_ROLLOUT_LAUNCH(true, true, true);
   else if (v.lean && v.one_call)

@@ -39,6 +39,37 @@ if os.path.exists(P + "/bench_full_unprofiled.json"):       # (round 6 on: the l
 for f in sorted(glob.glob(P + "/span_*.json")):
     shutil.copy(f, R + "/profiles/%s_%s" % (RND, os.path.basename(f)))
 
+# registers / occupancy of the default instantiations, appended to the summary so that the next regression is visible
+# (VERDICT round 5 #4): from the ISA listing of THIS tree (make -C gym_copter_amd/csrc asm)
+DEFAULTS = (("step_kernelILi0ELi0ELb1ELb1ELb0ELb1E", "step_kernel<lander3d, float32 words, lean, stream actions, one call>  headline, <= 98 304 envs"),
+            ("step_kernelILi0ELi0ELb1ELb0ELb0ELb1E", "step_kernel<lander3d, ..., no stream hints, one call>               98 304 < envs < 3.5 M"),
+            ("step_kernelILi0ELi0ELb1ELb0ELb1ELb1E", "step_kernel<lander3d, ..., stream state, one call>                  >= 3.5 M envs (the 4 M point)"),
+            ("step_kernelILi1ELi0ELb1ELb0ELb0ELb1E", "step_kernel<hover3d, ..., no stream hints, one call>                BASELINE configs[2]"),
+            ("step_kernelILi0ELi0ELb1ELb1ELb0ELb0E", "step_kernel<lander3d, ..., stream actions, substep loop>            BASELINE configs[4]"),
+            ("step_many_kernelILi0ELi0ELb1ELi0ELb1ELb1E", "step_many_kernel<lander3d, ..., open loop, per-lane rows>          cs_step_many, <= 65 536 envs"),
+            ("step_many_kernelILi0ELi0ELb1ELi4ELb1ELb1E", "step_many_kernel<lander3d, ..., PID (upstream's terms), per-lane rows>  cs_rollout_pid"),
+            ("step_many_kernelILi0ELi0ELb1ELi2ELb1ELb1E", "step_many_kernel<lander3d, ..., random policy, per-lane rows>      cs_rollout_random"))
+listing = R + "/gym_copter_amd/csrc/build/copterstep_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"
+subprocess.run(["make", "-C", R + "/gym_copter_amd/csrc", "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+if os.path.exists(listing):
+    import re
+    txt = open(listing).read()
+    rows = []
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+        g = lambda k: int(re.search(r"\.amdhsa_%s (\d+)" % k, m.group(2)).group(1))
+        rows.append((m.group(1), g("next_free_vgpr"), g("next_free_sgpr"), g("private_segment_fixed_size"), g("group_segment_fixed_size")))
+    nk = len([r for r in rows if "step_kernel" in r[0] or "step_many_kernel" in r[0]])
+    with open(R + "/profiles/%s_summary.txt" % RND, "a") as f:
+        f.write("\n== kernel resources of the default instantiations (ISA listing of this tree: make asm; occupancy = wavefronts per SIMD "
+                "= min(8, 512 // (VGPRs rounded up to 8))) ==\n")
+        for key, what in DEFAULTS:
+            for name, v, sg, sc, lds in rows:
+                if key in name:
+                    f.write("%-100s VGPR %3d  SGPR %3d  scratch %d  LDS %4d  occupancy %d\n"
+                            % (what, v, sg, sc, lds, min(8, 512 // ((v + 7) // 8 * 8))))
+        f.write("%d kernels in the listing, %d of them step / step_many instantiations; with scratch: %d\n"
+                % (len(rows), nk, sum(1 for r in rows if r[3] > 0)))
+
 import bench  # noqa: E402  (kernel_source_hash only; nothing touches a GPU)
 summ = json.load(open(P + "/summary.json"))
 commit = subprocess.run(["git", "-C", R, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
