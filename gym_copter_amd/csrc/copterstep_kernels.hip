@@ -185,7 +185,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(CS_STEP_ARGS) {
 enum { kPolicyNone = 0, kPolicyPid = 1, kPolicyRandom = 2, kPolicyPidHover = 3, kPolicyPidUpstream = 4 };
 constexpr int kPidUpstreamTerms = kPidRateD | kPidPosI | kPidPosD;  // attic/mars/lander3d.py:32-36: rate 1/0/1, position 1e-5/0.1/4
 
-template <int TASK, int MODE, bool LEAN, int POLICY, bool ONE_CALL, bool DIRECT_ROWS>
+// ROWS: how a step's outputs leave (dev_task.h: kRowsTranspose / kRowsDirect / kRowsDirectAll)
+template <int TASK, int MODE, bool LEAN, int POLICY, bool ONE_CALL, int ROWS>
 __global__ __launch_bounds__(kBlock) void step_many_kernel(
     char* const tiles, const uint32_t n_envs, float* const actions_dev, float* const obs_dev,
     float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   // occupancy: the PID kernel at 254 registers held ONE wavefront per SIMD at 4 M envs.  Those leave the PID GAINS
   // where the compiler puts them -- park_gains below is gated on DIRECT_ROWS; the step's own constants
   // (park_constants) are parked in every instantiation.)
+  constexpr bool DIRECT_ROWS = ROWS != kRowsTranspose, ALL_OUT = ROWS == kRowsDirectAll;
   DevConst c = c_arg;
   PidConst pc = pc_arg;
   park_constants<MODE == CS_STATE_F64 || kFullTrigInEveryMode>(c);
@@ -222,14 +224,14 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
   const uint32_t i = tile_index * kBlock + threadIdx.x;
   const int lane = threadIdx.x;
   const uint32_t env0 = i - lane;
-  // DIRECT_ROWS (the <= 65 536-env instantiations, one wavefront per SIMD: the loop is bound by its INSTRUCTION COUNT,
-  // scalar ones included -- profiles/r06_ab_kstep_shaping.txt) is also the form with UNCONDITIONAL outputs: the launcher
-  // picks it only for whole tiles (n % 64 == 0: no ragged last wavefront) whose four output arrays are all there with the
-  // flags interleaved ([K, N, 2], what CopterVecEnv allocates), so a step's stores need no exec masks, no pointer tests
-  // and no branches (nine s_cbranch + a dozen scalar instructions per step in the general form).  Any other call runs the
-  // LDS-transpose instantiation, which keeps every test.  (Accepting two plain flag arrays here as well, behind ONE
-  // uniform branch per step, measured +3.4 % on cs_step_many: 0.860 -> 0.889 us.)
-  const bool valid = DIRECT_ROWS ? true : i < n;
+  // ALL_OUT: at <= 65 536 envs (one wavefront per SIMD) the loop is bound by its INSTRUCTION COUNT, scalar ones included
+  // (profiles/r06_ab_kstep_shaping.txt), so the common call gets a form with UNCONDITIONAL outputs: the launcher picks it
+  // for whole tiles (n % 64 == 0: no ragged last wavefront) whose four output arrays are all there with the flags
+  // interleaved ([K, N, 2], what CopterVecEnv allocates) -- a step's stores then need no exec masks, no pointer tests and
+  // no branches (nine s_cbranch + a dozen scalar instructions per step in the general form).  Any other call at that size
+  // runs kRowsDirect, which keeps every test.  (Accepting two plain flag arrays in ALL_OUT as well, behind ONE uniform
+  // branch per step, measured +3.4 % on cs_step_many: 0.860 -> 0.889 us.)
+  const bool valid = ALL_OUT ? true : i < n;
   using TILE = TileIO<MODE>;
   const TILE tile(s, tile_index, lane);
 
@@ -363,10 +365,8 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
       asm volatile("" : "+v"(act_next.x), "+v"(act_next.y), "+v"(act_next.z), "+v"(act_next.w));
     }
     CS_KSTAMP(CS_KST(o), 7);  // controller hand-over / action row delivered
-    if constexpr (DIRECT_ROWS) {
-      // unconditional (see `valid` above): reward, the two flags as one 2-byte store, and the observation row straight
-      // from the lane -- at one wavefront per SIMD three row stores per lane cost fewer instructions than the LDS
-      // transpose (whose full-line stores win as soon as SIMDs hold two wavefronts)
+    if constexpr (ALL_OUT) {
+      // unconditional (see `valid` above): reward, the two flags as one 2-byte store, the observation row from the lane
       CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
       const uint16_t both = (uint16_t)((out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u));
       CS_NT_STORE(both, at32<uint16_t>(terminated_dev + 2 * row, i << 1));
@@ -378,7 +378,13 @@ __global__ __launch_bounds__(kBlock) void step_many_kernel(
         write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
       }
       CS_KSTAMP(CS_KST(o), 8);  // reward + flag stores issued
-      write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
+      if constexpr (DIRECT_ROWS) {
+        // one wavefront per SIMD: instruction issue is the limit, and three row stores per lane cost fewer
+        // instructions than the LDS transpose (whose full-line stores win as soon as SIMDs hold two wavefronts)
+        if (obs_dev != nullptr && valid) store_row_direct<OBS>(obs_dev + (row + i) * OBS, out.row);
+      } else {
+        write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
+      }
     }
     CS_KSTAMP(CS_KST(o), 9);   // observation row stores issued
     CS_KSTAMP(CS_KST(o), 14);  // (two stamps back to back: what a stamp itself costs)
@@ -822,9 +828,10 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
   const dim3 grid(grid_for(s.n)), block(kBlock);
   const bool lean = lean_config(c, s);
   const uint32_t direct_max = tune.direct_rows_max_envs ? tune.direct_rows_max_envs : kDirectRowsMaxEnvs;
-  // per-lane rows AND unconditional outputs (step_many_kernel: DIRECT_ROWS): whole tiles, all four outputs, flags interleaved
-  const bool direct = s.n <= direct_max && s.n % (uint32_t)kBlock == 0u && obs != nullptr && reward != nullptr &&
-                      term != nullptr && trunc == term + 1;
+  // per-lane rows at <= direct_max envs; with unconditional outputs for whole tiles, all four outputs, flags interleaved
+  const bool direct = s.n <= direct_max;
+  const bool direct_all = direct && s.n % (uint32_t)kBlock == 0u && obs != nullptr && reward != nullptr &&
+                          term != nullptr && trunc == term + 1;
   const PidConst pc = pid ? *pid : PidConst{};
 #define CS_MANY_N(LEAN, POLICY, ONE, DIRECT)                                                           \
   hipLaunchKernelGGL((step_many_kernel<TASK, MODE, LEAN, POLICY, ONE, DIRECT>), grid, block, 0, stream, \
@@ -836,14 +843,16 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
   do {                                                         \
     if constexpr (LEAN && is_tuned(TASK, MODE)) {              \
       if (c.nsub == 1) {                                       \
-        if (direct)                                            \
-          CS_MANY_N(LEAN, POLICY, true, true);                 \
+        if (direct_all)                                        \
+          CS_MANY_N(LEAN, POLICY, true, kRowsDirectAll);       \
+        else if (direct)                                       \
+          CS_MANY_N(LEAN, POLICY, true, kRowsDirect);          \
         else                                                   \
-          CS_MANY_N(LEAN, POLICY, true, false);                \
+          CS_MANY_N(LEAN, POLICY, true, kRowsTranspose);       \
         break;                                                 \
       }                                                        \
     }                                                          \
-    CS_MANY_N(LEAN, POLICY, false, false);                     \
+    CS_MANY_N(LEAN, POLICY, false, kRowsTranspose);            \
   } while (0)
   if (policy == kPolicyPid) {
     if constexpr (task_act_dim(TASK) == 4) {  // the heuristic reads the 3D observation
@@ -860,7 +869,12 @@ hipError_t step_many_t(const DevConst& c, const DevState& s, int num_steps, floa
       } else if (lean && is_tuned(TASK, MODE) && c.nsub == 1 && direct &&
                  (pc.terms & (kPidRateI | kPidRateD | kPidPosI | kPidPosD)) == kPidUpstreamTerms) {
         // upstream's own gains at <= 65 536 envs: the instantiation with their terms compiled in
-        if constexpr (is_tuned(TASK, MODE)) CS_MANY_N(true, kPolicyPidUpstream, true, true);
+        if constexpr (is_tuned(TASK, MODE)) {
+          if (direct_all)
+            CS_MANY_N(true, kPolicyPidUpstream, true, kRowsDirectAll);
+          else
+            CS_MANY_N(true, kPolicyPidUpstream, true, kRowsDirect);
+        }
       } else if (lean) {
         CS_MANY(true, kPolicyPid);
       } else {

@@ -83,6 +83,12 @@ inline uint32_t resolve_output_form(uint32_t form, uint32_t n, const float* obs,
   return n > 1u && pattern ? (uint32_t)CS_OUTPUT_PACKED_ROWS : (uint32_t)CS_OUTPUT_PLAIN;
 }
 
+// How the K-step kernels (step_many_kernel, the caller-policy kernel of include/copterstep_rollout.h) let a step's outputs
+// leave -- kRowsTranspose: observation rows through the LDS transpose (the form for > 65 536 envs); kRowsDirect: per-lane
+// row stores (<= 65 536 envs, one wavefront per SIMD); kRowsDirectAll: per-lane rows AND unconditional outputs (whole
+// tiles, all four output arrays present, flags interleaved: no masks, pointer tests or branches around the stores).
+enum { kRowsTranspose = 0, kRowsDirect = 1, kRowsDirectAll = 2 };
+
 // One env's observation row straight from its lane (the K-step kernels at one wavefront per SIMD, where instruction
 // issue is the limit and three stores per lane cost fewer instructions than the LDS transpose: dev_tile.h,
 // kDirectRowsMaxEnvs).  Rows are written once and never read back by the kernel: non-temporal, as every other

@@ -65,13 +65,14 @@
 namespace cs {
 namespace {
 
-template <int TASK, int MODE, bool LEAN, bool ONE_CALL, bool DIRECT_ROWS, class POLICY>
+template <int TASK, int MODE, bool LEAN, bool ONE_CALL, int ROWS, class POLICY>
 __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     char* const tiles, const uint32_t n_envs, float* const actions_dev, float* const obs_dev, float* const reward_dev,
     uint8_t* const terminated_dev, uint8_t* const truncated_dev, const int num_steps, const DevConst c_arg,
     const DevState s_rest, POLICY policy) {
   using T = typename ModeOf<MODE>::T;
   constexpr int OBS = task_obs_dim(TASK), FIRST = task_obs_first(TASK), ACT = task_act_dim(TASK);
+  constexpr bool DIRECT_ROWS = ROWS != kRowsTranspose, ALL_OUT = ROWS == kRowsDirectAll;   /* dev_task.h */
   DevConst c = c_arg;
   park_constants<MODE == CS_STATE_F64 || kFullTrigInEveryMode>(c);   // loop body: the deep constants out of the scalar registers' way
   DevState s = s_rest;
@@ -83,10 +84,10 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
   const int lane = threadIdx.x;
   const uint32_t i = tile_index * kBlock + lane;
   const uint32_t env0 = i - lane;
-  /* DIRECT_ROWS = per-lane observation rows AND unconditional outputs: cs_rollout_custom picks it only for whole tiles
+  /* ALL_OUT = per-lane observation rows AND unconditional outputs: cs_rollout_custom picks it for whole tiles
      (n % 64 == 0) with all four output arrays present and the flags interleaved ([K, N, 2]), as the library's own K-step
      kernels do (copterstep_kernels.hip: step_many_kernel) -- no exec masks, pointer tests or branches around a step's stores */
-  const bool valid = DIRECT_ROWS ? true : i < n;
+  const bool valid = ALL_OUT ? true : i < n;
   using TILE = TileIO<MODE>;
   const TILE tile(s, tile_index, lane);
 
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
     for (int j = 0; j < OBS; ++j) seen[j] = out.row[j];
     fresh = out.did_reset;
     CS_KSTAMP(CS_KST(o), 7);
-    if constexpr (DIRECT_ROWS) {  /* one wavefront per SIMD: three row stores per lane cost fewer instructions */
+    if constexpr (ALL_OUT) {
       CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
       const uint16_t both = (uint16_t)((out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u));
       CS_NT_STORE(both, at32<uint16_t>(terminated_dev + 2 * row, i << 1));
@@ -177,7 +178,11 @@ __global__ __launch_bounds__(kBlock) void rollout_custom_kernel(
         if (reward_dev) CS_NT_STORE((float)out.reward, at32<float>(reward_dev + row, i << 2));
         write_flags(terminated_dev, truncated_dev, row, i, out.term, out.trunc);
       }
-      write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
+      if constexpr (DIRECT_ROWS) {  /* one wavefront per SIMD: three row stores per lane cost fewer instructions */
+        if (obs_dev != nullptr && valid) store_row_direct<OBS>(obs_dev + (row + i) * OBS, out.row);
+      } else {
+        write_rows<OBS>(obs_dev ? obs_dev + row * OBS : nullptr, lds, lane, env0, n, valid, out.row);
+      }
     }
     CS_KSTAMP(CS_KST(o), 9);
     CS_KSTAMP(CS_KST(o), 14);
@@ -231,17 +236,20 @@ int cs_rollout_custom(cs_ctx* ctx, int num_steps, POLICY policy, float* actions_
   hipLaunchKernelGGL((cs::rollout_custom_kernel<TASK, MODE, LEAN, ONE, DIRECT, POLICY>), grid, block, 0, stream,    \
                      s.tiles, s.n, actions_out, obs_dev, reward_dev, terminated_dev, truncated_dev, num_steps, c, s, \
                      policy)
-  /* per-lane rows with unconditional outputs: whole tiles, all four outputs, flags interleaved ([K, N, 2]) */
-  const bool direct = v.direct_rows && s.n % (uint32_t)cs::kBlock == 0u && obs_dev != nullptr && reward_dev != nullptr &&
-                      terminated_dev != nullptr && truncated_dev == terminated_dev + 1;
-  if (v.lean && v.one_call && direct)
-    CS_ROLLOUT_LAUNCH(true, true, true);
+  /* per-lane rows at the sizes the library uses them; with unconditional outputs for whole tiles, all four outputs
+     present, flags interleaved ([K, N, 2]) */
+  const bool direct_all = v.direct_rows && s.n % (uint32_t)cs::kBlock == 0u && obs_dev != nullptr && reward_dev != nullptr &&
+                          terminated_dev != nullptr && truncated_dev == terminated_dev + 1;
+  if (v.lean && v.one_call && direct_all)
+    CS_ROLLOUT_LAUNCH(true, true, cs::kRowsDirectAll);
+  else if (v.lean && v.one_call && v.direct_rows)
+    CS_ROLLOUT_LAUNCH(true, true, cs::kRowsDirect);
   else if (v.lean && v.one_call)
-    CS_ROLLOUT_LAUNCH(true, true, false);
+    CS_ROLLOUT_LAUNCH(true, true, cs::kRowsTranspose);
   else if (v.lean)
-    CS_ROLLOUT_LAUNCH(true, false, false);
+    CS_ROLLOUT_LAUNCH(true, false, cs::kRowsTranspose);
   else
-    CS_ROLLOUT_LAUNCH(false, false, false);
+    CS_ROLLOUT_LAUNCH(false, false, cs::kRowsTranspose);
 #undef CS_ROLLOUT_LAUNCH
   const hipError_t launched = hipGetLastError();
   if (launched != hipSuccess) {
