@@ -46,9 +46,10 @@ DEFAULTS = (("step_kernelILi0ELi0ELb1ELb1ELb0ELb1E", "step_kernel<lander3d, floa
             ("step_kernelILi0ELi0ELb1ELb0ELb1ELb1E", "step_kernel<lander3d, ..., stream state, one call>                  >= 3.5 M envs (the 4 M point)"),
             ("step_kernelILi1ELi0ELb1ELb0ELb0ELb1E", "step_kernel<hover3d, ..., no stream hints, one call>                BASELINE configs[2]"),
             ("step_kernelILi0ELi0ELb1ELb1ELb0ELb0E", "step_kernel<lander3d, ..., stream actions, substep loop>            BASELINE configs[4]"),
-            ("step_many_kernelILi0ELi0ELb1ELi0ELb1ELb1E", "step_many_kernel<lander3d, ..., open loop, per-lane rows>          cs_step_many, <= 65 536 envs"),
-            ("step_many_kernelILi0ELi0ELb1ELi4ELb1ELb1E", "step_many_kernel<lander3d, ..., PID (upstream's terms), per-lane rows>  cs_rollout_pid"),
-            ("step_many_kernelILi0ELi0ELb1ELi2ELb1ELb1E", "step_many_kernel<lander3d, ..., random policy, per-lane rows>      cs_rollout_random"))
+            ("step_many_kernelILi0ELi0ELb1ELi0ELb1ELi2E", "step_many_kernel<lander3d, ..., open loop, per-lane rows + unconditional outputs>   cs_step_many, <= 65 536 envs"),
+            ("step_many_kernelILi0ELi0ELb1ELi4ELb1ELi2E", "step_many_kernel<lander3d, ..., PID (upstream's terms), same form>                   cs_rollout_pid"),
+            ("step_many_kernelILi0ELi0ELb1ELi2ELb1ELi2E", "step_many_kernel<lander3d, ..., random policy, same form>                             cs_rollout_random"),
+            ("step_many_kernelILi0ELi0ELb1ELi0ELb1ELi0E", "step_many_kernel<lander3d, ..., open loop, LDS transpose>                              cs_step_many, > 65 536 envs"))
 listing = R + "/gym_copter_amd/csrc/build/copterstep_kernels-hip-amdgcn-amd-amdhsa-gfx950.s"
 subprocess.run(["make", "-C", R + "/gym_copter_amd/csrc", "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 if os.path.exists(listing):
