@@ -441,6 +441,65 @@ def test_k_step_row_store_instantiations_agree(task):
         e.close()
 
 
+@pytest.mark.parametrize("task", ["lander3d", "hover3d"])
+def test_k_step_unconditional_output_form_agrees_with_the_general_forms(task):
+    """Round 6: at <= direct_rows_max_envs envs a call with whole tiles, all four outputs and interleaved flags (what the
+    wrapper passes) runs the K-step instantiation with UNCONDITIONAL outputs (no masks, pointer tests or branches around a
+    step's stores; the observation row converted after the masked reset).  Same bits as the general per-lane-row form
+    (two plain flag arrays through the C ABI) and as the LDS-transpose form (tuning), for the open loop, the random policy
+    and the PID heuristic, with reset churn; canary bytes behind every output buffer stay untouched."""
+    import ctypes as C
+    import torch
+    from gym_copter_amd import _lib
+    n, K = 4096, 24
+    rng = np.random.default_rng(14)
+    envs = []
+    for direct_max in (1 << 30, 1, 1 << 30):          # unconditional / transpose / general per-lane rows
+        e, _ = make_pair(task, n, "float32", autoreset="next_step", seed=8)
+        e.set_tuning(direct_rows_max_envs=direct_max)
+        e.configure_pid("hover" if task == "hover3d" else "lander")
+        e.reset()
+        envs.append(e)
+    dev, od = envs[0].device, envs[0].obs_dim
+    acts = torch.from_numpy(rng.uniform(-1, 1, (K, n, 4)).astype(np.float32)).to(dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    CANARY = 0x5A
+
+    def plain_call(e, leg):
+        """The same entry point through the C ABI with two PLAIN flag arrays (+ canaries behind every buffer)."""
+        obs = torch.full((K * n * od + 16,), float("nan"), device=dev)
+        rew = torch.full((K * n + 16,), float("nan"), device=dev)
+        term = torch.full((K * n + 16,), CANARY, dtype=torch.uint8, device=dev)
+        trunc = torch.full((K * n + 16,), CANARY, dtype=torch.uint8, device=dev)
+        aout = torch.empty((K, n, 4), device=dev)
+        s = e._stream()
+        with torch.cuda.device(dev):
+            if leg == "many":
+                _lib.check(e._lib.cs_step_many(e._ctx, K, p(acts), p(obs), p(rew), p(term), p(trunc), s))
+            elif leg == "random":
+                _lib.check(e._lib.cs_rollout_random(e._ctx, K, p(aout), p(obs), p(rew), p(term), p(trunc), s))
+            else:
+                _lib.check(e._lib.cs_rollout_pid(e._ctx, K, p(aout), p(obs), p(rew), p(term), p(trunc), s))
+        torch.cuda.synchronize()
+        assert torch.isnan(obs[K * n * od:]).all() and torch.isnan(rew[K * n:]).all()
+        assert (term[K * n:] == CANARY).all() and (trunc[K * n:] == CANARY).all()
+        out = [obs[:K * n * od].view(K, n, od), rew[:K * n].view(K, n), term[:K * n].view(K, n).bool(), trunc[:K * n].view(K, n).bool()]
+        return out + ([aout] if leg != "many" else [])
+
+    for leg, call in (("many", lambda e: e.step_many(acts)), ("random", lambda e: e.rollout_random(K, return_actions=True)),
+                      ("pid", lambda e: e.rollout_pid(K, return_actions=True))):
+        a, b, c = call(envs[0]), call(envs[1]), plain_call(envs[2], leg)
+        assert a[2].any(), "reset churn expected"
+        for u, v, w in zip(a, b, c):
+            assert torch.equal(u, v) and torch.equal(u, w), leg
+    states = [e.get_state() for e in envs]
+    for k in states[0]:
+        assert np.array_equal(states[0][k], states[1][k], equal_nan=True), k
+        assert np.array_equal(states[0][k], states[2][k], equal_nan=True), k
+    for e in envs:
+        e.close()
+
+
 @pytest.mark.parametrize("tuning", [dict(nt_action_max_envs=1, nt_state_min_envs=1),      # streamed state
                                     dict(nt_action_max_envs=1)])                           # plain (vs streamed actions)
 def test_stream_hint_instantiations_agree(tuning):
