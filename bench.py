@@ -38,8 +38,10 @@ resident action ring; cs_rollout_pid: closed loop under the on-device PID heuris
 never as `value`.  --full adds the rest of the sweep (other action laws, 262 144 / 1 M envs, Hover3D 1 M / 4 M, config 5
 at 1 M, the K-step kernels at 4 M), cs_rollout_random, the caller-compiled policy, the served leg and the launch floor.
 Multi-GPU: the env batch is sharded by contiguous env-id range with no data-path
-collective in the timed region ("scaling": "weak"); the optional concatenated-observation
-all-gather over RCCL (--gather) is timed separately and reported as value_with_allgather.
+collective in the timed region ("scaling": "weak").  The barriers and the MAX over ranks run on a gloo
+group; the RCCL communicator is opened only for the all-gather legs: at N > 1 one packed all-gather leg
+(eager launches, last, under a deadline: value_with_packed_allgather), with --gather all three legs
+(obs rows, packed, double-buffered half-batches; hipGraph-captured), timed separately from `value`.
 """
 import argparse
 import json
@@ -186,15 +188,18 @@ def make_actions(torch, law, ring, n, device, seed):
     return torch.full((ring, n, 4), 1.625e-2, device=device, dtype=torch.float32)
 
 
+RCCL_OPEN = [False]      # set once main() has opened the RCCL communicator (collectives())
+
+
 def quiesce_collectives(torch):
-    """Before a capture in a process with a process group: let the eager collectives finish and give
+    """Before a capture in a process whose RCCL communicator is open: let the eager collectives finish and give
     ProcessGroupNCCL's watchdog (polling period 100 ms) time to retire them, so that it has nothing to query while
-    the capture is open."""
+    the capture is open.  (The gloo control group has no such thread.)"""
+    if not RCCL_OPEN[0]:
+        return
     try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            torch.cuda.synchronize()
-            time.sleep(0.3)
+        torch.cuda.synchronize()
+        time.sleep(0.3)
     except Exception:
         pass
 
@@ -359,7 +364,11 @@ class Hip:
     current (= launch) stream, the process-group backend.  There is no CPU variant in the product: the constructor
     refuses a machine without a HIP device.  (tests/test_bench_launcher.py swaps a double in -- inside its own worker
     processes only -- to run the N > 1 line assembly under gloo at the world size of the target node.)"""
-    backend = "nccl"                       # = RCCL on ROCm
+    backend = "nccl"                       # = RCCL on ROCm: the DATA path (the all-gather legs), opened when first needed
+    control_backend = "gloo"               # barriers and the MAX over ranks of a region's wall time: CPU-side, so that no
+    #                                        ProcessGroupNCCL watchdog thread is alive while the collective-free legs capture
+    #                                        and replay hipGraphs (its event queries racing a capture aborted about one cold
+    #                                        start in fifteen with ONE rank: tests/gpu_util.py -- eight ranks would not get by)
     graphs = True                          # hipGraph capture / replay of the step launches
 
     def __init__(self, torch, local):
@@ -385,7 +394,11 @@ class Hip:
         return cus, float(getattr(props, "clock_rate", 0) or 0) * 1e3 or PEAK_ENGINE_CLOCK_HZ     # (kHz -> Hz)
 
     def init_group(self, dist):
-        dist.init_process_group(self.backend, device_id=self.device)
+        dist.init_process_group(self.control_backend)
+
+    def open_collectives(self, dist):
+        """The RCCL communicator over all ranks (a group of its own beside the gloo control plane)."""
+        return dist.new_group(backend=self.backend)
 
 
 class Timer:
@@ -412,7 +425,7 @@ class Timer:
         self.barrier()
         wall = t1 - t0
         if self.dist is not None:
-            t = torch.tensor([wall], device=self.device, dtype=torch.float64)
+            t = torch.tensor([wall], dtype=torch.float64)            # (host tensor: the control plane is gloo)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             wall = float(t.item())
         return wall, self.hip.elapsed_s(ev0, ev1)
@@ -427,7 +440,7 @@ class Timer:
             runner.run(max(quantum, warmup // quantum * quantum))
         w1, e1 = self.region(runner, steps)                       # also the calibration pass
         if self.dist is not None:                                 # every rank must pick the same R
-            t = self.torch.tensor([e1], device=self.device, dtype=self.torch.float64)
+            t = self.torch.tensor([e1], dtype=self.torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             e1 = float(t.item())
         reps = max(1, int(min_region_s / max(e1, 1e-9) + 0.999))
@@ -965,14 +978,26 @@ def main(argv=None):
                 # whatever else the box has can cost minutes; the data path is xGMI either way
                 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
                 os.environ.setdefault("NCCL_IB_DISABLE", "1")
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             hip.init_group(dist)
-        timer.barrier()      # (N > 1: the communicator is set up here, outside every timed region)
-        if dist is not None:
-            # what RCCL itself saw: an all-reduce of ones over the group (the driver can check N ranks took part)
-            ones = torch.ones(1, device=device, dtype=torch.float32)
-            dist.all_reduce(ones)
-            rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+        timer.barrier()      # (N > 1: the control group is set up here, outside every timed region)
+    coll = {"group": None}
+
+    def collectives():
+        """The RCCL communicator, opened when the first all-gather leg needs it -- after the collective-free legs have been
+        timed -- and what RCCL itself saw: an all-reduce of ones over it (the driver can check N ranks took part)."""
+        nonlocal rccl
+        if coll["group"] is None:
+            with stdout_to_stderr():
+                g = hip.open_collectives(dist)
+                ones = torch.ones(1, device=device, dtype=torch.float32)
+                dist.all_reduce(ones, group=g)
+                hip.synchronize()
+            coll["group"] = g
+            RCCL_OPEN[0] = True
+            rccl = {"backend": dist.get_backend(g), "world_size": dist.get_world_size(g),
                     "ranks_seen": int(round(float(ones.item())))}
+        return coll["group"]
 
     import gym_copter_amd as gca
     n = a.envs
@@ -1133,17 +1158,19 @@ def main(argv=None):
     # still ONE packed all-gather leg, so that the multi-GPU line shows value_with_packed_allgather beside the
     # collective-free value -- run LAST and under a deadline (below): the N > 1 collective path has only ever run on
     # one GPU and under gloo, and a leg that hangs must not cost the line
-    def run_gather_legs(gather_legs):
+    def run_gather_legs(gather_legs, graph=None):
         from gym_copter_amd.sharded import ShardGather, PackedOutputs
-        gather = ShardGather(n, world)           # the product's RCCL all-gather of the obs rows
+        grp = collectives()
+        graph = use_graph if graph is None else (graph and use_graph)
+        gather = ShardGather(n, world, group=grp)           # the product's RCCL all-gather of the obs rows
 
         def gather_leg(post, bind=None):
-            """step + collective per step, hipGraph-captured like the headline when RCCL allows it."""
+            """step + collective per step, hipGraph-captured like the headline when asked to and RCCL allows it."""
             if bind is not None:
                 bind()
-            mode = "graph" if use_graph else "eager"
+            mode = "graph" if graph else "eager"
             try:
-                st = Stepper(torch, env, actions, use_graph, chunk, post=post)
+                st = Stepper(torch, env, actions, graph, chunk, post=post)
             except Exception as e:      # capture of the collective refused: time it eagerly instead
                 torch.cuda.synchronize()
                 mode = "eager (capture failed: %s)" % type(e).__name__
@@ -1161,7 +1188,7 @@ def main(argv=None):
             extra["ms_per_step_with_allgather"] = g2["s_per_step"] * 1e3
         # everything a global learner needs (obs, reward, both flags) in ONE all-gather: the kernel
         # writes its outputs straight into the packed per-rank buffer
-        pk = PackedOutputs(n, env.obs_dim, world, device)
+        pk = PackedOutputs(n, env.obs_dim, world, device, group=grp)
         g3, modes["packed"] = gather_leg(pk.all_gather, bind=lambda: env.bind_outputs(pk.obs, pk.reward, pk.term, pk.trunc))
         extra["value_with_packed_allgather"] = total_envs / g3["s_per_step"]
         extra["ms_per_step_with_packed_allgather"] = g3["s_per_step"] * 1e3
@@ -1170,12 +1197,12 @@ def main(argv=None):
             # double-buffered half-batches: each half's step + packed all-gather on its own
             # stream, so one half's collective is on the links while the other half steps
             from gym_copter_amd.sharded import HalfBatchPipeline
-            pipe = HalfBatchPipeline(task=a.task, total_envs=total_envs, gather="all", device=local, seed=1234,
+            pipe = HalfBatchPipeline(task=a.task, total_envs=total_envs, gather="all", group=grp, device=local, seed=1234,
                                      autoreset_mode="next_step", state_dtype=a.state, substeps=a.substeps)
             pipe.reset()
-            mode4 = "graph" if use_graph else "eager"
+            mode4 = "graph" if graph else "eager"
             try:
-                pr = PipeStepper(torch, pipe, actions, device, use_graph, chunk)
+                pr = PipeStepper(torch, pipe, actions, device, graph, chunk)
             except Exception as e:
                 torch.cuda.synchronize()
                 mode4 = "eager (capture failed: %s)" % type(e).__name__
@@ -1379,10 +1406,13 @@ struct Policy {
         dog.daemon = True
         dog.start()
         try:
+            collectives()
             if os.environ.get("BENCH_TEST_HANG_GATHER") == "1":      # diagnostic: what a leg that never returns does to the line
                 while True:
                     time.sleep(1.0)
-            run_gather_legs(("packed",))
+            # EAGER launches: step + all-gather per step as a learner's loop issues them -- capturing a collective of N
+            # ranks into a hipGraph is the one thing here that has never run on N > 1 devices (--gather captures them)
+            run_gather_legs(("packed",), graph=False)
         except Exception as e:
             extra["value_with_packed_allgather"] = None
             extra["packed_allgather_note"] = "failed: %r" % (e,)

@@ -36,7 +36,10 @@ class CpuRuntime(bench.Hip):
         return 256, bench.PEAK_ENGINE_CLOCK_HZ
 
     def init_group(self, dist):
-        dist.init_process_group(self.backend)
+        dist.init_process_group(self.control_backend)
+
+    def open_collectives(self, dist):
+        return dist.new_group(backend=self.backend)
 
 
 class EnvDouble:
