@@ -49,6 +49,7 @@ class EnvDouble:
     def __init__(self, task="lander3d", num_envs=1, device=None, env_id_base=0, **_):
         import torch
         self.n, self.base, self.device = num_envs, env_id_base, torch.device("cpu")
+        self.single_observation_space = self.single_action_space = None      # (read, not used, by ShardedCopterVecEnv)
         self.bind_outputs(torch.empty((num_envs, self.obs_dim)), torch.empty(num_envs),
                           torch.empty(num_envs, dtype=torch.uint8), torch.empty(num_envs, dtype=torch.uint8))
         self.steps = 0
@@ -94,4 +95,5 @@ if __name__ == "__main__":
     import gym_copter_amd
     bench.Hip = CpuRuntime
     gym_copter_amd.CopterVecEnv = EnvDouble
+    gym_copter_amd.vecenv.CopterVecEnv = EnvDouble       # (what gym_copter_amd.sharded instantiates: the --gather legs)
     bench.main(sys.argv[1:])

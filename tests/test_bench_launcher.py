@@ -236,6 +236,24 @@ def test_n_rank_line_assembly_under_gloo(tmp_path, world):
     assert full["packed_allgather_bytes_per_rank"] == 1024 * 12 * 4 and full["rccl"] == d["rccl"]
 
 
+def test_n_rank_gather_flag_runs_all_three_collective_legs_on_the_collective_group(tmp_path):
+    """--gather at world 2: the observation all-gather, the packed all-gather and the double-buffered half-batch pipeline
+    each run on the group bench.py opens for collectives (beside its gloo control plane), and are reported beside
+    `value`, never as it."""
+    import json
+    p = _run_ranks(2, tmp_path, extra_args=("--gather", "--pid", "0", "--many", "0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= bench.LINE_BUDGET
+    d = json.loads(lines[0])
+    full = json.load(open(tmp_path / "full.json"))
+    assert d["rccl"] == {"backend": "gloo", "world_size": 2, "ranks_seen": 2}
+    assert set(full["allgather_launch_mode"]) == {"obs", "packed", "pipelined"}
+    for k in ("value_with_allgather", "value_with_packed_allgather", "value_with_pipelined_allgather"):
+        assert 0 < full[k] <= full["value"] * 1.05, k
+    assert d["value"] == full["value"] and d["value_with_packed_allgather"] == full["value_with_packed_allgather"]
+
+
 def test_n_rank_gather_leg_that_never_returns_degrades_the_line(tmp_path):
     """The default N > 1 packed all-gather leg under its deadline, 8 ranks: when it does not come back, rank 0 still
     prints the ONE compact line -- without the leg, "status": "degraded" -- and every rank leaves with a non-zero code."""
