@@ -70,7 +70,7 @@ INFINITY_CACHE_BYTES = 256 << 20                    # MI355X_MICROARCH.md: 256 M
 # The ONE stdout line is for a reader with a bounded buffer (the driver keeps ~8 KB of a run's stdout): contract keys,
 # roofline, cpu_baseline and a short summary only.  Everything else goes to the full record (--full-out) and stderr.
 LINE_BUDGET = 8000
-DEGRADED_EXIT = 3                                   # exit code when the N > 1 gather leg hit its deadline ("status": "degraded")
+DEGRADED_EXIT = 3                                   # exit code when the N > 1 gather leg hit its deadline or failed ("status": "degraded")
 SUMMARY_BUDGET = 1500
 
 def parse(argv=None):
@@ -967,6 +967,14 @@ def main(argv=None):
             # world 1: gym_copter_amd.sharded would shortcut the all-gathers to a return / a device copy;
             # the legs below are there to exercise RCCL, so ask for the collective
             os.environ.setdefault("COPTERSTEP_FORCE_COLLECTIVE", "1")
+    # more ranks than devices on this node (a test of the N > 1 path on the hardware there is): the ranks share the
+    # devices round-robin -- the collective-free legs and the gloo control plane work; RCCL refuses two ranks on one
+    # device, so the all-gather leg reports its failure ("status": "degraded") instead of a figure
+    ndev = max(1, int(torch.cuda.device_count()))
+    if local >= ndev:
+        print("bench.py: rank %d: LOCAL_RANK %d on a node with %d device(s): sharing device %d" % (rank, local, ndev, local % ndev),
+              file=sys.stderr, flush=True)
+        local = local % ndev
     hip = Hip(torch, local)
     device = hip.device
     timer = Timer(hip, dist)
@@ -1037,7 +1045,7 @@ def main(argv=None):
     value = total_envs / m["s_per_step"]
 
     extra = {}
-    state = {"deadline_hit": False}      # (set by the deadline of the default N > 1 gather leg)
+    state = {"deadline_hit": False}      # (set when the default N > 1 gather leg hits its deadline or fails: "status": "degraded")
 
     def assemble():
         """The ONE JSON line from what has been measured so far (also called by the deadline of the default N > 1
@@ -1413,9 +1421,10 @@ struct Policy {
             # EAGER launches: step + all-gather per step as a learner's loop issues them -- capturing a collective of N
             # ranks into a hipGraph is the one thing here that has never run on N > 1 devices (--gather captures them)
             run_gather_legs(("packed",), graph=False)
-        except Exception as e:
+        except Exception as e:      # the leg failed: the line says so and the exit code too (after the line is out)
             extra["value_with_packed_allgather"] = None
-            extra["packed_allgather_note"] = "failed: %r" % (e,)
+            extra["packed_allgather_note"] = ("failed: %r" % (e,))[:300]
+            state["deadline_hit"] = True
         dog.cancel()
     env.close()
     del stepper, env, actions
@@ -1609,7 +1618,7 @@ struct Policy {
     if dist is not None:
         hip.synchronize()
         profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
-        if launched or profiled:
+        if (launched or profiled) and not state["deadline_hit"]:     # (a communicator that failed is not torn down: leave)
             dist.destroy_process_group()
         if not profiled:               # (a profiler writes its files from exit handlers: leave normally under one)
             # leave without running the interpreter's shutdown: hipGraphs that captured collectives are still alive, and
@@ -1618,7 +1627,9 @@ struct Policy {
             # child) -- after the line is out, which a launcher would report as a failed rank.  The line is written,
             # the group is closed (launched runs), nothing is left to flush
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(DEGRADED_EXIT if state["deadline_hit"] else 0)
+    if state["deadline_hit"]:
+        sys.exit(DEGRADED_EXIT)
 
 
 if __name__ == "__main__":

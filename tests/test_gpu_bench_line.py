@@ -218,3 +218,36 @@ def test_default_bench_line_is_compact_and_on_a_diet(tmp_path):
     for k in ("rollout_random", "rollout_policy_linear", "served_producers_ahead", "rollout_custom", "dependent_launch_floor"):
         assert k not in d, k
     assert wall < 90, wall        # (incl. a cold `import torch`; the driver saw 30.6 s for round 5's default run)
+
+
+def test_two_ranks_sharing_the_one_gpu_run_the_n_rank_path_on_real_kernels(tmp_path):
+    """The driver's N > 1 command shape with TWO ranks on the ONE device there is (round 6: the control plane is gloo, so
+    the collective-free legs do not need RCCL; ranks beyond the node's devices share them round-robin).  Both ranks step
+    their own shard (env ids keyed by rank), the barrier / MAX-over-ranks timing runs, rank 0 alone prints the compact
+    line with n_gpus = 2 -- and the packed all-gather leg, which RCCL refuses on a shared device ("Duplicate GPU"),
+    degrades the line instead of costing it: status "degraded", no figure, the ranks exit with code 3."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--envs", "16384", "--min-region-ms", "5", "--regions", "3", "--full-out", str(tmp_path / "full.json")]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_GATHER_DEADLINE_S="60")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, (p.returncode, p.stdout[-1500:], p.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert len(lines[0]) <= 8000 and d["n_gpus"] == 2 and d["config"]["total_envs"] == 32768
+    assert d["config"]["parallelism"] == "env-shard x2" and d["scaling"] == "weak"
+    assert abs(d["value"] - 32768 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["value"] > 1e9
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 176 * 16384 and "cpu_baseline" not in d
+    assert set(d["summary"]["k_step_us"]) == {"step_many", "rollout_pid"}
+    assert "sharing device 0" in p.stderr
+    if d["status"] == "degraded":          # RCCL refused the shared device (what ROCm 7's RCCL does)
+        assert p.returncode != 0 and "exitcode  : 3" in p.stderr.replace("exitcode:", "exitcode  :")      # (torchrun reports its ranks' code)
+        assert d["value_with_packed_allgather"] is None
+        assert "failed" in d["packed_allgather_note"] or "deadline" in d["packed_allgather_note"]
+    else:                                   # a library that accepts it: the leg ran
+        assert p.returncode == 0 and d["value_with_packed_allgather"] > 0 and d["rccl"]["ranks_seen"] == 2
