@@ -266,3 +266,16 @@ def test_n_rank_gather_leg_that_never_returns_degrades_the_line(tmp_path):
     assert d["status"] == "degraded" and d["value"] > 0 and d["value_with_packed_allgather"] is None
     assert "deadline" in d["packed_allgather_note"] and d["rccl"]["ranks_seen"] == 8
     assert "status degraded" in p.stderr
+
+
+def test_committed_pmc_figures_are_stamped_with_this_trees_kernel_sources():
+    """bench.py reports `roofline.traffic` and the issue bounds only while profiles/traffic.json / pmc_counts.json carry
+    the hash of the kernel sources they were measured on: a kernel edit without a new profiling run (scripts/profile_gpu.sh
+    -> scripts/collect_profiles.py) would silently turn them into null in the driver's line.  This makes it loud."""
+    import json
+    here = bench.kernel_source_hash()
+    for name in ("traffic.json", "pmc_counts.json"):
+        stamp = json.load(open(os.path.join(ROOT, "profiles", name)))["kernel_source_sha16"]
+        assert stamp == here, "%s was measured on kernel sources %s, the tree has %s: re-run the profile" % (name, stamp, here)
+    d, why = bench.load_stamped("pmc_counts.json")
+    assert d is not None and d["valu_per_wavefront_step"]["step_many"] > 100, why
