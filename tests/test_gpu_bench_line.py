@@ -1,18 +1,13 @@
 """-m gpu: bench.py as the driver runs it: ONE compact stdout line (<= 8 000 bytes) with the contract keys, roofline and
 cpu_baseline, the full record beside it, the default legs, the --full blocks, the gather legs and the N > 1 deadline."""
-import ctypes as C
 import json
 import os
-import re
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 
-from conftest import load_cases
-from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu,
-                      make_pair, reward_limit, scaled_err, step_both, to_np)
+from gpu_util import have_gpu
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 

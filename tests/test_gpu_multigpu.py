@@ -1,19 +1,14 @@
 """-m gpu: the N > 1 code on the one GPU there is: shard invariance at BASELINE config 4's size, the sharded env in a
 spawned nccl (= RCCL) process group of one rank, a real (forced) RCCL collective eager and hipGraph-captured, cs_allgather from
 the C++ host.  World sizes 2 / 4 / 8 run under gloo on CPU: tests/test_sharded_gloo.py, tests/test_bench_launcher.py."""
-import ctypes as C
-import json
 import os
-import re
 import subprocess
 import sys
 
 import numpy as np
 import pytest
 
-from conftest import load_cases
-from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu,
-                      make_pair, reward_limit, scaled_err, step_both, to_np)
+from gpu_util import have_gpu, make_pair
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 

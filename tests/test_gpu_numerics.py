@@ -2,19 +2,14 @@
 BASELINE's sizes and in randomised configurations -- storage modes and the stored-word codec, substeps, auto-reset modes,
 ticks, counters, statistics, per-env vehicles, variants, perturbations, the NaN / inf guard, checkpoint round trips --
 and size-independent properties (mirror symmetry, position invariance, neighbour independence)."""
-import ctypes as C
-import json
 import os
-import re
-import subprocess
-import sys
 
 import numpy as np
 import pytest
 
 from conftest import load_cases
-from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu,
-                      make_pair, reward_limit, scaled_err, step_both, to_np)
+from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu, make_pair,
+                      scaled_err, step_both, to_np)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 

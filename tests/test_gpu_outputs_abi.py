@@ -2,18 +2,14 @@
 canary-guarded buffers, NumPy / DLPack / __cuda_array_interface__ actions, pickling, the C++ host on the C ABI, the ctypes stub
 printed in INTEGRATION.md, diagnostics (cs_clock_probe, cs_device_pci_address)."""
 import ctypes as C
-import json
 import os
 import re
 import subprocess
-import sys
 
 import numpy as np
 import pytest
 
-from conftest import load_cases
-from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu,
-                      make_pair, reward_limit, scaled_err, step_both, to_np)
+from gpu_util import (have_gpu, make_pair, to_np)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 

@@ -1,18 +1,12 @@
 """-m gpu: served stepping (cs_serve_*): a persistent env kernel fed through device memory -- bit-identical to cs_step,
 closed loop against cs_rollout_pid, time-outs, early stops, draining, hipGraph-replayed feeders, the stop-word race."""
-import ctypes as C
-import json
 import os
-import re
 import subprocess
-import sys
 
 import numpy as np
 import pytest
 
-from conftest import load_cases
-from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu,
-                      make_pair, reward_limit, scaled_err, step_both, to_np)
+from gpu_util import (MODE_TOL, assert_step_close, have_gpu, make_pair, to_np)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 

@@ -2,18 +2,14 @@
 replay, K steps per launch (cs_step_many, cs_rollout_pid, cs_rollout_random), the stream-hint and row-store instantiations,
 the caller's own policy fused into the K-step kernel (C++ header and compile_policy), two contexts on two threads."""
 import ctypes as C
-import json
 import os
-import re
 import subprocess
-import sys
 
 import numpy as np
 import pytest
 
-from conftest import load_cases
-from gpu_util import (AUTORESET, MODE_TOL, VecOracle, assert_state_close, assert_step_close, have_gpu,
-                      make_pair, reward_limit, scaled_err, step_both, to_np)
+from gpu_util import (MODE_TOL, assert_state_close, assert_step_close, have_gpu, make_pair, reward_limit, scaled_err,
+                      to_np)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_gpu(), reason="needs a HIP device")]
 
