@@ -394,7 +394,10 @@ class Hip:
         return cus, float(getattr(props, "clock_rate", 0) or 0) * 1e3 or PEAK_ENGINE_CLOCK_HZ     # (kHz -> Hz)
 
     def init_group(self, dist):
-        dist.init_process_group(self.control_backend)
+        # (a rank that dies outside the guarded gather leg must not leave the others at a barrier for the default 30 minutes)
+        import datetime
+        dist.init_process_group(self.control_backend,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("BENCH_CONTROL_TIMEOUT_S", 600))))
 
     def open_collectives(self, dist):
         """The RCCL communicator over all ranks (a group of its own beside the gloo control plane)."""

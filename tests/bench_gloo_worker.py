@@ -36,7 +36,7 @@ class CpuRuntime(bench.Hip):
         return 256, bench.PEAK_ENGINE_CLOCK_HZ
 
     def init_group(self, dist):
-        dist.init_process_group(self.control_backend)
+        bench.Hip.init_group(self, dist)          # (bench.py's own: the gloo control group with its timeout)
 
     def open_collectives(self, dist):
         return dist.new_group(backend=self.backend)
