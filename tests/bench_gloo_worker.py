@@ -14,7 +14,10 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-class CpuRuntime(bench.Hip):
+RealHip = bench.Hip
+
+
+class CpuRuntime(RealHip):
     backend = "gloo"
     graphs = False
 
@@ -36,7 +39,7 @@ class CpuRuntime(bench.Hip):
         return 256, bench.PEAK_ENGINE_CLOCK_HZ
 
     def init_group(self, dist):
-        bench.Hip.init_group(self, dist)          # (bench.py's own: the gloo control group with its timeout)
+        RealHip.init_group(self, dist)          # (bench.py's own: the gloo control group with its timeout)
 
     def open_collectives(self, dist):
         return dist.new_group(backend=self.backend)
