@@ -872,6 +872,8 @@ def compact_line(full, full_path=None, budget=LINE_BUDGET, summary_budget=SUMMAR
             c["all_cores"] = _short(pick(cb["all_cores"], "value", "cores"))
         if isinstance(cb.get("vectorised_numpy"), dict):
             c["vectorised_numpy"] = _short(pick(cb["vectorised_numpy"], "value"))
+        if isinstance(cb.get("one_core_other_law"), dict):      # both action laws on one core
+            c["one_core_other_law"] = _short(pick(cb["one_core_other_law"], "actions", "value"))
         line["cpu_baseline"] = c
     if full.get("rccl") is not None:
         line["rccl"] = full["rccl"]
