@@ -212,7 +212,7 @@ def test_default_bench_line_is_compact_and_on_a_diet(tmp_path):
     assert d["config5"]["envs"] == 65536 and d["config5"]["substeps"] == 10
     for k in ("rollout_random", "rollout_policy_linear", "served_producers_ahead", "rollout_custom", "dependent_launch_floor"):
         assert k not in d, k
-XX
+    assert wall < 180, wall       # (16 s on a warm box; a cold `import torch` in the children can add a minute)
 
 
 def test_two_ranks_sharing_the_one_gpu_run_the_n_rank_path_on_real_kernels(tmp_path):
