@@ -257,11 +257,12 @@ bool capturing(hipStream_t s) {
 // "Packed rows" (include/copterstep.h, cs_step_io) are written by cs_step / cs_step_ex only: the
 // same pointer pattern handed to an entry point whose kernel writes plain arrays would make those arrays overlap.
 int refuse_packed_rows(const cs_ctx* ctx, const char* who, const float* obs, const float* reward, const uint8_t* term,
-                       const uint8_t* trunc) {
+                       const uint8_t* trunc, int64_t num_steps = 1) {
   const int od = cs::task_obs_dim(ctx->cfg.task);
-  // (one env: the pattern is what adjacent fields of a caller's struct look like, and one env's plain arrays cannot
-  // overlap -- the n > 1 rule of CS_OUTPUT_AUTO, include/copterstep.h)
-  if (ctx->cfg.num_envs > 1 && obs != nullptr && reward == obs + od && term == reinterpret_cast<const uint8_t*>(obs + od + 1) && trunc == term + 1)
+  // (ONE row in all -- one env, one step: the pattern is what adjacent fields of a caller's struct look like, and plain
+  // arrays of one element each cannot overlap -- the n > 1 rule of CS_OUTPUT_AUTO, include/copterstep.h.  One env over
+  // K > 1 steps DOES overlap: step 1's observation row would start where step 0's reward is.)
+  if (ctx->cfg.num_envs * num_steps > 1 && obs != nullptr && reward == obs + od && term == reinterpret_cast<const uint8_t*>(obs + od + 1) && trunc == term + 1)
     return fail(CS_ERR_ARG, std::string(who) + ": the outputs are the columns of one packed [N, obs_dim + 2] array; that "
                                                "form is written by cs_step / cs_step_ex only -- pass separate arrays here");
   return CS_OK;
@@ -611,7 +612,7 @@ int cs_step_many(cs_ctx* ctx, int32_t num_steps, const float* actions_dev, float
   if (int rc_ = check_idle(ctx, "cs_step_many", stream, true)) return rc_;
   if (actions_dev == nullptr) return fail(CS_ERR_ARG, "cs_step_many: actions_dev is required");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_step_many: num_steps must be >= 1");
-  if (int rc_ = refuse_packed_rows(ctx, "cs_step_many", obs_dev, reward_dev, terminated_dev, truncated_dev)) return rc_;
+  if (int rc_ = refuse_packed_rows(ctx, "cs_step_many", obs_dev, reward_dev, terminated_dev, truncated_dev, num_steps)) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       const_cast<float*>(actions_dev), obs_dev, reward_dev,
@@ -791,7 +792,7 @@ int cs_rollout_pid(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, float
   if (cs::task_act_dim(ctx->cfg.task) != 4)
     return fail(CS_ERR_ARG, "cs_rollout_pid: the heuristic flies the 3D tasks only");
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_pid: num_steps must be >= 1");
-  if (int rc_ = refuse_packed_rows(ctx, "cs_rollout_pid", obs_dev, reward_dev, terminated_dev, truncated_dev)) return rc_;
+  if (int rc_ = refuse_packed_rows(ctx, "cs_rollout_pid", obs_dev, reward_dev, terminated_dev, truncated_dev, num_steps)) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,
@@ -806,7 +807,7 @@ int cs_rollout_random(cs_ctx* ctx, int32_t num_steps, float* actions_out_dev, fl
                       void* stream) {
   if (int rc_ = check_idle(ctx, "cs_rollout_random", stream, true)) return rc_;
   if (num_steps < 1) return fail(CS_ERR_ARG, "cs_rollout_random: num_steps must be >= 1");
-  if (int rc_ = refuse_packed_rows(ctx, "cs_rollout_random", obs_dev, reward_dev, terminated_dev, truncated_dev)) return rc_;
+  if (int rc_ = refuse_packed_rows(ctx, "cs_rollout_random", obs_dev, reward_dev, terminated_dev, truncated_dev, num_steps)) return rc_;
   const cs::DevConst& c = constants(ctx);
   hipError_t e = cs::launch_step_many(ctx->cfg.task, ctx->cfg.state_mode, c, ctx->st, num_steps,
                                       actions_out_dev, obs_dev, reward_dev, terminated_dev,

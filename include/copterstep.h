@@ -193,7 +193,8 @@ typedef struct cs_step_io {
                                 footprint: a packed row ENDS with a 4-byte flags word, two bytes past truncated_dev[i].
                                 With output_form = CS_OUTPUT_AUTO the pattern is recognised for num_envs > 1 only (see
                                 output_form).  The K-step, rollout and cs_serve_collect entry points refuse that pattern
-                                (CS_ERR_ARG). */
+                                (CS_ERR_ARG) unless the call writes ONE row in all (one env, one step: a caller's struct
+                                again, written as plain arrays). */
   float* final_obs_dev;      /* [N,obs_dim]; SAME_STEP only: pre-reset observation of
                                 envs that finished this step (other rows untouched) */
   /* done-mask compaction (wave ballot): ids of the envs that finished this step,

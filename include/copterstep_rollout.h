@@ -224,7 +224,7 @@ int cs_rollout_custom(cs_ctx* ctx, int num_steps, POLICY policy, float* actions_
     cs_set_last_error("cs_rollout_custom: num_steps < 1");
     return CS_ERR_ARG;
   }
-  if (obs_dev != nullptr && reward_dev == obs_dev + cs::task_obs_dim(TASK) &&
+  if (v.num_envs * num_steps > 1 && obs_dev != nullptr && reward_dev == obs_dev + cs::task_obs_dim(TASK) &&
       terminated_dev == reinterpret_cast<uint8_t*>(obs_dev + cs::task_obs_dim(TASK) + 1) && truncated_dev == terminated_dev + 1) {
     cs_set_last_error("cs_rollout_custom: packed rows (copterstep.h, cs_step_io) are written by cs_step only: pass separate arrays");
     return CS_ERR_ARG;

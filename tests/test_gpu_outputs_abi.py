@@ -433,6 +433,16 @@ def test_one_envs_adjacent_outputs_are_not_taken_for_a_packed_row():
     assert lib.cs_step_ex(env._ctx, C.byref(io), env._stream()) == _lib.ERR_ARG
     io.output_form, io.reserved_ = _lib.OUTPUT_AUTO, 1
     assert lib.cs_step_ex(env._ctx, C.byref(io), env._stream()) == _lib.ERR_ARG
+    # the K-step entry points: ONE row in all (one env, one step) is the struct again and is written as plain arrays;
+    # one env over K > 1 steps with this pattern would put step 1's observation over step 0's reward -- refused
+    buf.fill_(0xA5)
+    _lib.check(lib.cs_step_many(env._ctx, 1, C.c_void_p(act.data_ptr()), obs_p, rew_p, term_p, trunc_p, env._stream()))
+    torch.cuda.synchronize()
+    h = buf.cpu().numpy()
+    assert h[f] in (0, 1) and h[f + 1] in (0, 1) and np.all(h[f + 2:] == 0xA5)
+    act2 = torch.full((2, 1, 4), 0.0166, device=env.device)
+    rc = lib.cs_step_many(env._ctx, 2, C.c_void_p(act2.data_ptr()), obs_p, rew_p, term_p, trunc_p, env._stream())
+    assert rc == _lib.ERR_ARG and b"packed" in lib.cs_last_error()
     env.close()
 
 
