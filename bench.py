@@ -1445,8 +1445,11 @@ struct Policy {
                   ("lander3d", 1048576, "uniform", 8),
                   ("hover3d", 1048576, "uniform", 8), ("lander3d", 4194304, "uniform", 4),
                   ("hover3d", 4194304, "uniform", 4)]
-        if not a.full:       # the default run: BASELINE configs[2] and the HBM-resident point of the headline's kernel
-            points = [("hover3d", 262144, "uniform", 16), ("lander3d", 4194304, "uniform", 4)]
+        if not a.full:       # the default run: BASELINE configs[2], the headline's low-churn variant (SURVEY section 8(d) C2:
+            # near-hover actions, episodes that do not finish -- under uniform actions one lasts 7.8 steps and every
+            # wavefront resets lanes in every step) and the HBM-resident point of the headline's kernel
+            points = [("hover3d", 262144, "uniform", 16), ("lander3d", 65536, "near_hover", 64),
+                      ("lander3d", 4194304, "uniform", 4)]
         tile_bytes = 5632 if a.state != "float64" else 10752     # copterstep_internal.h: make_layout (4 groups + FE + RET + EPH)
 
         def resident(task, nn, ring):
