@@ -42,6 +42,8 @@ collective in the timed region ("scaling": "weak").  The barriers and the MAX ov
 group; the RCCL communicator is opened only for the all-gather legs: at N > 1 one packed all-gather leg
 (eager launches, last, under a deadline: value_with_packed_allgather), with --gather all three legs
 (obs rows, packed, double-buffered half-batches; hipGraph-captured), timed separately from `value`.
+north_star's other action law (lander.py's constant thrust) is a sweep point at N = 1 and, at N > 1, its own leg
+on the same shards, timed like the headline: value_constant_thrust.
 """
 import argparse
 import json
@@ -878,6 +880,9 @@ def compact_line(full, full_path=None, budget=LINE_BUDGET, summary_budget=SUMMAR
     if full.get("rccl") is not None:
         line["rccl"] = full["rccl"]
     line.update(pick(full, "value_with_packed_allgather", "ms_per_step_with_packed_allgather", "packed_allgather_note"))
+    line.update(_short(pick(full, "value_constant_thrust", "ms_per_step_constant_thrust", "constant_thrust_note"), 9))
+    if "value_constant_thrust" in full and full["value_constant_thrust"] is None:
+        line["value_constant_thrust"] = None
     if "value_with_packed_allgather" in full and full["value_with_packed_allgather"] is None:
         line["value_with_packed_allgather"] = None
     if full_path:
@@ -1392,6 +1397,18 @@ struct Policy {
     if a.full and a.pid > 0 and world == 1 and not any(k.startswith("ROCPROF") for k in os.environ) \
             and "rocprof" not in os.environ.get("LD_PRELOAD", ""):
         fused_policy_leg()
+    if world > 1 and not a.no_sweep:
+        # north_star: "constant-thrust and random-action workloads at 1, 2, 4 and 8 GPUs" -- at N = 1 the constant-thrust
+        # point is in the sweep; at N > 1 it is this leg: the same shards under lander.py's MOTORVAL, timed like the
+        # headline (barrier + synchronize, MAX over ranks).  Before the all-gather leg, which may end the run.
+        try:
+            gc_ = run_config(torch, timer, gca, a, a.task, n, "const", a.substeps, device, rank, 100, 100, a.ring,
+                             min_region_s, 3, use_graph=use_graph)
+            extra["value_constant_thrust"] = total_envs / gc_["s_per_step"]
+            extra["ms_per_step_constant_thrust"] = gc_["s_per_step"] * 1e3
+        except Exception as e:              # an extra never costs the headline
+            extra["value_constant_thrust"] = None
+            extra["constant_thrust_note"] = ("failed: %r" % (e,))[:300]
     if (world > 1 or a.default_gather_leg) and dist is not None and not a.gather:
         import threading
 
@@ -1445,11 +1462,12 @@ struct Policy {
                   ("lander3d", 1048576, "uniform", 8),
                   ("hover3d", 1048576, "uniform", 8), ("lander3d", 4194304, "uniform", 4),
                   ("hover3d", 4194304, "uniform", 4)]
-        if not a.full:       # the default run: BASELINE configs[2], the headline's low-churn variant (SURVEY section 8(d) C2:
+        if not a.full:       # the default run: BASELINE configs[2], north_star's other action law at the headline size (lander.py's
+            # constant thrust), the headline's low-churn variant (SURVEY section 8(d) C2:
             # near-hover actions, episodes that do not finish -- under uniform actions one lasts 7.8 steps and every
             # wavefront resets lanes in every step) and the HBM-resident point of the headline's kernel
-            points = [("hover3d", 262144, "uniform", 16), ("lander3d", 65536, "near_hover", 64),
-                      ("lander3d", 4194304, "uniform", 4)]
+            points = [("hover3d", 262144, "uniform", 16), ("lander3d", 65536, "const", 64),
+                      ("lander3d", 65536, "near_hover", 64), ("lander3d", 4194304, "uniform", 4)]
         tile_bytes = 5632 if a.state != "float64" else 10752     # copterstep_internal.h: make_layout (4 groups + FE + RET + EPH)
 
         def resident(task, nn, ring):

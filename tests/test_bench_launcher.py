@@ -230,6 +230,9 @@ def test_n_rank_line_assembly_under_gloo(tmp_path, world):
     assert d["config"]["total_envs"] == 1024 * world and d["config"]["parallelism"] == "env-shard x%d" % world
     assert abs(d["value"] - 1024 * world / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert 0 < d["value_with_packed_allgather"] <= d["value"] * 1.05
+    # north_star's other action law (constant thrust) on the same shards, timed like the headline, on every rank
+    assert d["value_constant_thrust"] > 0
+    assert abs(d["value_constant_thrust"] - 1024 * world / (d["ms_per_step_constant_thrust"] * 1e-3)) <= 1e-6 * d["value_constant_thrust"]
     assert "cpu_baseline" not in d                              # rank 0 at N = 1 only
     full = json.load(open(tmp_path / "full.json"))
     assert full["allgather_launch_mode"] == {"packed": "eager"} and full["allgather_is_a_collective"] is True

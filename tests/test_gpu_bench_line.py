@@ -205,12 +205,14 @@ def test_default_bench_line_is_compact_and_on_a_diet(tmp_path):
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and 1e3 < cb["value"] < 1e6 and "refcpu" in cb["sample"]
     sm = line["summary"]
-    assert set(sm["sweep_frac"]) == {"hover3d_262144_uniform", "lander3d_65536_near_hover", "lander3d_4194304_uniform"}
+    assert set(sm["sweep_frac"]) == {"hover3d_262144_uniform", "lander3d_65536_const", "lander3d_65536_near_hover",
+                                     "lander3d_4194304_uniform"}
     # (the low-churn variant of the headline -- episodes that do not finish -- is not slower than the headline)
     assert sm["sweep_frac"]["lander3d_65536_near_hover"] > 0.97 * rf["frac"]
     assert set(sm["k_step_us"]) == {"step_many", "rollout_pid"} and len(sm["config5"]) == 3
     sweep = {(e["task"], e["envs"], e["actions"]) for e in d["sweep"]}
-    assert sweep == {("hover3d", 262144, "uniform"), ("lander3d", 65536, "near_hover"), ("lander3d", 4194304, "uniform")}
+    assert sweep == {("hover3d", 262144, "uniform"), ("lander3d", 65536, "const"), ("lander3d", 65536, "near_hover"),
+                     ("lander3d", 4194304, "uniform")}
     assert d["config5"]["envs"] == 65536 and d["config5"]["substeps"] == 10
     for k in ("rollout_random", "rollout_policy_linear", "served_producers_ahead", "rollout_custom", "dependent_launch_floor"):
         assert k not in d, k
@@ -241,6 +243,8 @@ def test_two_ranks_sharing_the_one_gpu_run_the_n_rank_path_on_real_kernels(tmp_p
     assert abs(d["value"] - 32768 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["value"] > 1e9
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 176 * 16384 and "cpu_baseline" not in d
     assert set(d["summary"]["k_step_us"]) == {"step_many", "rollout_pid"}
+    # north_star's other action law on the same shards (constant thrust: no episode finishes, no slower than the headline)
+    assert d["value_constant_thrust"] > 0.9 * d["value"]
     assert "sharing device 0" in p.stderr
     if d["status"] == "degraded":          # RCCL refused the shared device (what ROCm 7's RCCL does)
         assert p.returncode != 0 and "exitcode  : 3" in p.stderr.replace("exitcode:", "exitcode  :")      # (torchrun reports its ranks' code)
