@@ -32,10 +32,11 @@ Rank 0 prints ONE COMPACT JSON line on stdout (<= 8 000 bytes, asserted here and
   summary      : <= 1.5 KB: roofline fraction per sweep point, us per step of the K-step paths, config 5's bounds
 and writes the FULL record (every leg with its clocks, region spreads, byte models, bounds and notes) to
 --full-out (default gpurun_out/bench_full.json) and to stderr.  The default run times the headline, its kernel-only span,
-the CPU baseline, Hover3D at 262 144 envs (BASELINE configs[2]), config 5 at 65 536 envs (configs[4]), the HBM-resident
+the CPU baseline, Hover3D at 262 144 envs (BASELINE configs[2]), config 5 at 65 536 envs (configs[4]), the headline's
+envs under the other two action laws (lander.py's constant thrust; near hover = the low-churn variant), the HBM-resident
 Lander3D point (4 M envs) and the two K-steps-per-launch paths on the headline's envs (cs_step_many: open loop over the
 resident action ring; cs_rollout_pid: closed loop under the on-device PID heuristic) -- reported BESIDE the headline,
-never as `value`.  --full adds the rest of the sweep (other action laws, 262 144 / 1 M envs, Hover3D 1 M / 4 M, config 5
+never as `value`.  --full adds the rest of the sweep (262 144 / 1 M envs, Hover3D 1 M / 4 M, config 5
 at 1 M, the K-step kernels at 4 M), cs_rollout_random, the caller-compiled policy, the served leg and the launch floor.
 Multi-GPU: the env batch is sharded by contiguous env-id range with no data-path
 collective in the timed region ("scaling": "weak").  The barriers and the MAX over ranks run on a gloo
