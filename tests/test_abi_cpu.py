@@ -280,3 +280,25 @@ def test_env_pickles_as_its_constructor_keywords(monkeypatch):
     if not torch.cuda.is_available():            # the real constructor is reached and fails loudly without a device
         with pytest.raises(_lib.CopterStepError):
             pickle.loads(blob)
+
+
+def test_every_kernel_maps_tile_t_to_workgroup_t():
+    """The XCD-aware mapping of the design (profiles/r06_l2_retention.txt): tile t is worked on by
+    workgroup t in EVERY kernel that touches the state tiles, so the XCD that wrote a tile in one launch is the one that
+    reads it in the next and finds it in its L2 (x 1.5 at the headline size).  A kernel that permuted its tiles would
+    still be correct -- and would silently evict every other kernel's tiles.  So: the only uses of blockIdx in the
+    device sources are `tile = blockIdx.x` (or a plain per-workgroup output slot), never arithmetic on it."""
+    import re
+    srcs = [os.path.join(ROOT, "gym_copter_amd", "csrc", f) for f in sorted(os.listdir(os.path.join(ROOT, "gym_copter_amd", "csrc")))
+            if f.endswith((".hip", ".h"))] + [os.path.join(ROOT, "include", "copterstep_rollout.h"),
+                                              os.path.join(ROOT, "include", "copterstep_serve.h")]
+    uses = []
+    for path in srcs:
+        for ln in open(path):
+            code = ln.split("//")[0]
+            if "blockIdx" in code:
+                uses.append((os.path.basename(path), code.strip()))
+    assert len(uses) >= 12
+    for where, code in uses:
+        ok = re.search(r"\btile(_index)? = blockIdx\.x\b", code) or re.search(r"out\[2 \* \(size_t\)blockIdx\.x \+ [01]\]", code)
+        assert ok, "%s: blockIdx used other than as the tile index: %s" % (where, code)
