@@ -51,7 +51,13 @@ namespace {
 // no done list / final_obs, time limit folded into `terminated`, uniform vehicle, float64 motor
 // model, no rotor-inertia term): the optional features are compiled out instead of being skipped
 // by uniform branches.
-template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL>
+// FORM: how the four outputs leave -- kFormRuntime: what cs_step_io.output_form says, tested by a uniform branch;
+// kFormPacked: packed rows, known when the launcher picks the instantiation (the tuned kernels: what CopterVecEnv passes
+// up to 131 072 envs), so the plain-array code, its three pointers (SGPRs that were spilled to lanes of a VGPR and read
+// back for the stores) and the branch are not in the kernel: -2.1 % on the headline.  Plain arrays known at compile time
+// gain nothing (+-0.5 %) and stay with the runtime form.  (round 6, profiles/r06_ab_output_form.txt)
+enum { kFormRuntime = 0, kFormPacked = 1 };
+template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL, int FORM>
 __device__ __forceinline__ void step_body(
     char* const tiles, const uint32_t n_envs, const uint32_t output_form, const float* const actions_dev,
     float* const obs_dev, float* const reward_dev, uint8_t* const terminated_dev, uint8_t* const truncated_dev,
@@ -127,7 +133,8 @@ __device__ __forceinline__ void step_body(
   store_env<MODE, TILE>(c, tile, e);
   if (o.stats) tile.store_ret(e.ep_ret);
   if (o.ticks) tile.store_ticks(e.ticks);
-  if (io.output_form == CS_OUTPUT_PACKED_ROWS) {  // uniform and preloaded; AUTO was resolved by the launcher
+  // (uniform and preloaded; AUTO was resolved by the launcher)
+  if (FORM == kFormPacked || (FORM == kFormRuntime && io.output_form == CS_OUTPUT_PACKED_ROWS)) {
     float row2[OBS + 2];
 #pragma unroll
     for (int k = 0; k < OBS; ++k) row2[k] = out.row[k];
@@ -160,9 +167,9 @@ __device__ __forceinline__ void step_body(
       float *const obs_dev, float *const reward_dev, uint8_t *const terminated_dev,                       \
       uint8_t *const truncated_dev, const uint64_t kernarg_pad, const DevConst c, const DevState s_rest,  \
       const cs_step_io io_rest
-template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL>
+template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL, int FORM>
 __global__ __launch_bounds__(kBlock) void step_kernel(CS_STEP_ARGS) {
-  step_body<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL>(
+  step_body<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL, FORM>(
       tiles, n_envs, output_form, actions_dev, obs_dev, reward_dev, terminated_dev, truncated_dev, c, s_rest, io_rest);
 }
 
@@ -793,21 +800,28 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io_in,
   const bool lean = lean_config(c, s) && io.done_count_dev == nullptr && io.final_obs_dev == nullptr;
   const uint32_t nt_act_max = tune.nt_action_max_envs ? tune.nt_action_max_envs : kNtActionMaxEnvs;
   const uint32_t nt_state_min = tune.nt_state_min_envs ? tune.nt_state_min_envs : kNtStateMinEnvs;
-#define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL)                                                  \
-  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL>), grid, block, 0, \
-                     stream, s.tiles, s.n, io.output_form, io.actions_dev, io.obs_dev, io.reward_dev,      \
+#define CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL, FORM)                                                  \
+  hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL, FORM>), grid, block, 0, \
+                     stream, s.tiles, s.n, io.output_form, io.actions_dev, io.obs_dev, io.reward_dev,            \
                      io.terminated_dev, io.truncated_dev, (uint64_t)0, c, s, io)
+#define CS_STEP_F(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL)            \
+  do {                                                                  \
+    if (io.output_form == CS_OUTPUT_PACKED_ROWS)                        \
+      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL, kFormPacked);   \
+    else                                                                \
+      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL, kFormRuntime);  \
+  } while (0)
 #define CS_STEP_N(LEAN, STREAM_ACT, STREAM_STATE)       \
   do {                                                  \
     if (c.nsub == 1)                                    \
-      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, true);    \
+      CS_STEP_F(LEAN, STREAM_ACT, STREAM_STATE, true);  \
     else                                                \
-      CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, false);   \
+      CS_STEP_F(LEAN, STREAM_ACT, STREAM_STATE, false); \
   } while (0)
   if (!lean) {
-    CS_STEP(false, false, false, false);
+    CS_STEP(false, false, false, false, kFormRuntime);
   } else if constexpr (!is_tuned(TASK, MODE)) {
-    CS_STEP(true, false, false, false);
+    CS_STEP(true, false, false, false, kFormRuntime);
   } else if (s.n <= nt_act_max) {  // the state fits the L2s: keep the action stream out of them
     CS_STEP_N(true, true, false);
   } else if (s.n >= nt_state_min) {  // the state exceeds the Infinity Cache: stream it past the caches
@@ -816,6 +830,7 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io_in,
     CS_STEP_N(true, false, false);
   }
 #undef CS_STEP_N
+#undef CS_STEP_F
 #undef CS_STEP
   return hipGetLastError();
 }

@@ -41,11 +41,11 @@ for f in sorted(glob.glob(P + "/span_*.json")):
 
 # registers / occupancy of the default instantiations, appended to the summary so that the next regression is visible
 # (VERDICT round 5 #4): from the ISA listing of THIS tree (make -C gym_copter_amd/csrc asm)
-DEFAULTS = (("step_kernelILi0ELi0ELb1ELb1ELb0ELb1E", "step_kernel<lander3d, float32 words, lean, stream actions, one call>  headline, <= 98 304 envs"),
-            ("step_kernelILi0ELi0ELb1ELb0ELb0ELb1E", "step_kernel<lander3d, ..., no stream hints, one call>               98 304 < envs < 3.5 M"),
-            ("step_kernelILi0ELi0ELb1ELb0ELb1ELb1E", "step_kernel<lander3d, ..., stream state, one call>                  >= 3.5 M envs (the 4 M point)"),
-            ("step_kernelILi1ELi0ELb1ELb0ELb0ELb1E", "step_kernel<hover3d, ..., no stream hints, one call>                BASELINE configs[2]"),
-            ("step_kernelILi0ELi0ELb1ELb1ELb0ELb0E", "step_kernel<lander3d, ..., stream actions, substep loop>            BASELINE configs[4]"),
+DEFAULTS = (("step_kernelILi0ELi0ELb1ELb1ELb0ELb1ELi1E", "step_kernel<lander3d, float32 words, lean, stream actions, one call, packed rows>  headline, <= 98 304 envs"),
+            ("step_kernelILi0ELi0ELb1ELb0ELb0ELb1ELi0E", "step_kernel<lander3d, ..., no stream hints, one call, output form at run time>   98 304 < envs < 3.5 M, plain arrays"),
+            ("step_kernelILi0ELi0ELb1ELb0ELb1ELb1ELi0E", "step_kernel<lander3d, ..., stream state, one call, run-time form>                >= 3.5 M envs (the 4 M point)"),
+            ("step_kernelILi1ELi0ELb1ELb0ELb0ELb1ELi0E", "step_kernel<hover3d, ..., no stream hints, one call, run-time form>              BASELINE configs[2]"),
+            ("step_kernelILi0ELi0ELb1ELb1ELb0ELb0ELi1E", "step_kernel<lander3d, ..., stream actions, substep loop, packed rows>            BASELINE configs[4]"),
             ("step_many_kernelILi0ELi0ELb1ELi0ELb1ELi2E", "step_many_kernel<lander3d, ..., open loop, per-lane rows + unconditional outputs>   cs_step_many, <= 65 536 envs"),
             ("step_many_kernelILi0ELi0ELb1ELi4ELb1ELi2E", "step_many_kernel<lander3d, ..., PID (upstream's terms), same form>                   cs_rollout_pid"),
             ("step_many_kernelILi0ELi0ELb1ELi2ELb1ELi2E", "step_many_kernel<lander3d, ..., random policy, same form>                             cs_rollout_random"),

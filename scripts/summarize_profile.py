@@ -27,7 +27,7 @@ def short(name):
     return re.sub(r"\(.*$", "", name)[:96]
 
 
-# the instantiations: step_kernel<task, mode, lean, stream actions, stream state, one call>
+# the instantiations: step_kernel<task, mode, lean, stream actions, stream state, one call, output form (1 = packed rows)>
 TASKS = {"0": "lander3d", "1": "hover3d"}
 
 # ---- 1. kernel trace grouped by (kernel, grid): every sweep point has its own row --------------------------
@@ -47,7 +47,7 @@ for sub, label in (("trace", "bench default command (65 536 envs + sweep + confi
     table = []
     for (name, grid), d in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         d = np.array(d)
-        m = re.search(r"step_kernel<(\d), (\d), (true|false), (true|false), (true|false), (true|false)>", name)
+        m = re.search(r"step_kernel<(\d), (\d), (true|false), (true|false), (true|false), (true|false)(?:, \d)?>", name)
         frac = ""
         if m and len(d) >= 20:
             envs = grid          # one thread per env, whole tiles
