@@ -52,9 +52,10 @@ namespace {
 // model, no rotor-inertia term): the optional features are compiled out instead of being skipped
 // by uniform branches.
 // FORM: how the four outputs leave -- kFormRuntime: what cs_step_io.output_form says, tested by a uniform branch;
-// kFormPacked: packed rows, known when the launcher picks the instantiation (the tuned kernels: what CopterVecEnv passes
-// up to 131 072 envs), so the plain-array code, its three pointers (SGPRs that were spilled to lanes of a VGPR and read
-// back for the stores) and the branch are not in the kernel: -2.1 % on the headline.  Plain arrays known at compile time
+// kFormPacked: packed rows of WHOLE tiles at a 16-byte aligned base, known when the launcher picks the instantiation (the
+// tuned kernels: what CopterVecEnv passes up to 131 072 envs), so the plain-array code, its three pointers (SGPRs that
+// were spilled to lanes of a VGPR and read back for the stores), the branch and the ragged-tile tests are not in the
+// kernel: -2.1 % on the headline.  Plain arrays known at compile time
 // gain nothing (+-0.5 %) and stay with the runtime form.  (round 6, profiles/r06_ab_output_form.txt)
 enum { kFormRuntime = 0, kFormPacked = 1 };
 template <int TASK, int MODE, bool LEAN, bool STREAM_ACT, bool STREAM_STATE, bool ONE_CALL, int FORM>
@@ -91,7 +92,8 @@ __device__ __forceinline__ void step_body(
   const uint32_t i = tile_index * kBlock + threadIdx.x;
   const uint32_t n = s.n;
   const uint32_t env0 = i - lane;
-  const bool valid = i < n;  // lanes past the end run on zeroed padding and never write out
+  // lanes past the end run on zeroed padding and never write out (kFormPacked: whole tiles, no such lane)
+  const bool valid = FORM == kFormPacked ? true : i < n;
   using TILE = TileIO<MODE, STREAM_STATE>;
   const TILE tile(s, tile_index, lane);
   CS_SPAN_BEGIN();
@@ -140,7 +142,7 @@ __device__ __forceinline__ void step_body(
     for (int k = 0; k < OBS; ++k) row2[k] = out.row[k];
     row2[OBS] = (float)out.reward;
     row2[OBS + 1] = __uint_as_float((out.term ? 1u : 0u) | (out.trunc ? 0x100u : 0u));  // bytes 0 / 1 = the two flags
-    write_rows<OBS + 2>(io.obs_dev, lds, lane, env0, n, valid, row2);
+    write_rows<OBS + 2, FORM == kFormPacked>(io.obs_dev, lds, lane, env0, n, valid, row2);
   } else {
     if (valid) {
       if (io.reward_dev) CS_NT_STORE((float)out.reward, at32<float>(io.reward_dev, i << 2));
@@ -804,9 +806,11 @@ hipError_t step_t(const DevConst& c, const DevState& s, const cs_step_io& io_in,
   hipLaunchKernelGGL((step_kernel<TASK, MODE, LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL, FORM>), grid, block, 0, \
                      stream, s.tiles, s.n, io.output_form, io.actions_dev, io.obs_dev, io.reward_dev,            \
                      io.terminated_dev, io.truncated_dev, (uint64_t)0, c, s, io)
+  const bool packed_whole = io.output_form == CS_OUTPUT_PACKED_ROWS && s.n % (uint32_t)kBlock == 0u &&
+                            (reinterpret_cast<uintptr_t>(io.obs_dev) & 15u) == 0;
 #define CS_STEP_F(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL)            \
   do {                                                                  \
-    if (io.output_form == CS_OUTPUT_PACKED_ROWS)                        \
+    if (packed_whole)                                                   \
       CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL, kFormPacked);   \
     else                                                                \
       CS_STEP(LEAN, STREAM_ACT, STREAM_STATE, ONE_CALL, kFormRuntime);  \

@@ -11,14 +11,16 @@ namespace {
 // Each lane deposits its OBS floats at row `lane`; the wavefront then streams the
 // 64*OBS contiguous floats out as 16-byte-per-lane stores (1 KiB per instruction).
 // ---------------------------------------------------------------------------------
-template <int OBS>
+// WHOLE: the launcher has checked that `out` is there, 16-byte aligned, and that every tile is whole (n a multiple of
+// 64): the three tests and the ragged path are not in the kernel (the packed-rows instantiations of step_kernel).
+template <int OBS, bool WHOLE = false>
 __device__ __forceinline__ void write_rows(float* __restrict__ out, float* lds_wave, int lane,
                                            uint32_t env0, uint32_t n, bool valid,
                                            const float (&row)[OBS]) {
-  if (out == nullptr) return;
+  if (!WHOLE && out == nullptr) return;
   // full wavefront (a wavefront past the end has env0 >= n) and a 16-byte aligned block: the K-step
   // kernels offset `out` by k*n*OBS floats, which an odd n leaves only 8-byte aligned
-  const bool vec_ok = env0 + (uint32_t)kWave <= n && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const bool vec_ok = WHOLE || (env0 + (uint32_t)kWave <= n && (reinterpret_cast<uintptr_t>(out) & 15u) == 0);
   if (vec_ok) {
 #pragma unroll
     for (int j = 0; j < OBS; j += 2) {
