@@ -63,7 +63,7 @@ __device__ __forceinline__ float4 draw_action(const DevConst& c, uint32_t i, uin
 // guard field holds significant bits 25..29, i.e. bits 28..24 of the float64 mantissa's low dword
 // (field j of a packed guard word sits at bit 5j).  round_stored() = float64 register -> the
 // float64 value the stored representation decodes to (what the next step and this step's
-// reward / termination logic see); words6() / pack_guards6() = such values -> words + guard fields;
+// reward / termination logic see); words12() / pack_guards6() = such values -> words + guard fields;
 // decode_word() the inverse.
 // ---------------------------------------------------------------------------------
 template <int MODE>
@@ -107,31 +107,37 @@ __device__ __forceinline__ uint32_t guard_of(double value) {
   }
 }
 
-// The float32 words of six stored values in one go (CS_STATE_F32G): a stored value has 29
+// The float32 words of stored values (CS_STATE_F32G): a stored value has 29
 // significant bits, its word is the value truncated to 24 -- v_cvt_f32_f64 under round-toward-zero
 // (the conversion follows MODE.fp_round[1:0], the float32 field: tools/ubench.hip), which saves the
-// and + register-pair copy per component that masking the low dword first would cost.  Six per block
-// (one half of the rigid body): fewer registers live at once than a block of twelve.
-__device__ __forceinline__ void words_of_rtz6(const double* v, float* w) {
+// and + register-pair copy per component that masking the low dword first would cost.
+// All twelve of an env under ONE switch of the rounding mode (until round 6: two blocks of six, which the scheduler put
+// back to back anyway -- mode reset, mode set: ~27 cycles for nothing; the twelve values are live at the end of a step
+// either way: 72 VGPRs before and after).  -0.2 ... -0.4 % per step, profiles/r06_ab_output_form.txt section 4.
+__device__ __forceinline__ void words_of_rtz12(const double* v, float* w) {
   asm volatile(
       "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
       "s_nop 0\n\t"
-      "v_cvt_f32_f64 %0, %6\n\tv_cvt_f32_f64 %1, %7\n\tv_cvt_f32_f64 %2, %8\n\t"
-      "v_cvt_f32_f64 %3, %9\n\tv_cvt_f32_f64 %4, %10\n\tv_cvt_f32_f64 %5, %11\n\t"
+      "v_cvt_f32_f64 %0, %12\n\tv_cvt_f32_f64 %1, %13\n\tv_cvt_f32_f64 %2, %14\n\t"
+      "v_cvt_f32_f64 %3, %15\n\tv_cvt_f32_f64 %4, %16\n\tv_cvt_f32_f64 %5, %17\n\t"
+      "v_cvt_f32_f64 %6, %18\n\tv_cvt_f32_f64 %7, %19\n\tv_cvt_f32_f64 %8, %20\n\t"
+      "v_cvt_f32_f64 %9, %21\n\tv_cvt_f32_f64 %10, %22\n\tv_cvt_f32_f64 %11, %23\n\t"
       "s_nop 0\n\t"
       "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
-      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5])
-      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]));
+      : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]),
+        "=&v"(w[8]), "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11])
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+        "v"(v[10]), "v"(v[11]));
 }
 
 // float32 / float64 words of already rounded values
 template <int MODE>
-__device__ __forceinline__ void words6(const double* v, typename ModeOf<MODE>::T* w) {
+__device__ __forceinline__ void words12(const double* v, typename ModeOf<MODE>::T* w) {
   if constexpr (MODE == CS_STATE_F32G) {
-    words_of_rtz6(v, w);
+    words_of_rtz12(v, w);
   } else {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w[k] = (typename ModeOf<MODE>::T)v[k];
+    for (int k = 0; k < 12; ++k) w[k] = (typename ModeOf<MODE>::T)v[k];
   }
 }
 // packed guard fields of six already rounded values (one v_bfe_u32 + one v_lshl_or_b32 each)

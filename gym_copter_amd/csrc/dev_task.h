@@ -235,8 +235,7 @@ template <int MODE, class TILE>
 __device__ __forceinline__ void store_env(const DevConst& c, const TILE& tile, const Env<MODE>& e) {
   using T = typename ModeOf<MODE>::T;
   T w[12];
-  words6<MODE>(e.x, w);
-  words6<MODE>(e.x + 6, w + 6);
+  words12<MODE>(e.x, w);
   const uint32_t gT = pack_guards6<MODE>(e.x) | ((uint32_t)e.fs << kStatusShift);
   // (the far flag also for a carry that finish_carry() is about to move into the EPH row: 0 - over has bit 31 set for
   // every over in [1, 2^31]; a compare + select here instead took the one-step kernels from 71-73 to 75-77 VGPRs, round 6)
