@@ -444,15 +444,17 @@ __device__ __forceinline__ void advance(const DevConst& c, const Coef& q, const 
   CS_KSTAMP(CS_KST(o), 3);  // Dynamics.setMotors done
   // ---- round to the stored precision; everything below sees exactly what is stored ----
   // The float32 observation row = round-to-nearest of the stored value (slots FIRST .. FIRST+OBS-1).  ROW_LATE (the lean
-  // K-step loops, which are bound by their instruction count): converted once, AFTER the masked reset has put the fresh
-  // state into e.x -- the same values ((float)(double)w0 == (float)w0) without the OBS moves that overwrite the row in
-  // every step in which any lane of the wavefront resets.  (SAME_STEP's final_obs needs the pre-reset row: not LEAN.)
+  // kernels: at one wavefront per SIMD they pay for every executed instruction): converted once, AFTER the masked reset
+  // has put the fresh state into e.x -- the same values ((float)(double)w0 == (float)w0) without the OBS moves that
+  // overwrite the row in every step in which any lane of the wavefront resets -- under BASELINE's uniform actions that
+  // is every step.  First in the K-step loops; the one-launch kernels followed late in round 6 (headline -1.1 %,
+  // configs[4] -2.1 %: profiles/r06_ab_output_form.txt section 6).  (SAME_STEP's final_obs needs the pre-reset row: not LEAN.)
   // Not in kernels that fuse a CALLER'S policy (CS_NO_ROW_LATE, set by include/copterstep_rollout.h): there the form is
   // worth 1-2 % for a light policy and cost a register-hungry one (a per-lane MLP at 410 registers) 30 %.
 #ifdef CS_NO_ROW_LATE
   constexpr bool ROW_LATE = false;
 #else
-  constexpr bool ROW_LATE = IN_LOOP && LEAN;
+  constexpr bool ROW_LATE = LEAN;
 #endif
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
