@@ -154,6 +154,53 @@ def test_numpy_returns_are_the_callers_to_keep_unless_copy_is_off():
 # ---------------------------------------------------------------------------------------
 # interleaved flags (include/copterstep.h, cs_step_io): truncated == terminated + 1
 # ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task", ["lander3d", "hover3d"])
+def test_packed_rows_of_whole_tiles_pick_the_compile_time_form_and_agree_with_the_others(task):
+    """Round 6: the tuned step kernels are instantiated by output form -- packed rows of WHOLE tiles at a 16-byte aligned
+    base run the instantiation without the other form's pointers, branch and ragged-tile tests (the launcher checks;
+    copterstep_kernels.hip: kFormPacked).  Same batch (256 envs = four whole tiles, uniform actions so that lanes finish
+    and reset in every step), four twins: (A) packed rows at an aligned base, (B) packed rows 8 bytes off (the run-time
+    form and its unaligned row path), (C) plain arrays, (D) packed rows of 255 envs + one env more would be ragged --
+    here: the first 255 rows of a 255-env twin of the same seed agree as well.  Canary words stay untouched."""
+    import torch
+    import gym_copter_amd
+    from gym_copter_amd.sharded import row_views
+    n = 256
+    kw = dict(task=task, state_dtype="float32", seed=5, autoreset_mode="next_step")
+    envs = [gym_copter_amd.CopterVecEnv(num_envs=n, **kw) for _ in range(3)] + [gym_copter_amd.CopterVecEnv(num_envs=n - 1, **kw)]
+    dev, od, ad = envs[0].device, envs[0].obs_dim, envs[0].action_dim
+    bufs = []
+    for e, off, rows_n in ((envs[0], 16, n), (envs[1], 18, n), (envs[3], 16, n - 1)):     # offsets in floats: 64 / 72 bytes
+        gr = torch.full((rows_n * (od + 2) + 64,), float("nan"), device=dev)
+        assert gr.data_ptr() % 16 == 0
+        rows = gr[off:off + rows_n * (od + 2)].view(rows_n, od + 2)
+        rows.zero_()
+        e.bind_outputs(*row_views(rows, od))
+        bufs.append((gr, off, rows_n))
+    assert envs[0]._obs.data_ptr() % 16 == 0 and envs[1]._obs.data_ptr() % 16 == 8
+    envs[2].bind_outputs(torch.zeros((n, od), device=dev), torch.zeros(n, device=dev),
+                         torch.zeros(n, dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev))
+    for e in envs:
+        e.reset()
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    finished = 0
+    for t in range(40):
+        act = torch.rand((n, ad), generator=g, device=dev) * 2 - 1
+        res = [e.step(act if e.num_envs == n else act[:n - 1]) for e in envs]
+        for other in res[1:3]:
+            for k in range(4):
+                assert torch.equal(res[0][k], other[k]), (t, k)
+        for k in range(4):
+            assert torch.equal(res[0][k][:n - 1], res[3][k]), (t, k)
+        finished += int(res[0][2].sum())
+    assert finished > n            # (every env finished more than once: the reset path ran in every step)
+    for gr, off, rows_n in bufs:
+        assert bool(torch.isnan(gr[:off]).all()) and bool(torch.isnan(gr[off + rows_n * (od + 2):]).all())
+    for e in envs:
+        e.close()
+
+
 @pytest.mark.parametrize("task,mode,trunc", [("lander3d", "float32", False), ("hover3d", "float64", True),
                                              ("lander2d", "float32", True), ("hover1d", "float32", False)])
 def test_output_forms_agree_packed_rows_interleaved_flags_separate_arrays(task, mode, trunc):
