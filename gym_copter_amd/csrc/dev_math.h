@@ -142,7 +142,7 @@ struct Trig {
 // __all() without its detour through an integer: HIP's __all(p) turns p into 0 / 1 in a vector register and compares that
 // again (v_cndmask + v_cmp per call); a ballot of the NEGATED predicate against zero is scalar work on the compare's own
 // mask.  Same meaning: true iff p holds on every ACTIVE lane.  Used in the K-step loops (bound by their instruction
-// count); the one-launch kernels keep __all -- their schedule is frozen.
+// count); the one-launch kernels keep __all: the ballot form measured +-0.1 % there (profiles/r06_ab_kstep_instruction_count.txt, D).
 __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
 // IN_LOOP: the call sits in a K-step loop, where laying the in-range path out as the fall-through pays
 // (-3 % per step); in the one-step kernel the same layout measured +2.5 %, so it keeps the compiler's
